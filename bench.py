@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""STLT forward throughput on MI355X: clips/s of the whole hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; clips are independent, so each rank runs its own shard of the batch with no data-path
+collective (weak scaling: per-GPU batch fixed).  A step = one Stlt.forward over the rank's resident batch.
+Rank 0 prints ONE JSON line.  After the timed region the same steps are replayed with hipEvents around every
+kernel launch (library-side, on the launch stream) for the `roofline` objects, and — at N=1 — the CPU oracle
+is timed on a bounded sample for `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "revisiting-spatial-temporal-layouts_amd"
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X f32-input MFMA dense peak (MI355X_MICROARCH.md, Chip-level parameters)
+HBM_PEAK_GBS = 8000.0         # HBM3E spec peak
+
+
+def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only):
+    """FLOPs the GEMM launches of one forward actually execute (2*M*N*K summed over launches)."""
+    tok, bt = B * T * N, B * T
+    per_row = 24.0 * d * d  # qkv 6d^2 + out 2d^2 + ffn 16d^2
+    full_sp = n_sp - 1 if (cls_only and N > 1 and n_sp > 0) else n_sp
+    f = full_sp * tok * per_row
+    if full_sp != n_sp:
+        f += tok * 4.0 * d * d + bt * 20.0 * d * d  # K,V for every token; Q/out-proj/FFN for the CLS rows
+    f += n_tp * bt * per_row
+    f += B * (2.0 * d * d + 2.0 * d * classes)
+    return f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cls-only", action="store_true", help="run the last spatial layer on every token")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier + max-over-ranks only
+
+    importlib.import_module("__graft_entry__").build() if rank == 0 else None
+    if dist is not None:
+        dist.barrier()
+    pkg = importlib.import_module(PKG)
+    c = pkg.synth.CONFIGS[args.config]
+    kw = pkg.synth.model_kwargs(args.config)
+    model = pkg.Stlt(pkg.StltModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    model.load_state_dict(sd)
+    model.train(False)
+    model.to(dev)
+    model.backbone.cls_only_last_spatial = not args.no_cls_only
+    B, T, N, d = args.batch, c["T"], c["N"], c["hidden_size"]
+    cpu_batch = pkg.synth.make_batch(B, T, N, dataset=c["dataset"], seed=1000 + rank)
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+
+    def step():
+        with torch.no_grad():
+            return model(batch)["stlt"]
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    clips_per_s = world * B * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations: hipEvents around every launch inside the library, same workload
+        pkg.ops.prof_enable(True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        prof = pkg.ops.prof_collect()
+        pkg.ops.prof_enable(False)
+        k_ms = {k: (ms / args.steps, int(n / args.steps)) for k, (ms, n) in prof.items()}
+        gemm_ms, gemm_n = k_ms["gemm"]
+        gflops = gemm_flops_per_step(B, T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"],
+                                     not args.no_cls_only)
+        gemm_tflops = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        at_ms, at_n = k_ms["attn_temporal"]
+        at_bytes = B * (16.0 * T * d + T)  # per launch: read packed QKV, write ctx, kpm byte
+        at_gbs = at_bytes / (at_ms / max(at_n, 1) * 1e-3) / 1e9 if at_ms > 0 else 0.0
+        as_ms, as_n = k_ms["attn_spatial"]
+        as_bytes = B * (16.0 * T * N * d + T * N)
+        as_gbs = as_bytes / (as_ms / max(as_n, 1) * 1e-3) / 1e9 if as_ms > 0 else 0.0
+        out = {
+            "metric": "clips/s STLT forward (T=32, N_obj=7, d=768)" if args.config == "cfg2" else f"clips/s STLT forward ({args.config})",
+            "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: STLT forward, T={T}, N={N}, d={d}, H={c['num_attention_heads']}, "
+                                   f"{c['num_spatial_layers']}+{c['num_temporal_layers']} layers, {c['num_classes']} classes",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collective",
+                       "cls_only_last_spatial": not args.no_cls_only,
+                       "flops_per_clip_dense": pkg.synth.flops_per_clip(T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"])},
+            "roofline": {"kernel": "gemm_nt_kernel (f32 MFMA nn.Linear)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
+            "roofline_attn_temporal": {"kernel": "attn_core_kernel (causal, L=T)", "bound": "hbm", "achieved": round(at_gbs, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at_gbs / HBM_PEAK_GBS, 4),
+                                       "traffic": None, "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
+            "roofline_attn_spatial": {"kernel": "attn_core_kernel (key padding, L=N)", "bound": "hbm", "achieved": round(as_gbs, 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(as_gbs / HBM_PEAK_GBS, 4),
+                                      "traffic": None, "launches_per_step": as_n, "us_per_launch": round(as_ms / max(as_n, 1) * 1e3, 2)},
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import stlt_oracle as O
+            nb = min(8, B)
+            sample = {k: v[:nb] for k, v in cpu_batch.items()}
+            threads = torch.get_num_threads()
+            with torch.no_grad():
+                ref = O.stlt_forward(sd, sample, c["num_attention_heads"])["stlt"]  # warm-up + parity sample
+                n_it, t1 = 0, time.perf_counter()
+                while n_it < 3 or (time.perf_counter() - t1 < 10.0 and n_it < 200):
+                    O.stlt_forward(sd, sample, c["num_attention_heads"])
+                    n_it += 1
+                cpu_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(nb * n_it / cpu_s, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+                                   "sample": f"oracle/stlt_oracle.py (torch {torch.__version__} CPU fp32), {n_it} forwards of "
+                                             f"{nb} clips of the same workload, host cores={os.cpu_count()}"}
+            out["logit_max_abs_diff"] = float((logits[:nb].cpu() - ref).abs().max())
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

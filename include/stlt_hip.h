@@ -1,0 +1,142 @@
+/*
+ * stlt_hip.h — C-ABI of libstlt_hip.so: the MI355X (gfx950) STLT forward hot path.
+ *
+ * The reference (gorjanradevski/revisiting-spatial-temporal-layouts) has no FFI: its boundary is the
+ * Python class surface of src/modelling/models.py.  This header is the inner boundary the drop-in
+ * `Stlt` / `StltBackbone` modules bind through ctypes; every entry point names the reference code it
+ * replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C"; every function returns 0 on success, a negative STLT_E* code on argument errors,
+ *     or a positive hipError_t; stlt_last_error() returns a thread-local message.
+ *   - all tensor arguments are raw DEVICE pointers owned by the caller (PyTorch allocations); the
+ *     library never allocates, frees or retains them.  fp32, row-major, contiguous unless a leading
+ *     dimension (ld*) is given in ELEMENTS.  ids/lengths int64, masks uint8 (1 = padded / masked).
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no implicit synchronisation; safe to
+ *     capture in a hipGraph.  Re-entrant: no mutable global state besides the error string.
+ */
+#ifndef STLT_HIP_H
+#define STLT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STLT_VERSION 100
+
+#define STLT_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define STLT_EWORKSPACE (-2) /* workspace too small */
+
+#define STLT_ACT_NONE 0
+#define STLT_ACT_GELU 1  /* exact erf GELU */
+
+typedef void* stlt_stream_t; /* hipStream_t */
+
+int stlt_version(void);
+const char* stlt_last_error(void);
+
+/* K1 — CategoryBoxEmbeddings.forward, src/modelling/models.py:29-39.
+ * out[t,:] = LN_eps( cat_table[categories[t]] + boxes[t,0:4]·box_w^T + box_b (+ scores[t]*score_w[:,0] + score_b) )
+ * scores may be NULL (key absent from the batch, models.py:33).  d % 4 == 0, d <= 2048. */
+int stlt_embed_fwd(const int64_t* categories, const float* boxes, const float* scores,
+                   const float* cat_table, int64_t n_categories,
+                   const float* box_w, const float* box_b, const float* score_w, const float* score_b,
+                   const float* ln_w, const float* ln_b, float eps,
+                   int64_t n_tokens, int64_t d, float* out, stlt_stream_t stream);
+
+/* K2/K4/K5/K6/K8 — nn.Linear (F.linear inside F.multi_head_attention_forward, linear1/linear2 of
+ * nn.TransformerEncoderLayer as configured at models.py:46-52,118-124; fc1/fc2 models.py:158-163).
+ * y[m, n] = act( sum_k x[m*ldx + k] * w[n*K + k] + bias[n] ),  w is (N,K) row-major (torch (out,in)).
+ * K % 32 == 0; M, N arbitrary.  f32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate. */
+int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias,
+                    float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, stlt_stream_t stream);
+
+/* K3 — attention core of F.multi_head_attention_forward as reached from models.py:68-71 (spatial,
+ * key-padding mask) and models.py:146-150 (temporal, causal mask of utils/model_utils.py:4-7 + key padding).
+ * qkv: (S*L, 3*H*dh) packed rows [q;k;v]; ctx: (S*L, H*dh).  kpm: (S*L) bytes, 1 = key masked.
+ * ctx[s,i,h,:] = softmax_j( q_i·k_j/sqrt(dh) + M_ij ) v_j with M_ij = -inf if kpm[s,j] or (causal and j>i).
+ * Rows whose keys are all masked produce zeros.  dh == 64. */
+int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal,
+                       int64_t S, int64_t L, int64_t H, int64_t dh, float* ctx, stlt_stream_t stream);
+
+/* Residual + LayerNorm (norm1/norm2 of nn.TransformerEncoderLayer, eps 1e-5; ClassificationHead.layer_norm
+ * models.py:159,163 with res == NULL).  out[m,:] = LN_eps( x[m*ldx + :] + res[m*ldres + :] ). */
+int stlt_add_layernorm_fwd(const float* x, int64_t ldx, const float* res, int64_t ldres,
+                           const float* ln_w, const float* ln_b, float eps,
+                           int64_t M, int64_t d, float* out, int64_t ldout, stlt_stream_t stream);
+
+/* K7 — CLS select (models.py:79) + FramesEmbeddings.forward (models.py:98-111).
+ * out[b,t,:] = LN_eps( spatial[(b*T+t)*row_stride + :] + pos_table[t] + type_table[frame_types[b,t]] ). */
+int stlt_frames_embed_fwd(const float* spatial, int64_t row_stride, const int64_t* frame_types,
+                          const float* pos_table, const float* type_table,
+                          const float* ln_w, const float* ln_b, float eps,
+                          int64_t B, int64_t T, int64_t d, float* out, stlt_stream_t stream);
+
+/* K8a — Stlt.forward gather, models.py:189-192: out[b,:] = x[b, lengths[b]-1, :] for batch-major x (B,T,d). */
+int stlt_gather_last_fwd(const float* x, const int64_t* lengths, int64_t B, int64_t T, int64_t d,
+                         float* out, stlt_stream_t stream);
+
+/* ---- whole-path entry points (host-side orchestration in native code) ---- */
+
+typedef struct {
+  const float *in_proj_w, *in_proj_b;   /* (3d,d) rows [q;k;v], (3d) */
+  const float *out_proj_w, *out_proj_b; /* (d,d), (d) */
+  const float *lin1_w, *lin1_b;         /* (4d,d), (4d) */
+  const float *lin2_w, *lin2_b;         /* (d,4d), (d) */
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* (d) each, eps 1e-5 */
+} stlt_layer_params;
+
+typedef struct {
+  int64_t d, H, n_categories, n_spatial, n_temporal, n_classes, n_positions;
+  float ln_eps; /* config.layer_norm_eps (1e-12) — the three explicit LayerNorms only */
+  const float *cat_emb, *box_w, *box_b, *score_w, *score_b, *emb_ln_w, *emb_ln_b; /* models.py:19-27 */
+  const float *pos_emb, *type_emb, *frames_ln_w, *frames_ln_b;                    /* models.py:88-93 */
+  const stlt_layer_params* spatial;  /* HOST array [n_spatial]  (models.py:53-55) */
+  const stlt_layer_params* temporal; /* HOST array [n_temporal] (models.py:126-128) */
+  const float *fc1_w, *fc1_b, *head_ln_w, *head_ln_b, *fc2_w, *fc2_b; /* models.py:158-160; may be NULL for backbone-only */
+} stlt_params;
+
+typedef struct {
+  int64_t B, T, N;
+  const int64_t* categories;   /* (B,T,N) */
+  const float* boxes;          /* (B,T,N,4) */
+  const float* scores;         /* (B,T,N) or NULL */
+  const uint8_t* kpm_boxes;    /* (B,T,N)  src_key_padding_mask_boxes */
+  const int64_t* frame_types;  /* (B,T) */
+  const uint8_t* kpm_frames;   /* (B,T)    src_key_padding_mask_frames */
+  const int64_t* lengths;      /* (B) */
+} stlt_inputs;
+
+#define STLT_FLAG_CLS_ONLY_LAST_SPATIAL 1 /* last spatial layer: Q/out-proj/FFN on the CLS rows only (the only rows read, models.py:79) */
+
+/* bytes of scratch the whole-path calls need for this shape */
+size_t stlt_workspace_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes);
+
+/* StltBackbone.forward, models.py:136-152.  out_btd is batch-major (B,T,d); the module returns its (T,B,d) view. */
+int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
+                          int flags, float* out_btd, stlt_stream_t stream);
+
+/* Stlt.forward, models.py:185-195: backbone -> gather at lengths-1 -> ClassificationHead.  logits (B,n_classes).
+ * out_btd may be NULL (then the backbone output lives in the workspace). */
+int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
+                 int flags, float* out_btd, float* logits, stlt_stream_t stream);
+
+/* ---- per-kernel timing (bench.py roofline leg): hipEvents around every launch of the whole-path calls ---- */
+#define STLT_K_EMBED 0
+#define STLT_K_GEMM 1
+#define STLT_K_ATTN_SPATIAL 2
+#define STLT_K_ATTN_TEMPORAL 3
+#define STLT_K_ADDLN 4
+#define STLT_K_FRAMES 5
+#define STLT_K_GATHER 6
+#define STLT_K_COUNT 7
+int stlt_prof_enable(int on);                       /* 1: record events around each launch (serialises nothing, adds events) */
+int stlt_prof_collect(double* ms_out, int64_t* launches_out); /* sync events, accumulate per-kernel ms / launch counts, reset */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STLT_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libstlt_hip.so (include/stlt_hip.h).  No fallback: if the library is missing the import of
+any compute entry point raises, loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstlt_hip.so")
+
+K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "frames_embed", "gather_last")
+FLAG_CLS_ONLY_LAST_SPATIAL = 1
+ACT_NONE, ACT_GELU = 0, 1
+
+_f = C.POINTER(C.c_float)
+_i64 = C.POINTER(C.c_int64)
+_u8 = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, _vp) for n in (
+        "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+        "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
+
+
+class Params(C.Structure):
+    _fields_ = (
+        [(n, C.c_int64) for n in ("d", "H", "n_categories", "n_spatial", "n_temporal", "n_classes", "n_positions")]
+        + [("ln_eps", C.c_float)]
+        + [(n, _vp) for n in ("cat_emb", "box_w", "box_b", "score_w", "score_b", "emb_ln_w", "emb_ln_b",
+                              "pos_emb", "type_emb", "frames_ln_w", "frames_ln_b")]
+        + [("spatial", C.POINTER(LayerParams)), ("temporal", C.POINTER(LayerParams))]
+        + [(n, _vp) for n in ("fc1_w", "fc1_b", "head_ln_w", "head_ln_b", "fc2_w", "fc2_b")]
+    )
+
+
+class Inputs(C.Structure):
+    _fields_ = [("B", C.c_int64), ("T", C.c_int64), ("N", C.c_int64)] + [
+        (n, _vp) for n in ("categories", "boxes", "scores", "kpm_boxes", "frame_types", "kpm_frames", "lengths")]
+
+
+# symbol -> (restype, argtypes); the not-gpu tests check that every one of these is exported
+SIGNATURES = {
+    "stlt_version": (C.c_int, []),
+    "stlt_last_error": (C.c_char_p, []),
+    "stlt_embed_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float,
+                                 C.c_int64, C.c_int64, _vp, _vp]),
+    "stlt_linear_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                  C.c_int, _vp]),
+    "stlt_attn_core_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
+    "stlt_add_layernorm_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_float, C.c_int64, C.c_int64,
+                                         _vp, C.c_int64, _vp]),
+    "stlt_frames_embed_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64,
+                                        C.c_int64, _vp, _vp]),
+    "stlt_gather_last_fwd": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
+    "stlt_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "stlt_backbone_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "stlt_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
+    "stlt_prof_enable": (C.c_int, [C.c_int]),
+    "stlt_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+class StltHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises StltHipError when the .so has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StltHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(or revisiting-spatial-temporal-layouts_amd/build.py). There is no CPU/PyTorch fallback for the STLT hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().stlt_last_error().decode("utf-8", "replace")
+        raise StltHipError(f"{what} failed ({code}): {msg}")

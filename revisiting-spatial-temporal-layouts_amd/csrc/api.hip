@@ -1,0 +1,268 @@
+// C-ABI of libstlt_hip.so (see include/stlt_hip.h): argument checks, error string, per-kernel event
+// timing, and the whole-path orchestration (StltBackbone.forward / Stlt.forward as a fixed launch sequence
+// on the caller's stream — no allocation, no synchronisation, graph-capturable).
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+struct ProfRec { int kid; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_event_pool;
+thread_local hipEvent_t g_open_start = nullptr;
+
+hipEvent_t get_event() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+int stlt_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int stlt_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return stlt_set_error((int)e, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+void stlt_prof_begin(int kid, hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_open_start = get_event();
+  (void)hipEventRecord(g_open_start, s);
+}
+
+void stlt_prof_end(int kid, hipStream_t s) {
+  if (!g_prof_on || !g_open_start) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEvent_t b = get_event();
+  (void)hipEventRecord(b, s);
+  g_prof_recs.push_back({kid, g_open_start, b});
+  g_open_start = nullptr;
+}
+
+extern "C" {
+
+int stlt_version(void) { return STLT_VERSION; }
+const char* stlt_last_error(void) { return g_err; }
+
+int stlt_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int stlt_prof_collect(double* ms_out, int64_t* launches_out) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int k = 0; k < STLT_K_COUNT; ++k) { if (ms_out) ms_out[k] = 0.0; if (launches_out) launches_out[k] = 0; }
+  for (auto& r : g_prof_recs) {
+    hipError_t e = hipEventSynchronize(r.b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) return stlt_set_error((int)e, "stlt_prof_collect: %s", hipGetErrorString(e));
+    if (r.kid >= 0 && r.kid < STLT_K_COUNT) { if (ms_out) ms_out[r.kid] += ms; if (launches_out) launches_out[r.kid] += 1; }
+    g_event_pool.push_back(r.a);
+    g_event_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  return 0;
+}
+
+int stlt_embed_fwd(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
+                   int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
+                   const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
+                   float* out, stlt_stream_t stream) {
+  return launch_embed(categories, boxes, scores, cat_table, n_categories, box_w, box_b, score_w, score_b, ln_w, ln_b,
+                      eps, n_tokens, d, out, (hipStream_t)stream);
+}
+
+int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
+                    int64_t N, int64_t K, int act, stlt_stream_t stream) {
+  return launch_linear(x, ldx, w, bias, y, ldy, M, N, K, act, (hipStream_t)stream);
+}
+
+int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
+                       float* ctx, stlt_stream_t stream) {
+  return launch_attn(qkv, kpm, causal, S, L, H, dh, ctx, causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL,
+                     (hipStream_t)stream);
+}
+
+int stlt_add_layernorm_fwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* ln_w,
+                           const float* ln_b, float eps, int64_t M, int64_t d, float* out, int64_t ldout,
+                           stlt_stream_t stream) {
+  return launch_add_layernorm(x, ldx, res, ldres, ln_w, ln_b, eps, M, d, out, ldout, (hipStream_t)stream);
+}
+
+int stlt_frames_embed_fwd(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
+                          const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B,
+                          int64_t T, int64_t d, float* out, stlt_stream_t stream) {
+  return launch_frames_embed(spatial, row_stride, frame_types, pos_table, type_table, ln_w, ln_b, eps, B, T, d, out,
+                             (hipStream_t)stream);
+}
+
+int stlt_gather_last_fwd(const float* x, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* out,
+                         stlt_stream_t stream) {
+  return launch_gather_last(x, lengths, B, T, d, out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ whole path
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout {
+  size_t x, x1, qkv, ctx, tmp, hh, head, total;
+};
+
+static WsLayout ws_layout(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes) {
+  const size_t tok = (size_t)B * T * N;  // spatial tokens >= temporal tokens
+  const size_t f = sizeof(float);
+  WsLayout w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  w.x = take(tok * d * f);
+  w.x1 = take(tok * d * f);
+  w.qkv = take(tok * 3 * d * f);
+  w.ctx = take(tok * d * f);
+  w.tmp = take(tok * d * f);
+  w.hh = take(tok * 4 * d * f);
+  w.head = take((size_t)B * (3 * d + n_classes) * f);
+  w.total = off;
+  return w;
+}
+
+size_t stlt_workspace_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes) {
+  if (B <= 0 || T <= 0 || N <= 0 || d <= 0) return 0;
+  return ws_layout(B, T, N, d, n_classes < 0 ? 0 : n_classes).total;
+}
+
+#define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+// One post-norm encoder layer (nn.TransformerEncoderLayer as configured at models.py:46-52,118-124) on M
+// compact rows of width d.  `out` may alias `x` (x is last read by the norm1 residual); x1 must not.
+static int encoder_layer(const stlt_layer_params& lp, int64_t d, int64_t H, const float* x, int64_t M, int64_t S,
+                         int64_t L, const uint8_t* kpm, int causal, int kid, float* qkv, float* ctx, float* tmp,
+                         float* x1, float* hh, float* out, hipStream_t s) {
+  TRY(launch_linear(x, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
+  TRY(launch_attn(qkv, kpm, causal, S, L, H, d / H, ctx, kid, s));
+  TRY(launch_linear(ctx, d, lp.out_proj_w, lp.out_proj_b, tmp, d, M, d, d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(tmp, d, x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, x1, d, s));
+  TRY(launch_linear(x1, d, lp.lin1_w, lp.lin1_b, hh, 4 * d, M, 4 * d, d, STLT_ACT_GELU, s));
+  TRY(launch_linear(hh, 4 * d, lp.lin2_w, lp.lin2_b, tmp, d, M, d, 4 * d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(tmp, d, x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, M, d, out, d, s));
+  return 0;
+}
+
+static int check_params(const stlt_params* p, const stlt_inputs* in, bool need_head) {
+  if (!p || !in) return stlt_set_error(STLT_EINVAL, "null params/inputs");
+  if (p->d <= 0 || p->H <= 0 || p->d % p->H != 0 || p->d / p->H != 64)
+    return stlt_set_error(STLT_EINVAL, "hidden_size %lld / heads %lld: head dim must be 64", (long long)p->d, (long long)p->H);
+  if (in->B <= 0 || in->T <= 0 || in->N <= 0) return stlt_set_error(STLT_EINVAL, "empty batch (B=%lld,T=%lld,N=%lld)", (long long)in->B, (long long)in->T, (long long)in->N);
+  if (in->T > p->n_positions) return stlt_set_error(STLT_EINVAL, "T=%lld exceeds the position table (%lld rows)", (long long)in->T, (long long)p->n_positions);
+  if (!in->categories || !in->boxes || !in->kpm_boxes || !in->frame_types || !in->kpm_frames)
+    return stlt_set_error(STLT_EINVAL, "null input tensor");
+  if (p->n_spatial < 0 || p->n_temporal < 0 || (p->n_spatial && !p->spatial) || (p->n_temporal && !p->temporal))
+    return stlt_set_error(STLT_EINVAL, "layer tables missing");
+  if (need_head && (!p->fc1_w || !p->fc1_b || !p->head_ln_w || !p->head_ln_b || !p->fc2_w || !p->fc2_b || !in->lengths || p->n_classes <= 0))
+    return stlt_set_error(STLT_EINVAL, "prediction head parameters / lengths missing");
+  return 0;
+}
+
+int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
+                          int flags, float* out_btd, stlt_stream_t stream) {
+  TRY(check_params(p, in, false));
+  if (!out_btd) return stlt_set_error(STLT_EINVAL, "stlt_backbone_forward: out_btd is null");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
+  const WsLayout w = ws_layout(B, T, N, d, p->n_classes < 0 ? 0 : p->n_classes);
+  if (!workspace || workspace_bytes < w.total)
+    return stlt_set_error(STLT_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
+  char* base = (char*)workspace;
+  float* x = (float*)(base + w.x);
+  float* x1 = (float*)(base + w.x1);
+  float* qkv = (float*)(base + w.qkv);
+  float* ctx = (float*)(base + w.ctx);
+  float* tmp = (float*)(base + w.tmp);
+  float* hh = (float*)(base + w.hh);
+
+  const int64_t tok = B * T * N, BT = B * T;
+  // K1
+  TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
+                   p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x, s));
+  // spatial transformer: sequences = frames (B*T), tokens = objects (N), key-padding mask only
+  const bool cls_only = (flags & STLT_FLAG_CLS_ONLY_LAST_SPATIAL) && p->n_spatial > 0 && N > 1;
+  const int64_t full_layers = cls_only ? p->n_spatial - 1 : p->n_spatial;
+  for (int64_t l = 0; l < full_layers; ++l)
+    TRY(encoder_layer(p->spatial[l], d, H, x, tok, BT, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, qkv, ctx, tmp, x1, hh, x, s));
+  const float* cls_rows = x;
+  int64_t cls_stride = N * d;
+  if (cls_only) {
+    // Only token 0 of each frame is read after the spatial transformer (models.py:79).  K and V are needed
+    // for every object token, Q / out-proj / FFN only for the B*T CLS rows (rows of stride N*d in x).
+    const stlt_layer_params& lp = p->spatial[p->n_spatial - 1];
+    TRY(launch_linear(x, d, lp.in_proj_w + d * d, lp.in_proj_b + d, qkv + d, 3 * d, tok, 2 * d, d, STLT_ACT_NONE, s));
+    TRY(launch_linear(x, N * d, lp.in_proj_w, lp.in_proj_b, qkv, N * 3 * d, BT, d, d, STLT_ACT_NONE, s));
+    // non-CLS query rows of qkv hold stale scratch; each attention output row depends on its own query row
+    // only, and only the CLS rows of ctx are read below.
+    TRY(launch_attn(qkv, in->kpm_boxes, 0, BT, N, H, d / H, ctx, STLT_K_ATTN_SPATIAL, s));
+    TRY(launch_linear(ctx, N * d, lp.out_proj_w, lp.out_proj_b, tmp, d, BT, d, d, STLT_ACT_NONE, s));
+    TRY(launch_add_layernorm(tmp, d, x, N * d, lp.norm1_w, lp.norm1_b, 1e-5f, BT, d, x1, d, s));
+    TRY(launch_linear(x1, d, lp.lin1_w, lp.lin1_b, hh, 4 * d, BT, 4 * d, d, STLT_ACT_GELU, s));
+    TRY(launch_linear(hh, 4 * d, lp.lin2_w, lp.lin2_b, tmp, d, BT, d, 4 * d, STLT_ACT_NONE, s));
+    TRY(launch_add_layernorm(tmp, d, x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, BT, d, ctx, d, s));
+    cls_rows = ctx;
+    cls_stride = d;
+  }
+  // K7: CLS select + position + frame type + LN -> (B,T,d).  x1 is free here (its last reader was the
+  // final norm2 above), x / ctx still hold the CLS rows being read.
+  float* tbuf = p->n_temporal > 0 ? x1 : out_btd;
+  TRY(launch_frames_embed(cls_rows, cls_stride, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w,
+                          p->frames_ln_b, p->ln_eps, B, T, d, tbuf, s));
+  // temporal transformer: sequences = clips (B), tokens = frames (T), causal + key padding.  Layers run in
+  // place on tbuf (a layer's input is last read by its norm1), x is the post-norm1 scratch; the last layer
+  // writes the caller's buffer.
+  for (int64_t l = 0; l < p->n_temporal; ++l) {
+    float* dst = (l == p->n_temporal - 1) ? out_btd : tbuf;
+    TRY(encoder_layer(p->temporal[l], d, H, tbuf, BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, qkv, ctx, tmp,
+                      x, hh, dst, s));
+  }
+  return 0;
+}
+
+int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes, int flags,
+                 float* out_btd, float* logits, stlt_stream_t stream) {
+  TRY(check_params(p, in, true));
+  if (!logits) return stlt_set_error(STLT_EINVAL, "stlt_forward: logits is null");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t B = in->B, T = in->T, N = in->N, d = p->d;
+  const WsLayout w = ws_layout(B, T, N, d, p->n_classes);
+  if (!workspace || workspace_bytes < w.total)
+    return stlt_set_error(STLT_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
+  char* base = (char*)workspace;
+  float* bb_out = out_btd ? out_btd : (float*)(base + w.x1);  // x1 doubles as the in-place temporal buffer
+  TRY(stlt_backbone_forward(p, in, workspace, workspace_bytes, flags, bb_out, stream));
+  float* h0 = (float*)(base + w.head);
+  float* h1 = h0 + (size_t)B * d;
+  float* h2 = h1 + (size_t)B * d;
+  TRY(launch_gather_last(bb_out, in->lengths, B, T, d, h0, s));                                   // models.py:189-192
+  TRY(launch_linear(h0, d, p->fc1_w, p->fc1_b, h1, d, B, d, d, STLT_ACT_GELU, s));                // gelu(fc1(h))
+  TRY(launch_add_layernorm(h1, d, nullptr, 0, p->head_ln_w, p->head_ln_b, p->ln_eps, B, d, h2, d, s));
+  TRY(launch_linear(h2, d, p->fc2_w, p->fc2_b, logits, p->n_classes, B, p->n_classes, d, STLT_ACT_NONE, s));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// Shared device/host helpers for libstlt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "stlt_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define STLT_WAVE 64
+
+// error plumbing (api.hip)
+int stlt_set_error(int code, const char* fmt, ...);
+int stlt_check_launch(const char* what);
+
+// per-kernel timing hooks (api.hip)
+void stlt_prof_begin(int kid, hipStream_t s);
+void stlt_prof_end(int kid, hipStream_t s);
+struct StltProfScope {
+  int kid; hipStream_t s;
+  StltProfScope(int k, hipStream_t st) : kid(k), s(st) { stlt_prof_begin(kid, s); }
+  ~StltProfScope() { stlt_prof_end(kid, s); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// internal launchers shared between the per-kernel C-ABI and the whole-path entry points
+int launch_embed(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
+                 int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
+                 const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
+                 float* out, hipStream_t s);
+int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
+                  int64_t N, int64_t K, int act, hipStream_t s);
+int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
+                float* ctx, int kid, hipStream_t s);
+int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* w, const float* b,
+                         float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s);
+int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
+                        const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
+                        int64_t d, float* out, hipStream_t s);
+int launch_gather_last(const float* x, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* out,
+                       hipStream_t s);

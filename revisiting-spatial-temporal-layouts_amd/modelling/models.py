@@ -1,0 +1,310 @@
+"""Drop-in ``StltBackbone`` / ``Stlt`` for the reference's ``src/modelling/models.py:16-195``.
+
+Same constructor (``StltModelConfig``), same ``forward(batch: Dict[str, Tensor])`` signature and return
+values, same 174 state-dict keys (168 for the backbone) — but the modules below only *store* parameters
+(``nn.Parameter`` holders with torch's default initialisation).  All arithmetic runs in hand-written HIP
+kernels for gfx950 through the C-ABI of ``libstlt_hip.so``; no ``torch.nn`` forward is ever called and
+there is no CPU fallback (CPU tensors raise ``StltHipError``).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import ops
+from .configs import StltModelConfig, model_configs_factory  # noqa: F401  (re-exported like the reference)
+
+_ENC_EPS = 1e-5  # nn.TransformerEncoderLayer default; config.layer_norm_eps is not forwarded (models.py:46-52,118-124)
+
+
+class _SelfAttnParams(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names/shapes/init: in_proj_weight (3d,d) rows [q;k;v]."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _EncoderLayerParams(nn.Module):
+    """Parameter holder with nn.TransformerEncoderLayer's 12 tensors (post-norm, gelu, dim_feedforward=4d)."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.self_attn = _SelfAttnParams(d)
+        self.linear1 = nn.Linear(d, 4 * d)
+        self.linear2 = nn.Linear(4 * d, d)
+        self.norm1 = nn.LayerNorm(d, eps=_ENC_EPS)
+        self.norm2 = nn.LayerNorm(d, eps=_ENC_EPS)
+
+    def c_struct(self) -> L.LayerParams:
+        sa = self.self_attn
+        ts = (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, self.linear1.weight,
+              self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias,
+              self.norm2.weight, self.norm2.bias)
+        return L.LayerParams(*[_dev_ptr(t) for t in ts])
+
+
+class _EncoderStack(nn.Module):
+    """``nn.TransformerEncoder``'s container: ``layers`` are deep copies of one layer (same initial weights)."""
+
+    def __init__(self, layer: _EncoderLayerParams, num_layers: int):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+
+
+def _dev_ptr(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise L.StltHipError("STLT parameters must be on a GPU (`model.to('cuda')`): the hot path has no CPU fallback")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise L.StltHipError("STLT parameters must be contiguous float32")
+    return t.data_ptr()
+
+
+class CategoryBoxEmbeddings(nn.Module):
+    """Parameters of reference models.py:16-27; forward = ``stlt_embed_fwd`` (K1)."""
+
+    def __init__(self, config: StltModelConfig):
+        super().__init__()
+        self.category_embeddings = nn.Embedding(config.unique_categories, config.hidden_size, padding_idx=0)
+        self.box_embedding = nn.Linear(4, config.hidden_size)
+        self.score_embeddings = nn.Linear(1, config.hidden_size)
+        self.layer_norm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.eps = config.layer_norm_eps
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        scores = batch["scores"].contiguous() if "scores" in batch else None
+        return ops.embed(batch["categories"].contiguous(), batch["boxes"].contiguous(), scores,
+                         self.category_embeddings.weight, self.box_embedding.weight, self.box_embedding.bias,
+                         self.score_embeddings.weight, self.score_embeddings.bias, self.layer_norm.weight,
+                         self.layer_norm.bias, self.eps)
+
+
+class SpatialTransformer(nn.Module):
+    """Parameters of reference models.py:42-55 (incl. the never-used ``encoder_layer`` the state dict carries)."""
+
+    def __init__(self, config: StltModelConfig):
+        super().__init__()
+        self.category_box_embeddings = CategoryBoxEmbeddings(config)
+        self.encoder_layer = _EncoderLayerParams(config.hidden_size)
+        self.transformer = _EncoderStack(self.encoder_layer, config.num_spatial_layers)
+
+
+class FramesEmbeddings(nn.Module):
+    """Parameters of reference models.py:84-96."""
+
+    def __init__(self, config: StltModelConfig):
+        super().__init__()
+        self.layout_embedding = SpatialTransformer(config)
+        self.position_embeddings = nn.Embedding(config.layout_num_frames, config.hidden_size)
+        self.frame_type_embedding = nn.Embedding(5, config.hidden_size, padding_idx=0)
+        self.layer_norm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.register_buffer("position_ids", torch.arange(config.layout_num_frames).expand((1, -1)))
+
+
+class ClassificationHead(nn.Module):
+    """Parameters of reference models.py:155-160; forward = fc2(LN(gelu(fc1(h)))) on the HIP kernels."""
+
+    def __init__(self, config: StltModelConfig):
+        super().__init__()
+        self.fc1 = nn.Linear(config.hidden_size, config.hidden_size)
+        self.layer_norm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.fc2 = nn.Linear(config.hidden_size, config.num_classes)
+        self.eps = config.layer_norm_eps
+
+    def forward(self, hidden_state: torch.Tensor) -> torch.Tensor:
+        h = ops.linear(hidden_state.contiguous(), self.fc1.weight, self.fc1.bias, act=L.ACT_GELU)
+        h = ops.add_layernorm(h, None, self.layer_norm.weight, self.layer_norm.bias, self.eps)
+        return ops.linear(h, self.fc2.weight, self.fc2.bias)
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device, reused across forwards (the C-ABI never allocates)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.device != device or self.buf.numel() < nbytes:
+            self.buf = None
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def _prep_inputs(batch: Dict[str, torch.Tensor], need_lengths: bool):
+    """Validate the collated batch (reference src/modelling/datasets.py:243-288) and build the C struct."""
+    cats = batch["categories"]
+    if cats.dim() != 3:
+        raise L.StltHipError(f"categories must be (B,T,N), got {tuple(cats.shape)}")
+    B, T, N = cats.shape
+    keep = []  # keep converted tensors alive until the launch is enqueued
+
+    def take(t, dtype, name, shape):
+        if tuple(t.shape) != shape:
+            raise L.StltHipError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+        if dtype == torch.uint8:
+            t = ops._mask_u8(t, name)
+        else:
+            t = ops._chk(t.contiguous(), dtype, name)
+        keep.append(t)
+        return t.data_ptr()
+
+    inp = L.Inputs()
+    inp.B, inp.T, inp.N = B, T, N
+    inp.categories = take(cats, torch.int64, "categories", (B, T, N))
+    inp.boxes = take(batch["boxes"], torch.float32, "boxes", (B, T, N, 4))
+    inp.scores = take(batch["scores"], torch.float32, "scores", (B, T, N)) if "scores" in batch else None
+    inp.kpm_boxes = take(batch["src_key_padding_mask_boxes"], torch.uint8, "src_key_padding_mask_boxes", (B, T, N))
+    inp.frame_types = take(batch["frame_types"], torch.int64, "frame_types", (B, T))
+    inp.kpm_frames = take(batch["src_key_padding_mask_frames"], torch.uint8, "src_key_padding_mask_frames", (B, T))
+    inp.lengths = take(batch["lengths"], torch.int64, "lengths", (B,)) if need_lengths else None
+    return inp, keep, (B, T, N)
+
+
+class StltBackbone(nn.Module):
+    """Drop-in for reference ``StltBackbone`` (models.py:114-152): ``forward(batch) -> (T, B, d)``."""
+
+    def __init__(self, config: StltModelConfig):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        self.config = config
+        self.frames_embeddings = FramesEmbeddings(config)
+        self.transformer = _EncoderStack(_EncoderLayerParams(config.hidden_size), config.num_temporal_layers)
+        self.cls_only_last_spatial = True  # exact: only token 0 of the last spatial layer is read (models.py:79)
+        self._cache = None
+        self._ws = _Workspace()
+
+    def __getstate__(self):  # ctypes tables / scratch are rebuilt lazily; keep deepcopy / pickling working
+        state = self.__dict__.copy()
+        state["_cache"] = None
+        state["_ws"] = _Workspace()
+        return state
+
+    @classmethod
+    def from_pretrained(cls, config: StltModelConfig):
+        model = cls(config)
+        model.load_state_dict(torch.load(config.load_backbone_path, map_location="cpu"))
+        return model
+
+    # ---- parameter table for the C-ABI -------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):
+        self._cache = None  # .to()/.cuda()/.float() move parameter storage
+        return super()._apply(fn, *a, **kw)
+
+    def _sentinel(self):
+        w0 = self.frames_embeddings.position_embeddings.weight
+        w1 = self.transformer.layers[-1].norm2.bias if len(self.transformer.layers) else w0
+        return (w0.data_ptr(), w1.data_ptr(), w0.device)
+
+    def c_params(self, head: Optional["ClassificationHead"] = None):
+        key = (self._sentinel(), None if head is None else head.fc2.weight.data_ptr())
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1]
+        cfg = self.config
+        fe = self.frames_embeddings
+        le = fe.layout_embedding
+        cbe = le.category_box_embeddings
+        sp = (L.LayerParams * max(1, len(le.transformer.layers)))(*[l.c_struct() for l in le.transformer.layers])
+        tp = (L.LayerParams * max(1, len(self.transformer.layers)))(*[l.c_struct() for l in self.transformer.layers])
+        p = L.Params()
+        p.d, p.H = cfg.hidden_size, cfg.num_attention_heads
+        p.n_categories = cbe.category_embeddings.weight.shape[0]
+        p.n_spatial, p.n_temporal = len(le.transformer.layers), len(self.transformer.layers)
+        p.n_classes = 0 if head is None else head.fc2.weight.shape[0]
+        p.n_positions = fe.position_embeddings.weight.shape[0]
+        p.ln_eps = cfg.layer_norm_eps
+        for name, t in (("cat_emb", cbe.category_embeddings.weight), ("box_w", cbe.box_embedding.weight),
+                        ("box_b", cbe.box_embedding.bias), ("score_w", cbe.score_embeddings.weight),
+                        ("score_b", cbe.score_embeddings.bias), ("emb_ln_w", cbe.layer_norm.weight),
+                        ("emb_ln_b", cbe.layer_norm.bias), ("pos_emb", fe.position_embeddings.weight),
+                        ("type_emb", fe.frame_type_embedding.weight), ("frames_ln_w", fe.layer_norm.weight),
+                        ("frames_ln_b", fe.layer_norm.bias)):
+            setattr(p, name, _dev_ptr(t))
+        p.spatial, p.temporal = sp, tp
+        if head is not None:
+            for name, t in (("fc1_w", head.fc1.weight), ("fc1_b", head.fc1.bias), ("head_ln_w", head.layer_norm.weight),
+                            ("head_ln_b", head.layer_norm.bias), ("fc2_w", head.fc2.weight), ("fc2_b", head.fc2.bias)):
+                setattr(p, name, _dev_ptr(t))
+        self._cache = (key, (p, sp, tp))  # keep the layer arrays alive with the struct
+        return self._cache[1]
+
+    def _flags(self) -> int:
+        return L.FLAG_CLS_ONLY_LAST_SPATIAL if self.cls_only_last_spatial else 0
+
+    def _check_mode(self):
+        if self.training and self.config.hidden_dropout_prob > 0:
+            raise L.StltHipError("train-mode dropout is not implemented in the HIP path yet: build the model with "
+                                 "hidden_dropout_prob=0 or call model.train(False)")
+
+    def forward_batch_major(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """HIP forward, batch-major (B,T,d) result (the layout the kernels compute in)."""
+        self._check_mode()
+        lib = L.load()
+        inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=False)
+        device = batch["categories"].device
+        p, _, _ = self.c_params()
+        d = self.config.hidden_size
+        nbytes = ops.workspace_bytes(B, T, N, d, 0)
+        ws = self._ws.get(nbytes, device)
+        out = torch.empty(B, T, d, device=device, dtype=torch.float32)
+        with torch.cuda.device(device):
+            L.check(lib.stlt_backbone_forward(C.byref(p), C.byref(inp), ws.data_ptr(), ws.numel(), self._flags(),
+                                              out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                    "stlt_backbone_forward")
+        return out
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        # [Num. frames, Batch size, Hidden size] like the reference (a transposed view of the batch-major result)
+        return self.forward_batch_major(batch).transpose(0, 1)
+
+
+class Stlt(nn.Module):
+    """Drop-in for reference ``Stlt`` (models.py:166-195): ``forward(batch) -> {"stlt": (B, num_classes)}``."""
+
+    def __init__(self, config: StltModelConfig):
+        super().__init__()
+        self.config = config
+        if config.load_backbone_path is not None:
+            self.backbone = StltBackbone.from_pretrained(config)
+            if config.freeze_backbone:
+                for param in self.backbone.parameters():
+                    param.requires_grad = False
+        else:
+            self.backbone = StltBackbone(config)
+        self.prediction_head = ClassificationHead(config)
+        self.logit_names = ("stlt",)
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        if self.config.load_backbone_path and self.config.freeze_backbone:
+            self.backbone.train(False)
+        return self  # the reference returns None here; returning self is a superset
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        bb = self.backbone
+        bb._check_mode()
+        lib = L.load()
+        inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=True)
+        device = batch["categories"].device
+        p, _, _ = bb.c_params(self.prediction_head)
+        d, K = self.config.hidden_size, self.prediction_head.fc2.weight.shape[0]
+        nbytes = ops.workspace_bytes(B, T, N, d, K)
+        ws = bb._ws.get(nbytes, device)
+        logits = torch.empty(B, K, device=device, dtype=torch.float32)
+        with torch.cuda.device(device):
+            L.check(lib.stlt_forward(C.byref(p), C.byref(inp), ws.data_ptr(), ws.numel(), bb._flags(), None,
+                                     logits.data_ptr(), torch.cuda.current_stream().cuda_stream), "stlt_forward")
+        return {k: v for k, v in zip(self.logit_names, (logits,))}
+
+
+models_factory = {"stlt": Stlt}

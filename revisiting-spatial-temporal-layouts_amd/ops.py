@@ -1,0 +1,147 @@
+"""Tensor-level wrappers over the C-ABI (one function per entry point of include/stlt_hip.h).
+
+PyTorch is plumbing here: device allocations, the current HIP stream, nothing else.  Every wrapper checks
+that its tensors live on a GPU, are fp32/int64/bool as the ABI expects and contiguous, then passes raw
+device pointers.  There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise L.StltHipError(f"{name}: expected a GPU tensor (the STLT hot path has no CPU fallback), got "
+                             f"{getattr(t, 'device', type(t))}")
+    if t.dtype != dtype:
+        raise L.StltHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.StltHipError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _mask_u8(t: torch.Tensor, name: str) -> torch.Tensor:
+    """bool masks are 1 byte/element: reinterpret, never copy."""
+    if t.dtype == torch.bool:
+        t = t.contiguous().view(torch.uint8)
+    return _chk(t, torch.uint8, name)
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def embed(categories, boxes, scores, cat_table, box_w, box_b, score_w, score_b, ln_w, ln_b, eps: float):
+    """K1 — CategoryBoxEmbeddings.forward (reference src/modelling/models.py:29-39). -> (*categories.shape, d)"""
+    lib = L.load()
+    _chk(categories, torch.int64, "categories"); _chk(boxes, torch.float32, "boxes")
+    if scores is not None:
+        _chk(scores, torch.float32, "scores")
+    for n, t in (("cat_table", cat_table), ("box_w", box_w), ("box_b", box_b), ("ln_w", ln_w), ("ln_b", ln_b)):
+        _chk(t, torch.float32, n)
+    d = cat_table.shape[1]
+    n_tok = categories.numel()
+    assert boxes.numel() == n_tok * 4
+    out = torch.empty(*categories.shape, d, device=categories.device, dtype=torch.float32)
+    L.check(lib.stlt_embed_fwd(_p(categories), _p(boxes), _p(scores), _p(cat_table), cat_table.shape[0], _p(box_w),
+                               _p(box_b), _p(score_w), _p(score_b), _p(ln_w), _p(ln_b), eps, n_tok, d, _p(out),
+                               _stream()), "stlt_embed_fwd")
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = L.ACT_NONE,
+           out: Optional[torch.Tensor] = None, rows: Optional[int] = None, ldx: Optional[int] = None):
+    """nn.Linear forward y = act(x wᵀ + b) on the f32 matrix cores.  x (..., K) contiguous; with rows/ldx a strided row view."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"); _chk(w, torch.float32, "w")
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    N, K = w.shape
+    if rows is None:
+        assert x.shape[-1] == K
+        M, ldx_ = x.numel() // K, K
+        out_shape = (*x.shape[:-1], N)
+    else:
+        M, ldx_ = rows, ldx
+        out_shape = (rows, N)
+    if out is None:
+        out = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    L.check(lib.stlt_linear_fwd(_p(x), ldx_, _p(w), _p(bias), _p(out), N, M, N, K, act, _stream()), "stlt_linear_fwd")
+    return out
+
+
+def attn_core(qkv: torch.Tensor, kpm: torch.Tensor, causal: bool, num_heads: int):
+    """K3 — qkv (S,L,3d) packed [q;k;v], kpm (S,L) bool/uint8 (True = key masked). -> ctx (S,L,d)"""
+    lib = L.load()
+    _chk(qkv, torch.float32, "qkv")
+    kpm = _mask_u8(kpm, "kpm")
+    S, Lq, d3 = qkv.shape
+    d = d3 // 3
+    ctx = torch.empty(S, Lq, d, device=qkv.device, dtype=torch.float32)
+    L.check(lib.stlt_attn_core_fwd(_p(qkv), _p(kpm), int(bool(causal)), S, Lq, num_heads, d // num_heads, _p(ctx),
+                                   _stream()), "stlt_attn_core_fwd")
+    return ctx
+
+
+def add_layernorm(x: torch.Tensor, res: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, eps: float):
+    """out = LayerNorm_eps(x + res) over the last dim (res may be None)."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"); _chk(w, torch.float32, "ln_w"); _chk(b, torch.float32, "ln_b")
+    if res is not None:
+        _chk(res, torch.float32, "res")
+        assert res.shape == x.shape
+    d = x.shape[-1]
+    M = x.numel() // d
+    out = torch.empty_like(x)
+    L.check(lib.stlt_add_layernorm_fwd(_p(x), d, _p(res), d, _p(w), _p(b), eps, M, d, _p(out), d, _stream()),
+            "stlt_add_layernorm_fwd")
+    return out
+
+
+def frames_embed(spatial: torch.Tensor, frame_types: torch.Tensor, pos_table, type_table, ln_w, ln_b, eps: float):
+    """K7 — spatial (B,T,N,d) (token 0 is read) or (B,T,d); frame_types (B,T). -> (B,T,d)"""
+    lib = L.load()
+    _chk(spatial, torch.float32, "spatial"); _chk(frame_types, torch.int64, "frame_types")
+    B, T = frame_types.shape
+    d = spatial.shape[-1]
+    row_stride = spatial.numel() // (B * T)
+    out = torch.empty(B, T, d, device=spatial.device, dtype=torch.float32)
+    L.check(lib.stlt_frames_embed_fwd(_p(spatial), row_stride, _p(frame_types), _p(pos_table), _p(type_table),
+                                      _p(ln_w), _p(ln_b), eps, B, T, d, _p(out), _stream()), "stlt_frames_embed_fwd")
+    return out
+
+
+def gather_last(x_btd: torch.Tensor, lengths: torch.Tensor):
+    """K8a — out[b] = x[b, lengths[b]-1] (reference models.py:189-192 on the batch-major layout)."""
+    lib = L.load()
+    _chk(x_btd, torch.float32, "x"); _chk(lengths, torch.int64, "lengths")
+    B, T, d = x_btd.shape
+    out = torch.empty(B, d, device=x_btd.device, dtype=torch.float32)
+    L.check(lib.stlt_gather_last_fwd(_p(x_btd), _p(lengths), B, T, d, _p(out), _stream()), "stlt_gather_last_fwd")
+    return out
+
+
+def workspace_bytes(B: int, T: int, N: int, d: int, n_classes: int) -> int:
+    return int(L.load().stlt_workspace_bytes(B, T, N, d, n_classes))
+
+
+def prof_enable(on: bool):
+    L.load().stlt_prof_enable(int(on))
+
+
+def prof_collect():
+    """-> {kernel name: (total ms, launches)} accumulated since the last collect."""
+    n = len(L.K_NAMES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    L.check(L.load().stlt_prof_collect(ms, cnt), "stlt_prof_collect")
+    return {L.K_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}

@@ -1,0 +1,116 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the drop-in
+modules carry the reference's state-dict schema, and the product path refuses to run without a GPU."""
+import copy
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, "include", "stlt_hip.h")).read()
+    declared = set(re.findall(r"\b(stlt_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = pkg._lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/stlt_hip.h but not exported"
+    assert declared == set(pkg._lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert lib.stlt_version() == 100
+    # workspace sizing is pure host arithmetic: callable without a GPU
+    a = pkg.ops.workspace_bytes(8, 32, 7, 768, 174)
+    b = pkg.ops.workspace_bytes(16, 32, 7, 768, 174)
+    assert 0 < a < b
+    assert pkg.ops.workspace_bytes(0, 32, 7, 768, 174) == 0
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4"])
+def test_state_dict_schema_matches_reference(pkg, name):
+    _, meta = load_golden(name)
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    sd = m.state_dict()
+    assert list(sd) == list(meta["keys"])  # same keys, same order
+    for k, v in sd.items():
+        assert list(v.shape) == meta["keys"][k]["shape"], k
+        assert str(v.dtype).replace("torch.", "") == meta["keys"][k]["dtype"], k
+    assert len(m.backbone.state_dict()) == len(sd) - 6
+    assert m.logit_names == ("stlt",)
+    # 1-D / bias parameters are what add_weight_decay exempts (train_inference_utils.py:47); names must agree
+    params = list(m.named_parameters())
+    assert len(params) == 173  # 174 keys minus the position_ids buffer
+    assert sum(1 for n, p in params if p.dim() == 1 or n.endswith(".bias")) == 114  # probed on the reference
+    # spatial layers start as copies of the (dead) encoder_layer, like nn.TransformerEncoder's deep copies
+    le = m.backbone.frames_embeddings.layout_embedding
+    assert torch.equal(le.encoder_layer.linear1.weight, le.transformer.layers[2].linear1.weight)
+    copy.deepcopy(m)
+
+
+def test_strict_and_nonstrict_loading(pkg):
+    """inference.py:59-69: strict load, falling back to strict=False when score_embeddings are absent."""
+    _, meta = load_golden("cfg1")
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs("cfg1")))
+    sd = pkg.synth.make_state_dict({k: tuple(v["shape"]) for k, v in meta["keys"].items()})
+    m.load_state_dict(sd, strict=True)
+    partial = {k: v for k, v in sd.items() if "score_embeddings" not in k}
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(partial, strict=True)
+    res = m.load_state_dict(partial, strict=False)
+    assert all("score_embeddings" in k for k in res.missing_keys) and not res.unexpected_keys
+
+
+def test_config_surface(pkg):
+    with pytest.raises(AssertionError):
+        pkg.StltModelConfig(unique_categories=4)
+    with pytest.raises(AssertionError):
+        pkg.StltModelConfig(num_classes=174)
+    c = pkg.StltModelConfig(num_classes=174, unique_categories=4)
+    assert (c.hidden_size, c.num_attention_heads, c.num_spatial_layers, c.num_temporal_layers) == (768, 12, 4, 8)
+    assert (c.hidden_dropout_prob, c.layer_norm_eps, c.layout_num_frames) == (0.1, 1e-12, 256)
+    assert c.load_backbone_path is None and c.freeze_backbone is False
+    assert pkg.models_factory["stlt"] is pkg.Stlt and pkg.model_configs_factory["stlt"] is pkg.StltModelConfig
+
+
+def test_no_cpu_fallback(pkg):
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs("cfg1")))
+    m.train(False)
+    with pytest.raises(pkg.StltHipError):
+        m(pkg.synth.make_batch(2, 16, 4))
+
+
+def test_frozen_backbone_stays_in_eval(pkg, tmp_path):
+    """Stlt.train override (models.py:180-183) + from_pretrained (models.py:130-134)."""
+    kw = pkg.synth.model_kwargs("cfg1")
+    bb = pkg.StltBackbone(pkg.StltModelConfig(**kw))
+    path = str(tmp_path / "bb.pt")
+    torch.save(bb.state_dict(), path)
+    m = pkg.Stlt(pkg.StltModelConfig(**kw, load_backbone_path=path, freeze_backbone=True))
+    assert all(not p.requires_grad for p in m.backbone.parameters())
+    assert all(p.requires_grad for p in m.prediction_head.parameters())
+    m.train(True)
+    assert m.training and not m.backbone.training
+    assert torch.equal(m.backbone.transformer.layers[3].linear2.weight, bb.transformer.layers[3].linear2.weight)
+
+
+def test_causal_mask_helper(pkg):
+    mk = pkg.generate_square_subsequent_mask(5)
+    assert mk.dtype == torch.bool and mk[0, 1] and not mk[1, 1] and not mk[3, 0]
+
+
+def test_synth_invariants(pkg):
+    for ds, T, N in (("something", 32, 7), ("action_genome", 64, 36)):
+        b = pkg.synth.make_batch(16, T, N, dataset=ds, seed=5)
+        v = pkg.synth.DATASETS[ds]
+        assert (b["categories"][:, :, 0] == v["cls"]).all()
+        assert b["lengths"][0] == T and (b["lengths"] >= 2).all() and (b["lengths"] <= T).all()
+        for i in range(16):
+            ln = int(b["lengths"][i])
+            assert (b["frame_types"][i, :ln] != 0).all() and (b["frame_types"][i, ln:] == 0).all()
+            assert b["frame_types"][i, ln - 1] == v["extract"]
+            assert (b["categories"][i, ln - 1:, 1:] == 0).all()
+        assert torch.equal(b["src_key_padding_mask_boxes"], b["categories"] == 0)
+        assert ("scores" in b) == (ds == "action_genome")
+        assert (b["boxes"][..., 0] <= b["boxes"][..., 2]).all() and (b["boxes"][..., 1] <= b["boxes"][..., 3]).all()

@@ -1,0 +1,137 @@
+"""Per-kernel parity: each C-ABI entry point (through ops.*) against the CPU oracle on seeded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stlt_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 32), (37, 174, 256), (128, 128, 768), (300, 768, 96), (129, 2304, 768),
+                                   (1000, 130, 3072)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear(pkg, M, N, K, act):
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3, scale=0.1)
+    y = pkg.ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=act).cpu()
+    ref = x.double() @ w.double().t() + b.double()
+    if act:
+        ref = O.gelu(ref)
+    assert y.shape == (M, N)
+    assert (y.double() - ref).abs().max().item() <= 2e-5
+
+
+def test_linear_strided_rows_and_no_bias(pkg):
+    # rows of stride 3*K (the CLS-row view used by the last spatial layer)
+    M, N, K = 50, 256, 256
+    x = _rand(M, 3 * K, seed=4)
+    w = _rand(N, K, seed=5, scale=1 / 16)
+    y = pkg.ops.linear(x.to(DEV), w.to(DEV), None, rows=M, ldx=3 * K).cpu()
+    ref = x[:, :K].double() @ w.double().t()
+    assert (y.double() - ref).abs().max().item() <= 2e-5
+
+
+def test_linear_rejects_bad_k(pkg):
+    with pytest.raises(pkg.StltHipError):
+        pkg.ops.linear(torch.zeros(4, 20, device=DEV), torch.zeros(8, 20, device=DEV), None)
+
+
+@pytest.mark.parametrize("d,C,with_scores", [(256, 4, False), (768, 4, False), (768, 38, True), (1024, 5, True), (64, 3, True)])
+def test_embed(pkg, d, C, with_scores):
+    B, T, N = 3, 5, 6
+    g = torch.Generator().manual_seed(7)
+    cats = torch.randint(0, C, (B, T, N), generator=g)
+    boxes = torch.rand(B, T, N, 4, generator=g)
+    scores = torch.rand(B, T, N, generator=g)
+    sd = {"category_embeddings.weight": _rand(C, d, seed=8), "box_embedding.weight": _rand(d, 4, seed=9, scale=0.5),
+          "box_embedding.bias": _rand(d, seed=10, scale=0.5), "score_embeddings.weight": _rand(d, 1, seed=11),
+          "score_embeddings.bias": _rand(d, seed=12, scale=0.5), "layer_norm.weight": 1 + _rand(d, seed=13, scale=0.1),
+          "layer_norm.bias": _rand(d, seed=14, scale=0.1)}
+    batch = {"categories": cats, "boxes": boxes}
+    if with_scores:
+        batch["scores"] = scores
+    ref = O.category_box_embeddings({k: v.double() for k, v in sd.items()}, "", batch, 1e-12)
+    D = {k: v.to(DEV) for k, v in sd.items()}
+    got = pkg.ops.embed(cats.to(DEV), boxes.to(DEV), scores.to(DEV) if with_scores else None,
+                        D["category_embeddings.weight"], D["box_embedding.weight"], D["box_embedding.bias"],
+                        D["score_embeddings.weight"], D["score_embeddings.bias"], D["layer_norm.weight"],
+                        D["layer_norm.bias"], 1e-12).cpu()
+    assert got.shape == (B, T, N, d)
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+def _attn_ref(qkv, kpm, causal, H):
+    S, L, _ = qkv.shape
+    masked = kpm[:, None, :].expand(S, L, L).clone()
+    if causal:
+        masked |= torch.triu(torch.ones(L, L, dtype=torch.bool), diagonal=1)[None]
+    m = torch.zeros(S, L, L, dtype=torch.float64).masked_fill(masked, float("-inf"))
+    return O.attention_core(qkv.double(), m, H)
+
+
+@pytest.mark.parametrize("L", [1, 2, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 36, 37, 64, 65, 100, 256])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attn_core(pkg, L, causal):
+    S, H = (9 if L < 100 else 3), 4
+    d = 64 * H
+    qkv = _rand(S, L, 3 * d, seed=L, scale=1.5)
+    g = torch.Generator().manual_seed(100 + L)
+    kpm = torch.rand(S, L, generator=g) < 0.3
+    kpm[:, 0] = False  # invariant §8b: key 0 is never masked
+    got = pkg.ops.attn_core(qkv.to(DEV), kpm.to(DEV), causal, H).cpu()
+    ref = _attn_ref(qkv, kpm, causal, H)
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+def test_attn_core_peaked_and_fully_masked_rows(pkg):
+    # large logits (online-softmax rescale across key tiles) and a sequence whose keys are all masked -> zeros
+    S, L, H = 4, 70, 2
+    d = 64 * H
+    qkv = _rand(S, L, 3 * d, seed=5, scale=6.0)
+    kpm = torch.zeros(S, L, dtype=torch.bool)
+    kpm[1, :] = True
+    kpm[2, :40] = True  # first key tile fully masked for sequence 2
+    got = pkg.ops.attn_core(qkv.to(DEV), kpm.to(DEV), False, H).cpu()
+    ref = _attn_ref(qkv, kpm, False, H)
+    assert torch.isfinite(got).all()
+    assert got[1].abs().max().item() == 0.0
+    assert (got.double() - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("d", [64, 256, 768, 1024, 2048])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_add_layernorm(pkg, d, with_res):
+    M = 37
+    x, r = _rand(M, d, seed=1, scale=3), _rand(M, d, seed=2, scale=3)
+    w, b = 1 + _rand(d, seed=3, scale=0.2), _rand(d, seed=4, scale=0.2)
+    got = pkg.ops.add_layernorm(x.to(DEV), r.to(DEV) if with_res else None, w.to(DEV), b.to(DEV), 1e-5).cpu()
+    ref = O.layer_norm((x + r if with_res else x).double(), w.double(), b.double(), 1e-5)
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+def test_frames_embed_and_gather(pkg):
+    B, T, N, d = 3, 6, 4, 256
+    sp = _rand(B, T, N, d, seed=1)
+    ft = torch.randint(0, 5, (B, T), generator=torch.Generator().manual_seed(2))
+    P, F = _rand(256, d, seed=3), _rand(5, d, seed=4)
+    w, b = 1 + _rand(d, seed=5, scale=0.1), _rand(d, seed=6, scale=0.1)
+    got = pkg.ops.frames_embed(sp.to(DEV), ft.to(DEV), P.to(DEV), F.to(DEV), w.to(DEV), b.to(DEV), 1e-12).cpu()
+    ref = O.layer_norm((sp[:, :, 0] + P[:T][None] + F[ft]).double(), w.double(), b.double(), 1e-12)
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+    lengths = torch.tensor([6, 2, 4])
+    h = pkg.ops.gather_last(got.to(DEV), lengths.to(DEV)).cpu()
+    assert torch.equal(h, got[torch.arange(B), lengths - 1])  # pure data movement: bit exact
+
+
+def test_cpu_tensors_are_refused(pkg):
+    with pytest.raises(pkg.StltHipError):
+        pkg.ops.linear(torch.zeros(4, 32), torch.zeros(8, 32), None)

@@ -1,0 +1,171 @@
+"""Whole-path parity: drop-in Stlt / StltBackbone on the GPU vs the reference goldens and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_case
+from oracle import stlt_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4  # BASELINE.json north_star: logits within 1e-4 max-abs of the reference CPU forward (fp32)
+
+
+def _model(pkg, name, sd):
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.load_state_dict(sd, strict=True)
+    m.train(False)
+    return m.to(DEV)
+
+
+def _to(batch):
+    return {k: v.to(DEV) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg2p", "cfg4"])
+@pytest.mark.parametrize("cls_only", [True, False])
+def test_logits_match_reference_golden(pkg, name, cls_only):
+    sd, batch, z, meta = golden_case(name)
+    m = _model(pkg, name, sd)
+    m.backbone.cls_only_last_spatial = cls_only
+    with torch.no_grad():
+        out = m(_to(batch))
+    assert set(out) == {"stlt"}
+    got = out["stlt"].cpu().numpy()
+    assert got.shape == z["logits"].shape
+    assert np.isfinite(got).all()
+    err = np.abs(got - z["logits"]).max()
+    err64 = np.abs(got.astype(np.float64) - z["logits_fp64"]).max()
+    print(f"{name} cls_only={cls_only}: max|gpu-ref32|={err:.2e} max|gpu-ref64|={err64:.2e}")
+    assert err <= TOL and err64 <= TOL
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4"])
+def test_backbone_output_matches_reference_golden(pkg, name):
+    sd, batch, z, meta = golden_case(name)
+    m = _model(pkg, name, sd)
+    with torch.no_grad():
+        out = m.backbone(_to(batch))
+    assert out.shape == z["backbone_tbd"].shape  # (T,B,d) like the reference
+    assert np.abs(out.cpu().numpy() - z["backbone_tbd"]).max() <= TOL
+
+
+def test_stage_taps_cfg1(pkg):
+    """K1 / first + last spatial layer / K7 / first + last temporal layer against the reference's hooks."""
+    name = "cfg1"
+    sd, batch, z, meta = golden_case(name)
+    m = _model(pkg, name, sd)
+    H = pkg.synth.CONFIGS[name]["num_attention_heads"]
+    bb = m.backbone
+    le = bb.frames_embeddings.layout_embedding
+    b = _to(batch)
+    B, T, N = batch["categories"].shape
+    x = le.category_box_embeddings(b)
+    assert np.abs(x.cpu().numpy() - z["tap_embed"]).max() <= 2e-5
+    real = ~batch["src_key_padding_mask_boxes"].numpy()
+
+    def layer(x, lp, kpm, causal):
+        S, L, d = x.shape
+        qkv = pkg.ops.linear(x, lp.self_attn.in_proj_weight, lp.self_attn.in_proj_bias)
+        a = pkg.ops.attn_core(qkv, kpm, causal, H)
+        a = pkg.ops.linear(a, lp.self_attn.out_proj.weight, lp.self_attn.out_proj.bias)
+        x = pkg.ops.add_layernorm(a, x, lp.norm1.weight, lp.norm1.bias, 1e-5)
+        h = pkg.ops.linear(x, lp.linear1.weight, lp.linear1.bias, act=1)
+        h = pkg.ops.linear(h, lp.linear2.weight, lp.linear2.bias)
+        return pkg.ops.add_layernorm(h, x, lp.norm2.weight, lp.norm2.bias, 1e-5)
+
+    x = x.reshape(B * T, N, -1)
+    kpm = b["src_key_padding_mask_boxes"].reshape(B * T, N)
+    for li, lp in enumerate(le.transformer.layers):
+        x = layer(x, lp, kpm, False)
+        key = f"tap_spatial{li}"
+        if key in z.files:
+            got = x.reshape(B, T, N, -1).cpu().numpy()
+            assert np.abs(got[real] - z[key][real]).max() <= 5e-5, key
+    fe = bb.frames_embeddings
+    g = pkg.ops.frames_embed(x.reshape(B, T, N, -1), b["frame_types"], fe.position_embeddings.weight,
+                             fe.frame_type_embedding.weight, fe.layer_norm.weight, fe.layer_norm.bias, 1e-12)
+    assert np.abs(g.cpu().numpy() - z["tap_frames"]).max() <= 5e-5
+    x = g
+    for li, lp in enumerate(bb.transformer.layers):
+        x = layer(x, lp, b["src_key_padding_mask_frames"], True)
+        key = f"tap_temporal{li}"
+        if key in z.files:
+            assert np.abs(x.cpu().numpy() - z[key]).max() <= 1e-4, key
+
+
+def test_matches_oracle_on_fresh_seed_with_scores_absent_and_present(pkg):
+    """Seeds the goldens never saw; scores key toggles the K1 branch (reference models.py:33)."""
+    for name, seed in (("cfg1", 11), ("cfg4", 12)):
+        c = pkg.synth.CONFIGS[name]
+        m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+        sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=99, gain=2.0)
+        m.load_state_dict(sd)
+        m = m.train(False).to(DEV)
+        for with_scores in (False, True):
+            batch = pkg.synth.make_batch(3, c["T"], c["N"], dataset=c["dataset"], seed=seed, with_scores=with_scores)
+            with torch.no_grad():
+                got = m(_to(batch))["stlt"].cpu()
+                ref = O.stlt_forward(sd, batch, c["num_attention_heads"])["stlt"]
+            assert (got - ref).abs().max().item() <= TOL
+
+
+def test_full_size_properties_cfg2(pkg):
+    """BASELINE-size batch (cfg2, B=64): size-independent properties, no oracle needed."""
+    name = "cfg2"
+    c = pkg.synth.CONFIGS[name]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234)
+    m.load_state_dict(sd)
+    m = m.train(False).to(DEV)
+    B = 64
+    batch = _to(pkg.synth.make_batch(B, c["T"], c["N"], seed=3))
+    with torch.no_grad():
+        full = m(batch)["stlt"]
+        assert torch.isfinite(full).all()
+        # (1) determinism
+        assert torch.equal(full, m(batch)["stlt"])
+        # (2) clips are independent: permuting the batch permutes the logits
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(DEV)
+        pb = {k: v[perm] for k, v in batch.items()}
+        assert (m(pb)["stlt"] - full[perm]).abs().max().item() <= 1e-5
+        # (3) batch shards concatenate to the full batch (the multi-GPU split)
+        parts = [m({k: v[i:i + 16] for k, v in batch.items()})["stlt"] for i in range(0, B, 16)]
+        assert (torch.cat(parts) - full).abs().max().item() <= 1e-5
+        # (4) appending padded frames / padded object slots changes nothing
+        T, N = c["T"], c["N"]
+        ext = {}
+        ext["categories"] = torch.zeros(B, T + 3, N + 2, dtype=torch.int64, device=DEV)
+        ext["categories"][:, :, 0] = 3
+        ext["categories"][:, :T, :N] = batch["categories"]
+        ext["boxes"] = torch.zeros(B, T + 3, N + 2, 4, device=DEV)
+        ext["boxes"][:, :, 0] = torch.tensor([0., 0., 1., 1.], device=DEV)
+        ext["boxes"][:, :T, :N] = batch["boxes"]
+        ext["frame_types"] = torch.zeros(B, T + 3, dtype=torch.int64, device=DEV)
+        ext["frame_types"][:, :T] = batch["frame_types"]
+        ext["lengths"] = batch["lengths"]
+        ext["src_key_padding_mask_boxes"] = ext["categories"] == 0
+        ext["src_key_padding_mask_frames"] = ext["frame_types"] == 0
+        assert (m(ext)["stlt"] - full).abs().max().item() <= 2e-5
+
+
+def test_state_dict_roundtrip_and_train_flag(pkg):
+    name = "cfg1"
+    sd, batch, z, meta = golden_case(name)
+    m = _model(pkg, name, sd)
+    sd2 = {k: v.cpu() for k, v in m.state_dict().items()}
+    assert list(sd2) == list(meta["keys"])
+    for k in sd:
+        assert torch.equal(sd[k], sd2[k])
+    # backbone-only dict (train.py:152 / models.py:130-134): 168 keys
+    assert len(m.backbone.state_dict()) == 168
+    # p=0 -> train mode runs the same math; p>0 in train mode is refused, not silently wrong
+    m.train(True)
+    with torch.no_grad():
+        a = m(_to(batch))["stlt"]
+    m.backbone.config.hidden_dropout_prob = 0.1
+    with pytest.raises(pkg.StltHipError):
+        m(_to(batch))
+    m.train(False)
+    with torch.no_grad():
+        assert torch.equal(a, m(_to(batch))["stlt"])
