@@ -10,41 +10,55 @@
 // h = lane>>5) then holds query i's scores for 16 of the 32 keys in its accumulator registers, so the row
 // max / row sum are in-register plus one cross-half shuffle, and the probabilities are already the
 // B operand of Oᵀ += Vᵀ·Pᵀ (MFMA sums over the accumulator's row index: no lane movement, no LDS round
-// trip).  Q/K/V tiles are staged in LDS with fully coalesced 16-byte loads (a head row is 256 B).
+// trip).  Q/K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: fully coalesced 256-B head rows, no
+// staging VGPRs), XOR-swizzled for conflict-free fragment reads; the output tile leaves through LDS as whole rows.
 #include "common.h"
 
 namespace {
 
 constexpr int DH = 64;
-constexpr int LD = DH + 4;  // padded LDS row: conflict-free ds_read_b128 for the 16-lane groups
 constexpr int TILE = 32;
+constexpr int TILE_FLOATS = TILE * DH;  // 8 KB, unpadded: LDS-DMA writes 1 KB (4 rows) per wave instruction
 
-__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, int64_t ld,
-                                           int rows_valid, int lane) {
-  // 32 rows x 64 floats; float4 f = lane + 64*i -> row f/16, col4 f%16: 16 lanes cover one 256-B head row
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// LDS image of a 32x64 tile: row r, 16-B chunk q lives at chunk slot q ^ (r & 15).  With 256-B rows every row
+// starts on bank 0, so an unswizzled ds_read_b128 column read would be a 16-way conflict; the XOR spreads the 16
+// lanes of each ds_read_b128 group over all 16 slots.  LDS-DMA writes lane-linearly, so the swizzle is applied
+// to the per-lane SOURCE address (same 256-B row -> coalescing unchanged) and again on every read.
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ (row & 15); }
+
+// 8 x global_load_lds_dwordx4: no VGPR staging, no ds_write; rows past the end re-read the last valid row
+// (their keys are masked / their query rows never stored).
+__device__ __forceinline__ void tile_dma(float* lds_tile, const float* __restrict__ src, int64_t ld, int rows_valid,
+                                         int lane) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int f = lane + 64 * i;
-    const int row = f >> 4, c4 = (f & 15) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < rows_valid) v = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld + c4);
-    *reinterpret_cast<f32x4*>(dst + row * LD + c4) = v;
+    const int row = 4 * i + (lane >> 4), slot = lane & 15;
+    const int rr = row < rows_valid ? row : rows_valid - 1;
+    const float* g = src + (int64_t)rr * ld + swz(row, slot) * 4;
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(lds_tile + i * 256), 16, 0, 0);
   }
 }
 
 __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ kpm,
                                                        int causal, int64_t n_tokens, int L, int H, int GL, int nt,
                                                        float scale, float* __restrict__ ctx) {
-  __shared__ __attribute__((aligned(16))) float Qs[TILE * LD];
-  __shared__ __attribute__((aligned(16))) float Ks[TILE * LD];
-  __shared__ __attribute__((aligned(16))) float Vs[TILE * LD];
-  __shared__ int kmeta[TILE];
+  __shared__ __attribute__((aligned(16))) float smem[3 * TILE_FLOATS + TILE];
+  float* Qs = smem;
+  float* Ks = smem + TILE_FLOATS;
+  float* Vs = smem + 2 * TILE_FLOATS;
+  int* kmeta = reinterpret_cast<int*>(smem + 3 * TILE_FLOATS);
 
   const int lane = threadIdx.x;
   const int li = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t g = blockIdx.x / nt;
-  const int qb = blockIdx.x % nt;
+  // head-fastest block order: the waves resident at any moment cover all heads of the same tokens, i.e. whole
+  // contiguous qkv rows.
+  const int head = blockIdx.x % H;
+  const int64_t tile_id = blockIdx.x / H;
+  const int64_t g = tile_id / nt;
+  const int qb = (int)(tile_id % nt);
   const int64_t tok0 = g * GL;
   const int gvalid = (int)((n_tokens - tok0) < GL ? (n_tokens - tok0) : GL);  // tokens of this group
   const int d = H * DH;
@@ -52,12 +66,6 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
   const int q_first = qb * TILE;
   const int q_rows = gvalid - q_first < TILE ? gvalid - q_first : TILE;
   if (q_rows <= 0) return;
-
-  stage_tile(Qs, qkv + (tok0 + q_first) * ld + head * DH, ld, q_rows, lane);
-  __syncthreads();
-  f32x4 qf[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4*>(Qs + li * LD + 8 * c + 4 * lh);
 
   // this lane's query: position in the group, sequence id and position in the sequence
   const int qi = q_first + li;
@@ -67,24 +75,30 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
+  f32x4 qf[8];
 
   const int kt_end = (causal && GL == L) ? qb + 1 : nt;  // causal: key tiles past the query tile are fully masked
   for (int kt = 0; kt < kt_end; ++kt) {
     const int k_first = kt * TILE;
     const int k_rows = gvalid - k_first < TILE ? gvalid - k_first : TILE;
-    __syncthreads();  // previous tile's LDS reads are done
-    stage_tile(Ks, qkv + (tok0 + k_first) * ld + d + head * DH, ld, k_rows, lane);
-    stage_tile(Vs, qkv + (tok0 + k_first) * ld + 2 * d + head * DH, ld, k_rows, lane);
-    if (lane < TILE) {
-      const int kj = k_first + lane;
-      int meta = -1;
-      if (lane < k_rows && kpm[tok0 + kj] == 0) {
-        const int ks = kj / L;
-        meta = (ks << 16) | (kj - ks * L);
-      }
-      kmeta[lane] = meta;
+    if (kt > 0) __syncthreads();  // previous tile's LDS reads are done
+    // every byte of the tile (and, first time round, the queries) is in flight before the first wait
+    if (kt == 0) tile_dma(Qs, qkv + (tok0 + q_first) * ld + head * DH, ld, q_rows, lane);
+    tile_dma(Ks, qkv + (tok0 + k_first) * ld + d + head * DH, ld, k_rows, lane);
+    tile_dma(Vs, qkv + (tok0 + k_first) * ld + 2 * d + head * DH, ld, k_rows, lane);
+    {
+      // key metadata for the mask: -1 = masked/absent, else (sequence id << 16) | position in sequence
+      const int kj = k_first + li;
+      const bool kvalid = li < k_rows;
+      const uint8_t pad = kpm[tok0 + (kvalid ? kj : k_first)];
+      const int ks = kj / L;
+      if (lane < TILE) kmeta[lane] = (kvalid && pad == 0) ? ((ks << 16) | (kj - ks * L)) : -1;
     }
-    __syncthreads();
+    __syncthreads();  // waits vmcnt(0) (LDS-DMA landed) + lgkmcnt(0)
+    if (kt == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4*>(Qs + li * DH + swz(li, 2 * c + lh) * 4);
+    }
 
     // Sᵀ[j][i] = sum_k K[j][k] Q[i][k]
     f32x16 st;
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * LD + 8 * c + 4 * lh);
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * DH + swz(li, 2 * c + lh) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], st, 0, 0, 0);
     }
@@ -119,15 +133,18 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    if (kt > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
 
     // Oᵀ[c][i] += sum_j V[j][c] P[j][i] ; MFMA step r sums keys j(r,0) and j(r,1)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float v0 = Vs[j * LD + li];
-      const float v1 = Vs[j * LD + 32 + li];
+      const float* vrow = Vs + j * DH + (li & 3);
+      const float v0 = vrow[swz(j, li >> 2) * 4];
+      const float v1 = vrow[swz(j, 8 + (li >> 2)) * 4];
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o1, 0, 0, 0);
     }
@@ -135,16 +152,23 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // fully masked row -> zeros
-  if (li < q_rows) {
-    float* orow = ctx + (tok0 + qi) * (int64_t)d + head * DH;
-    // lane (i,h), register 4q..4q+3 <-> channels 8q + 4h + (0..3) (+32 for o1)
+  // Epilogue through LDS (the Q tile is dead: its fragments live in registers) so that every global store
+  // instruction writes whole 256-B head rows.  lane (i,h), registers 4q..4q+3 <-> channels 8q+4h+(0..3) (+32 for o1)
+  __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 a = {o0[4 * q] * inv, o0[4 * q + 1] * inv, o0[4 * q + 2] * inv, o0[4 * q + 3] * inv};
-      f32x4 b = {o1[4 * q] * inv, o1[4 * q + 1] * inv, o1[4 * q + 2] * inv, o1[4 * q + 3] * inv};
-      *reinterpret_cast<f32x4*>(orow + 8 * q + 4 * lh) = a;
-      *reinterpret_cast<f32x4*>(orow + 32 + 8 * q + 4 * lh) = b;
-    }
+  for (int q = 0; q < 4; ++q) {
+    f32x4 a = {o0[4 * q] * inv, o0[4 * q + 1] * inv, o0[4 * q + 2] * inv, o0[4 * q + 3] * inv};
+    f32x4 b = {o1[4 * q] * inv, o1[4 * q + 1] * inv, o1[4 * q + 2] * inv, o1[4 * q + 3] * inv};
+    *reinterpret_cast<f32x4*>(Qs + li * DH + swz(li, 2 * q + lh) * 4) = a;
+    *reinterpret_cast<f32x4*>(Qs + li * DH + swz(li, 8 + 2 * q + lh) * 4) = b;
+  }
+  __syncthreads();
+  float* obase = ctx + (tok0 + q_first) * (int64_t)d + head * DH;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 4 * i + (lane >> 4), chunk = lane & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Qs + row * DH + swz(row, chunk) * 4);
+    if (row < q_rows) *reinterpret_cast<f32x4*>(obase + (int64_t)row * d + chunk * 4) = v;
   }
 }
 
@@ -161,9 +185,9 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
   const int nt = (GL + TILE - 1) / TILE;
   const int64_t n_tokens = S * L;
   const int64_t groups = (S + P - 1) / P;
-  if (groups * nt > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles");
+  if (groups * nt * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles");
   StltProfScope ps(kid, s);
-  dim3 grid((unsigned)(groups * nt), (unsigned)H);
+  dim3 grid((unsigned)(groups * nt * H));
   hipLaunchKernelGGL(attn_core_kernel, grid, dim3(64), 0, s, qkv, kpm, causal, n_tokens, (int)L, (int)H, GL, nt,
                      1.0f / sqrtf((float)dh), ctx);
   return stlt_check_launch("attn_core_kernel");
