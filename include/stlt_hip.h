@@ -136,6 +136,10 @@ int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, s
 int stlt_prof_enable(int on);                       /* 1: record events around each launch (serialises nothing, adds events) */
 int stlt_prof_collect(double* ms_out, int64_t* launches_out); /* sync events, accumulate per-kernel ms / launch counts, reset */
 
+/* Diagnostics only: when non-NULL, stlt_attn_core_fwd runs its s_memtime-stamped build and writes 8 phase
+ * stamps (uint64) per (tile, head) item to dev_buf.  Pass NULL to restore the product kernel. */
+int stlt_debug_attn_stamps(void* dev_buf);
+
 #ifdef __cplusplus
 }
 #endif

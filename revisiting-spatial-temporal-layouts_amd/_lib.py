@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libstlt_hip.so")
+LIB_PATH = os.environ.get("STLT_HIP_LIB") or os.path.join(HERE, "libstlt_hip.so")  # env override: A/B experiments only
 
 K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "frames_embed", "gather_last")
 FLAG_CLS_ONLY_LAST_SPATIAL = 1
@@ -59,6 +59,7 @@ SIGNATURES = {
     "stlt_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
     "stlt_prof_enable": (C.c_int, [C.c_int]),
     "stlt_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "stlt_debug_attn_stamps": (C.c_int, [_vp]),
 }
 
 _lib = None

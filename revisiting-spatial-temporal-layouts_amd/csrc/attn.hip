@@ -12,6 +12,8 @@
 // B operand of Oᵀ += Vᵀ·Pᵀ (MFMA sums over the accumulator's row index: no lane movement, no LDS round
 // trip).  Q/K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: fully coalesced 256-B head rows, no
 // staging VGPRs), XOR-swizzled for conflict-free fragment reads; the output tile leaves through LDS as whole rows.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -42,62 +44,103 @@ __device__ __forceinline__ void tile_dma(float* lds_tile, const float* __restric
   }
 }
 
-__global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ kpm,
-                                                       int causal, int64_t n_tokens, int L, int H, int GL, int nt,
-                                                       float scale, float* __restrict__ ctx) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * TILE_FLOATS + TILE];
-  float* Qs = smem;
-  float* Ks = smem + TILE_FLOATS;
-  float* Vs = smem + 2 * TILE_FLOATS;
-  int* kmeta = reinterpret_cast<int*>(smem + 3 * TILE_FLOATS);
+// MFMA A/B operand fragments of a 32x64 tile straight from global memory: lane (r, h) holds, for c = 0..7, the
+// 4 consecutive channels of 16-B chunk 2c+h of row r (rows past the end re-read the last valid row).
+__device__ __forceinline__ void frag_load(f32x4 (&f)[8], const float* __restrict__ src, int64_t ld, int rows_valid,
+                                          int li, int lh) {
+  const int rr = li < rows_valid ? li : rows_valid - 1;
+  const float* row = src + (int64_t)rr * ld + 4 * lh;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) f[c] = *reinterpret_cast<const f32x4*>(row + 8 * c);
+}
 
-  const int lane = threadIdx.x;
-  const int li = lane & 31, lh = lane >> 5;
-  // head-fastest block order: the waves resident at any moment cover all heads of the same tokens, i.e. whole
-  // contiguous qkv rows.
-  const int head = blockIdx.x % H;
-  const int64_t tile_id = blockIdx.x / H;
+// A wave only ever touches its own LDS slice, so synchronisation is wave-local: wait for this wave's LDS-DMA
+// (vmcnt) and LDS ops (lgkmcnt); DS operations of one wave execute in order.  No s_barrier: the waves of a
+// workgroup walk different items.
+__device__ __forceinline__ void wave_mem_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+constexpr int WAVES = 4;                                   // independent waves per workgroup
+constexpr int WAVE_LDS_FLOATS = 2 * TILE_FLOATS + TILE;    // two V buffers + key metadata
+
+// Geometry of one step = (item, key tile).  item = (token group, query tile, head), head fastest so that the
+// waves of a workgroup read adjacent 256-B head slices of the same rows.
+struct StepGeo {
+  int head, qb, q_first, q_rows, k_first, k_rows, kt_end;
+  int64_t tok0;
+};
+
+__device__ __forceinline__ StepGeo step_geo(int64_t item, int kt, int64_t n_tokens, int L, int H, int GL, int nt,
+                                            int causal) {
+  StepGeo s;
+  s.head = (int)(item % H);
+  const int64_t tile_id = item / H;
   const int64_t g = tile_id / nt;
-  const int qb = (int)(tile_id % nt);
-  const int64_t tok0 = g * GL;
-  const int gvalid = (int)((n_tokens - tok0) < GL ? (n_tokens - tok0) : GL);  // tokens of this group
+  s.qb = (int)(tile_id % nt);
+  s.tok0 = g * GL;
+  const int gvalid = (int)((n_tokens - s.tok0) < GL ? (n_tokens - s.tok0) : GL);
+  s.q_first = s.qb * TILE;
+  s.q_rows = gvalid - s.q_first < TILE ? gvalid - s.q_first : TILE;
+  s.k_first = kt * TILE;
+  s.k_rows = gvalid - s.k_first < TILE ? gvalid - s.k_first : TILE;
+  s.kt_end = (causal && GL == L) ? s.qb + 1 : nt;  // causal: key tiles past the query tile are fully masked
+  return s;
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* __restrict__ qkv,
+                                                                  const uint8_t* __restrict__ kpm, int causal,
+                                                                  int64_t n_tokens, int64_t n_items, int L, int H,
+                                                                  int GL, int nt, float scale,
+                                                                  float* __restrict__ ctx,
+                                                                  unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(16))) float smem_all[WAVES * WAVE_LDS_FLOATS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* smem = smem_all + wave * WAVE_LDS_FLOATS;
+  int* kmeta = reinterpret_cast<int*>(smem + 2 * TILE_FLOATS);
+
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
   const int d = H * DH;
   const int64_t ld = 3 * (int64_t)d;
-  const int q_first = qb * TILE;
-  const int q_rows = gvalid - q_first < TILE ? gvalid - q_first : TILE;
-  if (q_rows <= 0) return;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;  // persistent waves: item, item + stride, ...
+  int64_t item = (int64_t)blockIdx.x * WAVES + wave;
+  if (item >= n_items) return;
 
-  // this lane's query: position in the group, sequence id and position in the sequence
-  const int qi = q_first + li;
-  const int q_seq = qi / L, q_pos = qi - q_seq * L;
+  unsigned long long ts[8];
+#define STAMP_AT(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); ts[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+  STAMP_AT(0);
+
+  f32x4 qf[8], kf[8];
+  int kt = 0, buf = 0;
+  uint8_t pad;
+  {  // prologue: first step's loads
+    const StepGeo s0 = step_geo(item, 0, n_tokens, L, H, GL, nt, causal);
+    frag_load(qf, qkv + (s0.tok0 + s0.q_first) * ld + s0.head * DH, ld, s0.q_rows, li, lh);
+    frag_load(kf, qkv + (s0.tok0 + s0.k_first) * ld + d + s0.head * DH, ld, s0.k_rows, li, lh);
+    tile_dma(smem, qkv + (s0.tok0 + s0.k_first) * ld + 2 * d + s0.head * DH, ld, s0.k_rows, lane);
+    pad = kpm[s0.tok0 + s0.k_first + (li < s0.k_rows ? li : 0)];
+  }
 
   f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
-  f32x4 qf[8];
 
-  const int kt_end = (causal && GL == L) ? qb + 1 : nt;  // causal: key tiles past the query tile are fully masked
-  for (int kt = 0; kt < kt_end; ++kt) {
-    const int k_first = kt * TILE;
-    const int k_rows = gvalid - k_first < TILE ? gvalid - k_first : TILE;
-    if (kt > 0) __syncthreads();  // previous tile's LDS reads are done
-    // every byte of the tile (and, first time round, the queries) is in flight before the first wait
-    if (kt == 0) tile_dma(Qs, qkv + (tok0 + q_first) * ld + head * DH, ld, q_rows, lane);
-    tile_dma(Ks, qkv + (tok0 + k_first) * ld + d + head * DH, ld, k_rows, lane);
-    tile_dma(Vs, qkv + (tok0 + k_first) * ld + 2 * d + head * DH, ld, k_rows, lane);
+  for (;;) {
+    const StepGeo s = step_geo(item, kt, n_tokens, L, H, GL, nt, causal);
+    float* Vs = smem + buf * TILE_FLOATS;
+    STAMP_AT(1);
+    wave_mem_sync();  // this step's fragments + V tile have landed (and the previous item's stores retired)
+    STAMP_AT(2);
     {
       // key metadata for the mask: -1 = masked/absent, else (sequence id << 16) | position in sequence
-      const int kj = k_first + li;
-      const bool kvalid = li < k_rows;
-      const uint8_t pad = kpm[tok0 + (kvalid ? kj : k_first)];
+      const int kj = s.k_first + li;
       const int ks = kj / L;
-      if (lane < TILE) kmeta[lane] = (kvalid && pad == 0) ? ((ks << 16) | (kj - ks * L)) : -1;
+      if (lane < TILE) kmeta[lane] = (li < s.k_rows && pad == 0) ? ((ks << 16) | (kj - ks * L)) : -1;
     }
-    __syncthreads();  // waits vmcnt(0) (LDS-DMA landed) + lgkmcnt(0)
     if (kt == 0) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4*>(Qs + li * DH + swz(li, 2 * c + lh) * 4);
+      for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+      m_run = -1e30f;
+      l_run = 0.f;
     }
 
     // Sᵀ[j][i] = sum_k K[j][k] Q[i][k]
@@ -106,19 +149,42 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * DH + swz(li, 2 * c + lh) * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], st, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c][e], qf[c][e], st, 0, 0, 0);
     }
 
-    // mask + online softmax; register r <-> key j = (r&3) + 8*(r>>2) + 4*lh
+    // The K (and, at the end of an item, Q) registers are dead: put the next step's loads in flight now so
+    // that mask/softmax, P·V, the epilogue and the stores run under their latency.
+    int64_t n_item = item;
+    int n_kt = kt + 1;
+    if (n_kt >= s.kt_end) { n_item = item + stride; n_kt = 0; }
+    const bool have_next = n_item < n_items;
+    uint8_t n_pad = 0;
+    if (have_next) {
+      const StepGeo sn = step_geo(n_item, n_kt, n_tokens, L, H, GL, nt, causal);
+      if (n_kt == 0) frag_load(qf, qkv + (sn.tok0 + sn.q_first) * ld + sn.head * DH, ld, sn.q_rows, li, lh);
+      frag_load(kf, qkv + (sn.tok0 + sn.k_first) * ld + d + sn.head * DH, ld, sn.k_rows, li, lh);
+      tile_dma(smem + (buf ^ 1) * TILE_FLOATS, qkv + (sn.tok0 + sn.k_first) * ld + 2 * d + sn.head * DH, ld, sn.k_rows, lane);
+      n_pad = kpm[sn.tok0 + sn.k_first + (li < sn.k_rows ? li : 0)];
+    }
+    if (STAMP) asm volatile("" :: "v"(st[0]), "v"(st[15]));
+    STAMP_AT(3);
+
+    // mask + online softmax; register r <-> key j = (r&3) + 8*(r>>2) + 4*lh.  Branch-free: all 16 metadata
+    // words are fetched first (two addresses per instruction -> LDS broadcast).
+    const int qi = s.q_first + li;
+    const int q_seq = qi / L, q_pos = qi - q_seq * L;
+    const int q_hi = q_seq << 16;
+    const int pos_lim = causal ? q_pos : 0xffff;
+    int meta[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) meta[r] = kmeta[(r & 3) + 8 * (r >> 2) + 4 * lh];
     float p[16];
     float m_tile = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int meta = kmeta[j];
-      const bool ok = meta >= 0 && (meta >> 16) == q_seq && (!causal || (meta & 0xffff) <= q_pos);
+      // valid key: meta >= 0, same sequence, position <= limit
+      const bool ok = (meta[r] >= 0) & ((meta[r] & ~0xffff) == q_hi) & ((meta[r] & 0xffff) <= pos_lim);
       p[r] = ok ? st[r] * scale : -1e30f;
       m_tile = fmaxf(m_tile, p[r]);
     }
@@ -137,6 +203,8 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     }
+    if (STAMP) asm volatile("" :: "v"(p[0]), "v"(p[15]), "v"(l_run));
+    STAMP_AT(4);
 
     // Oᵀ[c][i] += sum_j V[j][c] P[j][i] ; MFMA step r sums keys j(r,0) and j(r,1)
 #pragma unroll
@@ -148,31 +216,51 @@ __global__ __launch_bounds__(64) void attn_core_kernel(const float* __restrict__
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o1, 0, 0, 0);
     }
-  }
+    if (STAMP) asm volatile("" :: "v"(o0[0]), "v"(o1[15]));
+    STAMP_AT(5);
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // fully masked row -> zeros
-  // Epilogue through LDS (the Q tile is dead: its fragments live in registers) so that every global store
-  // instruction writes whole 256-B head rows.  lane (i,h), registers 4q..4q+3 <-> channels 8q+4h+(0..3) (+32 for o1)
-  __syncthreads();
+    if (kt + 1 >= s.kt_end) {
+      const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+      const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;  // fully masked row -> zeros
+      // Epilogue through LDS (this step's V buffer is dead after the last P·V) so that every global store
+      // instruction writes whole 256-B head rows.  lane (i,h), registers 4q..4q+3 <-> channels 8q+4h+(0..3)
+      // (+32 for o1).  DS ops of a wave execute in order: no wait needed between the P·V reads and these writes.
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 a = {o0[4 * q] * inv, o0[4 * q + 1] * inv, o0[4 * q + 2] * inv, o0[4 * q + 3] * inv};
-    f32x4 b = {o1[4 * q] * inv, o1[4 * q + 1] * inv, o1[4 * q + 2] * inv, o1[4 * q + 3] * inv};
-    *reinterpret_cast<f32x4*>(Qs + li * DH + swz(li, 2 * q + lh) * 4) = a;
-    *reinterpret_cast<f32x4*>(Qs + li * DH + swz(li, 8 + 2 * q + lh) * 4) = b;
-  }
-  __syncthreads();
-  float* obase = ctx + (tok0 + q_first) * (int64_t)d + head * DH;
+      for (int q = 0; q < 4; ++q) {
+        f32x4 a = {o0[4 * q] * inv, o0[4 * q + 1] * inv, o0[4 * q + 2] * inv, o0[4 * q + 3] * inv};
+        f32x4 b = {o1[4 * q] * inv, o1[4 * q + 1] * inv, o1[4 * q + 2] * inv, o1[4 * q + 3] * inv};
+        *reinterpret_cast<f32x4*>(Vs + li * DH + swz(li, 2 * q + lh) * 4) = a;
+        *reinterpret_cast<f32x4*>(Vs + li * DH + swz(li, 8 + 2 * q + lh) * 4) = b;
+      }
+      STAMP_AT(6);
+      float* obase = ctx + (s.tok0 + s.q_first) * (int64_t)d + s.head * DH;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = 4 * i + (lane >> 4), chunk = lane & 15;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(Qs + row * DH + swz(row, chunk) * 4);
-    if (row < q_rows) *reinterpret_cast<f32x4*>(obase + (int64_t)row * d + chunk * 4) = v;
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + (lane >> 4), chunk = lane & 15;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Vs + row * DH + swz(row, chunk) * 4);
+        if (row < s.q_rows) *reinterpret_cast<f32x4*>(obase + (int64_t)row * d + chunk * 4) = v;
+      }
+      if (STAMP) {
+        STAMP_AT(7);
+        if (lane == 0 && stamps) {
+          for (int k = 0; k < 8; ++k) stamps[item * 8 + k] = ts[k];
+        }
+        STAMP_AT(0);
+      }
+    }
+    if (!have_next) break;
+    item = n_item;
+    kt = n_kt;
+    pad = n_pad;
+    buf ^= 1;
   }
+#undef STAMP_AT
 }
 
 }  // namespace
+
+static unsigned long long* g_attn_stamps = nullptr;
+extern "C" int stlt_debug_attn_stamps(void* dev_buf) { g_attn_stamps = (unsigned long long*)dev_buf; return 0; }
 
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s) {
@@ -187,8 +275,27 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
   const int64_t groups = (S + P - 1) / P;
   if (groups * nt * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles");
   StltProfScope ps(kid, s);
-  dim3 grid((unsigned)(groups * nt * H));
-  hipLaunchKernelGGL(attn_core_kernel, grid, dim3(64), 0, s, qkv, kpm, causal, n_tokens, (int)L, (int)H, GL, nt,
-                     1.0f / sqrtf((float)dh), ctx);
+  const int64_t n_items = groups * nt * H;
+  // persistent waves: as many workgroups as are resident at once (occupancy API x CU count), each wave strides
+  // over the items; there is no inter-workgroup dependency, so a wrong residency guess only costs speed
+  static int n_cu = 0, wg_per_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
+      wg_per_cu = 1;
+    if (getenv("STLT_DEBUG")) fprintf(stderr, "[stlt] attn: %d CUs, %d workgroups/CU of %d waves\n", n_cu, wg_per_cu, WAVES);
+  }
+  int64_t n_wg = (n_items + WAVES - 1) / WAVES;
+  if (n_wg > (int64_t)wg_per_cu * n_cu) n_wg = (int64_t)wg_per_cu * n_cu;
+  dim3 grid((unsigned)n_wg);
+  if (g_attn_stamps)  // diagnostic build path only (tools/attn_stamps.py); never set by the product
+    hipLaunchKernelGGL(attn_core_kernel<true>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
+                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, g_attn_stamps);
+  else
+    hipLaunchKernelGGL(attn_core_kernel<false>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
+                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr);
   return stlt_check_launch("attn_core_kernel");
 }
