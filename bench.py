@@ -43,10 +43,10 @@ def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU per step (1024 makes every cfg2 GEMM a whole number of 256-tile rounds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cls-only", action="store_true", help="run the last spatial layer on every token")
     args = ap.parse_args()

@@ -136,9 +136,10 @@ int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, s
 int stlt_prof_enable(int on);                       /* 1: record events around each launch (serialises nothing, adds events) */
 int stlt_prof_collect(double* ms_out, int64_t* launches_out); /* sync events, accumulate per-kernel ms / launch counts, reset */
 
-/* Diagnostics only: when non-NULL, stlt_attn_core_fwd runs its s_memtime-stamped build and writes 8 phase
- * stamps (uint64) per (tile, head) item to dev_buf.  Pass NULL to restore the product kernel. */
-int stlt_debug_attn_stamps(void* dev_buf);
+/* Diagnostics only (tools/attn_stamps.py, tools/gemm_block_times.py): when non-NULL, stlt_attn_core_fwd runs its
+ * s_memtime-stamped build (8 uint64 phase stamps per item) and stlt_linear_fwd records per-workgroup start/end
+ * times (4 uint64 per workgroup) into dev_buf.  Pass NULL to restore normal operation. */
+int stlt_debug_set_buffer(void* dev_buf);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ SIGNATURES = {
     "stlt_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
     "stlt_prof_enable": (C.c_int, [C.c_int]),
     "stlt_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "stlt_debug_attn_stamps": (C.c_int, [_vp]),
+    "stlt_debug_set_buffer": (C.c_int, [_vp]),
 }
 
 _lib = None

@@ -56,7 +56,11 @@ void stlt_prof_end(int kid, hipStream_t s) {
   g_open_start = nullptr;
 }
 
+unsigned long long* g_stlt_debug_buf = nullptr;
+
 extern "C" {
+
+int stlt_debug_set_buffer(void* dev_buf) { g_stlt_debug_buf = (unsigned long long*)dev_buf; return 0; }
 
 int stlt_version(void) { return STLT_VERSION; }
 const char* stlt_last_error(void) { return g_err; }

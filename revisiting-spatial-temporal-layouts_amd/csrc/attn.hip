@@ -259,8 +259,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
 
 }  // namespace
 
-static unsigned long long* g_attn_stamps = nullptr;
-extern "C" int stlt_debug_attn_stamps(void* dev_buf) { g_attn_stamps = (unsigned long long*)dev_buf; return 0; }
 
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s) {
@@ -291,9 +289,9 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
   int64_t n_wg = (n_items + WAVES - 1) / WAVES;
   if (n_wg > (int64_t)wg_per_cu * n_cu) n_wg = (int64_t)wg_per_cu * n_cu;
   dim3 grid((unsigned)n_wg);
-  if (g_attn_stamps)  // diagnostic build path only (tools/attn_stamps.py); never set by the product
+  if (g_stlt_debug_buf)  // diagnostic build path only (tools/attn_stamps.py); never set by the product
     hipLaunchKernelGGL(attn_core_kernel<true>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
-                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, g_attn_stamps);
+                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, g_stlt_debug_buf);
   else
     hipLaunchKernelGGL(attn_core_kernel<false>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
                        (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr);

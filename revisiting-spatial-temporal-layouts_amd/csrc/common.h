@@ -13,6 +13,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 int stlt_set_error(int code, const char* fmt, ...);
 int stlt_check_launch(const char* what);
 
+// diagnostics buffer (api.hip: stlt_debug_set_buffer); NULL in normal operation
+extern unsigned long long* g_stlt_debug_buf;
+
 // per-kernel timing hooks (api.hip)
 void stlt_prof_begin(int kid, hipStream_t s);
 void stlt_prof_end(int kid, hipStream_t s);

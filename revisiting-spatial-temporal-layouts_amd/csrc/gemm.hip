@@ -6,139 +6,285 @@
 //   v_mfma_f32_32x32x2_f32.  The k index inside an 8-wide chunk is permuted (MFMA e pairs k = 8c+e with
 //   k = 8c+4+e); a sum over k does not care, and A and B use the same permutation.
 //
-//   Block tile 128x128x32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator
-//   VGPRs).  LDS rows are padded to 36 floats: conflict-free for the ds_read_b128 lane groups.
-//   Global->LDS staging goes through registers (issue the next tile's loads before the MFMAs of the
-//   current one, write them to the other LDS buffer after), one barrier per k-tile, 2 blocks per CU.
+// Structure (one persistent 512-thread workgroup per CU = 8 waves as 4x2):
+//   * block tile 256x128x32, each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).  The per-CU
+//     fetch path (~10 B/clk measured) is co-critical with the f32 MFMA pipe: two independent 128x128 tiles per
+//     CU need 8 B/clk at full MFMA rate and queue up at VMEM issue; one 256x128 tile needs 6 B/clk;
+//   * a workgroup walks its tiles (XCD-contiguous tile order) as ONE flattened stream of k-steps, so the next
+//     tile's operands are already in flight while a tile's epilogue runs;
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write.  The LDS image is
+//     lane-linear per wave instruction (8 rows x 128 B), so the bank swizzle chunk ^= (row>>1)&7 is applied
+//     to the per-lane SOURCE address and again on the fragment reads (conflict-free ds_read_b128);
+//   * three LDS stages (144 KB): step s+2's DMA is issued in thirds between the MFMA chunks of step s (into the
+//     stage retired by the previous barrier); the barrier that retires step s is preceded by a COUNTED
+//     vmcnt(6) that only waits for step s+1's data;
+//   * fragments are read one 8-wide k-chunk ahead (ping-pong registers), and the read of the next step's first
+//     chunk sits between the barrier and the last 16 MFMAs of the current step;
+//   * the bias is the accumulators' initial value, fetched one tile ahead.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
-constexpr int GEMM_THREADS = 256;
+constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int GEMM_WAVES = 8;
+constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
+constexpr int NSTAGE = 3;
+constexpr int STAGE_FLOATS = (BM + BN) * BK;  // 12288 floats = 48 KB per stage
 
-template <int ACT>
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <int ACT, bool STAMP>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ Y, int64_t ldy, int M, int N,
-                                                                  int K, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
-  constexpr int STAGE = (BM + BN) * LDS_LD;  // floats per pipeline stage: A tile then B tile
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
-  // contiguous run of tiles, walked N-fastest: neighbours then share the X panel and stream W through L2.
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+                                                                  int K, int tiles_m, int tiles_n,
+                                                                  unsigned long long* __restrict__ dbg) {
+  __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + 2 * BN];  // operand stages + 2 bias strips
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64x64
   const int lr = lane & 31, lh = lane >> 5;
+  const int nk = K / BK;
+  const int n_tiles = tiles_m * tiles_n;
 
-  // staging map: float4 f = tid + 256*i -> row f/8, 16-B column f%8 ; 8 consecutive lanes read one 128-B line
-  const int srow = tid >> 3, scol = (tid & 7) * 4;
-  const float* xg[4];
-  const float* wg[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int rm = m0 + srow + 32 * i;
-    rm = rm < M ? rm : M - 1;  // clamp: ragged tiles re-read the last row, stores are guarded
-    xg[i] = X + (int64_t)rm * ldx + scol;
-    int rn = n0 + srow + 32 * i;
-    rn = rn < N ? rn : N - 1;
-    wg[i] = W + (int64_t)rn * K + scol;
+  // XCD-contiguous tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so virtual id
+  // v = (b%8)*(G/8) + b/8 gives each XCD a contiguous run of tiles (N fastest: they share the X panel).
+  const int G = gridDim.x;
+  int v = blockIdx.x;
+  if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int my_tiles = (n_tiles - v + G - 1) / G;  // tiles v, v+G, v+2G, ...
+  if (my_tiles <= 0) return;
+  if (dbg && tid == 0) {  // diagnostics only (tools/gemm_block_times.py): per-workgroup start/end on the 100 MHz clock
+    dbg[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+    dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
+    dbg[4 * blockIdx.x + 3] = my_tiles;
   }
+  const int total_steps = my_tiles * nk;
 
+  auto tile_origin = [&](int it, int& m0, int& n0) {
+    const int tile = v + it * G;
+    const int tm = tile / tiles_n;
+    m0 = tm * BM;
+    n0 = (tile - tm * tiles_n) * BN;
+  };
+
+  // ---- DMA side -------------------------------------------------------------------------------------
+  // wave w stages rows [32w, 32w+32) of the A tile (4 instructions) and rows [16w, 16w+16) of the B tile (2).
+  // Row pointers are computed once per tile; a k-step only adds k0.
+  const int drow = lane >> 3, dslot = lane & 7;
+  const float* pa[4];
+  const float* pb[2];
+  auto dma_set_tile = [&](int it) {
+    int m0, n0;
+    tile_origin(it, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wave * 32 + i * 8 + drow;      // row inside the A tile
+      int gm = m0 + r;
+      gm = gm < M ? gm : M - 1;                    // ragged tiles re-read the last row; stores are guarded
+      pa[i] = X + (int64_t)gm * ldx + (dslot ^ ((r >> 1) & 7)) * 4;  // source-side swizzle
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = wave * 16 + i * 8 + drow;      // row inside the B tile
+      int gn = n0 + r;
+      gn = gn < N ? gn : N - 1;
+      pb[i] = W + (int64_t)gn * K + (dslot ^ ((r >> 1) & 7)) * 4;
+    }
+  };
+  // One k-step's DMA = 6 instructions per wave, issued in three parts (A rows 0-1, A rows 2-3, B rows) so they
+  // can be spread between the MFMA chunks of the previous step instead of queueing at the TA all at once.
+  auto issue_dma_part = [&](int part, int kt, int stage) {
+    const int k0 = kt * BK;
+    float* sa = smem + stage * STAGE_FLOATS + (wave * 32) * BK;
+    float* sb = smem + stage * STAGE_FLOATS + (BM + wave * 16) * BK;
+    if (part < 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(pa[2 * part + i] + k0), (lds_void_ptr)(sa + (2 * part + i) * 8 * BK), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(pb[i] + k0), (lds_void_ptr)(sb + i * 8 * BK), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment side --------------------------------------------------------------------------------
+  const int sw = (lr >> 1) & 7;
+  const int a_row = (wm * 64 + lr) * BK;         // + 32*BK for the second M tile
+  const int b_row = (BM + wn * 64 + lr) * BK;    // + 32*BK for the second N tile
+  struct Frags { f32x4 a0, a1, b0, b1; };
+  auto read_frags = [&](int stage, int c) {
+    const float* s = smem + stage * STAGE_FLOATS;
+    const int off = ((2 * c + lh) ^ sw) * 4;
+    Frags f;
+    f.a0 = *reinterpret_cast<const f32x4*>(s + a_row + off);
+    f.a1 = *reinterpret_cast<const f32x4*>(s + a_row + 32 * BK + off);
+    f.b0 = *reinterpret_cast<const f32x4*>(s + b_row + off);
+    f.b1 = *reinterpret_cast<const f32x4*>(s + b_row + 32 * BK + off);
+    return f;
+  };
+
+  // The bias is the accumulators' initial value (one column per lane: n is fixed per lane and N-tile), so the
+  // epilogue adds nothing.  The next tile's two bias values are fetched during the current tile's last k-step
+  // It travels like the operands: wave 0 DMAs the tile's 128 bias values into a small LDS strip (double
+  // buffered by tile parity) at the start of the previous tile's last k-step; that step's counted wait + barrier
+  // publish it, and every wave then reads its two columns with ordinary ds_reads.  (A VGPR-destination load here
+  // would make hipcc drain the DMA in flight with a vmcnt(0) at its first use.)
+  float* bias_lds = smem + NSTAGE * STAGE_FLOATS;
+  auto dma_bias = [&](int it) {
+    if (bias && wave == 0) {
+      int m0, n0;
+      tile_origin(it, m0, n0);
+      float* dst = bias_lds + (it & 1) * BN;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int n = n0 + i * 64 + lane;
+        n = n < N ? n : N - 1;  // columns past N are never stored
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(bias + n), (lds_void_ptr)(dst + i * 64), 4, 0, 0);
+      }
+    }
+  };
+  auto read_bias = [&](int it, float& b0, float& b1) {
+    if (bias) {
+      const float* src = bias_lds + (it & 1) * BN + wn * 64 + lr;
+      b0 = src[0];
+      b1 = src[32];
+    } else {
+      b0 = 0.f;
+      b1 = 0.f;
+    }
+  };
+  float bn0 = 0.f, bn1 = 0.f;
+  dma_bias(0);
   f32x16 acc[2][2];
+
+  auto mfma_chunk = [&](const Frags& f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], f.b0[e], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], f.b1[e], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], f.b0[e], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], f.b1[e], acc[1][1], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: two steps in flight ------------------------------------------------------------------
+  int d_it = 0, d_kt = 0;  // DMA stream position (runs two steps ahead of the MFMAs)
+  int d_stage = 0;
+  auto dma_part = [&](int part) {  // part 0 also moves to the next tile's row pointers when needed
+    if (part == 0 && d_kt == 0) dma_set_tile(d_it);
+    issue_dma_part(part, d_kt, d_stage);
+    if (part == 2) {
+      if (++d_kt == nk) { d_kt = 0; ++d_it; }
+      if (++d_stage == NSTAGE) d_stage = 0;
+    }
+  };
+  dma_part(0); dma_part(1); dma_part(2);
+  if (total_steps > 1) {
+    dma_part(0); dma_part(1); dma_part(2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // in-order counter: step 0 (and the bias strip before it) landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  read_bias(0, bn0, bn1);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[a][0][r] = bn0; acc[a][1][r] = bn1; }
+  Frags fa = read_frags(0, 0), fb;  // ping-pong fragment registers: 4 chunk reads per step, so fa is "current" at every step start
 
-  f32x4 xa[4], wb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    xa[i] = *reinterpret_cast<const f32x4*>(xg[i]);
-    wb[i] = *reinterpret_cast<const f32x4*>(wg[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<f32x4*>(&smem[(srow + 32 * i) * LDS_LD + scol]) = xa[i];
-    *reinterpret_cast<f32x4*>(&smem[(BM + srow + 32 * i) * LDS_LD + scol]) = wb[i];
-  }
-  __syncthreads();
+  int c_it = 0, c_kt = 0;  // MFMA stream position
+  int stage = 0;
+  unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
+#define GSTAMP(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); t_acc[k] += t_now - t_prev; t_prev = t_now; __builtin_amdgcn_sched_barrier(0); } } while (0)
+  if (STAMP) { t_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+  for (int step = 0; step < total_steps; ++step) {
+    const int next_stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    const bool prefetch = step + 2 < total_steps;  // step+2's operands go to the stage retired by the previous barrier
+    const bool bias_step = c_kt == nk - 1 && c_it + 1 < my_tiles;
+    if (bias_step) dma_bias(c_it + 1);  // older than this step's operand DMA: covered by the counted wait below
+    // chunks 0..2: read the next chunk of this stage, 16 MFMAs on the current one, a third of step+2's DMA
+    fb = read_frags(stage, 1);
+    mfma_chunk(fa);
+    if (prefetch) dma_part(0);
+    fa = read_frags(stage, 2);
+    mfma_chunk(fb);
+    if (prefetch) dma_part(1);
+    fb = read_frags(stage, 3);
+    mfma_chunk(fa);
+    if (prefetch) dma_part(2);
+    if (STAMP) asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][1][15]));
+    GSTAMP(0);  // chunks 0..2: 48 MFMAs + fragment reads + DMA issue
+    // chunk 3: retire this stage.  Every wave has received all its reads of `stage`, and step+1's DMA has
+    // landed.  The VMEM counter is in order: the only operations younger than step+1's DMA that may stay in
+    // flight are the 6 DMAs of step+2 (the bias strip and a previous epilogue's stores are older than those).
+    if (prefetch) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    GSTAMP(1);  // wait for own DMA + LDS reads
+    __builtin_amdgcn_s_barrier();
+    GSTAMP(2);  // barrier
+    if (bias_step) read_bias(c_it + 1, bn0, bn1);
+    GSTAMP(3);
+    if (step + 1 < total_steps) fa = read_frags(next_stage, 0);
+    mfma_chunk(fb);
+    if (STAMP) asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][1][15]));
+    GSTAMP(4);  // chunk 3: 16 MFMAs + next step's first fragment read
+    stage = next_stage;
 
-  const int nk = K / BK;
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      const int ko = (kt + 1) * BK;
+    if (++c_kt == nk) {
+      // ---- epilogue of tile c_it (the next tile's first fragments are already in registers, its next two
+      // k-steps are in flight).  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+      int m0, n0;
+      tile_origin(c_it, m0, n0);
+      const bool interior = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xa[i] = *reinterpret_cast<const f32x4*>(xg[i] + ko);
-        wb[i] = *reinterpret_cast<const f32x4*>(wg[i] + ko);
-      }
-    }
-    const float* Ac = smem + cur * STAGE + (wm * 64 + lr) * LDS_LD + 4 * lh;
-    const float* Bc = smem + cur * STAGE + (BM + wn * 64 + lr) * LDS_LD + 4 * lh;
+      for (int a = 0; a < 2; ++a) {
 #pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-      f32x4 a0 = *reinterpret_cast<const f32x4*>(Ac + 8 * c);
-      f32x4 a1 = *reinterpret_cast<const f32x4*>(Ac + 32 * LDS_LD + 8 * c);
-      f32x4 b0 = *reinterpret_cast<const f32x4*>(Bc + 8 * c);
-      f32x4 b1 = *reinterpret_cast<const f32x4*>(Bc + 32 * LDS_LD + 8 * c);
+        for (int b = 0; b < 2; ++b) {
+          const int n = n0 + wn * 64 + b * 32 + lr;
+          const int mb = m0 + wm * 64 + a * 32 + 4 * lh;
+          float* yp = Y + (int64_t)mb * ldy + n;
+          if (interior) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
-      }
-    }
-    if (more) {
-      float* An = smem + (cur ^ 1) * STAGE;
-      float* Bn = An + BM * LDS_LD;
+            for (int r = 0; r < 16; ++r) {
+              float val = acc[a][b][r];
+              if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+              yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = val;
+            }
+          } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4*>(&An[(srow + 32 * i) * LDS_LD + scol]) = xa[i];
-        *reinterpret_cast<f32x4*>(&Bn[(srow + 32 * i) * LDS_LD + scol]) = wb[i];
-      }
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+            for (int r = 0; r < 16; ++r) {
+              const int row = (r & 3) + 8 * (r >> 2);
+              float val = acc[a][b][r];
+              if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+              if (n < N && mb + row < M) yp[(int64_t)row * ldy] = val;
+            }
+          }
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int n = n0 + wn * 64 + b * 32 + lr;
-    if (n >= N) continue;
-    const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int mb = m0 + wm * 64 + a * 32 + 4 * lh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m < M) {
-          float v = acc[a][b][r] + bv;
-          if (ACT == STLT_ACT_GELU) v = gelu_erf(v);
-          Y[(int64_t)m * ldy + n] = v;
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = b == 0 ? bn0 : bn1;
         }
       }
+      c_kt = 0;
+      ++c_it;
+      GSTAMP(5);  // epilogue
     }
   }
+  if (dbg && tid == 0) dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  if (STAMP && dbg && lane == 0) {
+    unsigned long long* o = dbg + 4 * (size_t)gridDim.x + ((size_t)blockIdx.x * GEMM_WAVES + wave) * 6;
+    for (int k = 0; k < 6; ++k) o[k] = t_acc[k];
+  }
+#undef GSTAMP
 }
+
+int g_n_cu = 0;
 
 }  // namespace
 
@@ -152,12 +298,23 @@ int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias
   if (M > 0x7fffff00LL || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: M/N too large");
   if (act != STLT_ACT_NONE && act != STLT_ACT_GELU) return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: unknown activation %d", act);
   if (M == 0) return 0;
-  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  if (tiles_m * tiles_n > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: too many tiles");
+  if (g_n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_n_cu = prop.multiProcessorCount;
+    if (g_n_cu <= 0) g_n_cu = 256;
+  }
+  // persistent grid: one 144-KB workgroup per CU; no inter-workgroup dependency, so residency is only a speed matter
+  int64_t n_wg = tiles_m * tiles_n;
+  if (n_wg > g_n_cu) n_wg = g_n_cu;
   StltProfScope ps(STLT_K_GEMM, s);
-  dim3 grid((unsigned)(tiles_m * tiles_n)), block(GEMM_THREADS);
-  if (act == STLT_ACT_GELU)
-    hipLaunchKernelGGL((gemm_nt_kernel<STLT_ACT_GELU>), grid, block, 0, s, x, ldx, w, bias, y, ldy, (int)M, (int)N, (int)K, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<STLT_ACT_NONE>), grid, block, 0, s, x, ldx, w, bias, y, ldy, (int)M, (int)N, (int)K, tiles_m, tiles_n);
+  dim3 grid((unsigned)n_wg), block(GEMM_THREADS);
+#define LAUNCH(ACTV, STAMPV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV>), grid, block, 0, s, x, ldx, w, bias, y, ldy, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, g_stlt_debug_buf)
+  if (g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true);  // diagnostic build path only
+  else if (act == STLT_ACT_GELU) LAUNCH(STLT_ACT_GELU, false);
+  else LAUNCH(STLT_ACT_NONE, false);
+#undef LAUNCH
   return stlt_check_launch("gemm_nt_kernel");
 }

@@ -14,9 +14,9 @@ for (S, L, causal) in ((1024, 32, True), (32768, 7, False)):
     n_items = ((S + P - 1) // P) * ((P * L + 31) // 32) * H
     buf = torch.zeros(n_items * 8, dtype=torch.int64, device="cuda")
     for _ in range(3): pkg.ops.attn_core(qkv, kpm, causal, H)
-    lib.stlt_debug_attn_stamps(buf.data_ptr())
+    lib.stlt_debug_set_buffer(buf.data_ptr())
     pkg.ops.attn_core(qkv, kpm, causal, H); torch.cuda.synchronize()
-    lib.stlt_debug_attn_stamps(None)
+    lib.stlt_debug_set_buffer(None)
     t = buf.view(n_items, 8).cpu().double()
     dt = t[:, 1:] - t[:, :-1]
     tot = (t[:, 7] - t[:, 0])

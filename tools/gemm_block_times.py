@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-workgroup start/end times of the persistent GEMM (100 MHz s_memrealtime), grouped by XCD."""
+import importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("revisiting-spatial-temporal-layouts_amd")
+lib = pkg._lib.load()
+M, N, K = 229376, 768, 3072
+if len(sys.argv) > 3: M, N, K = map(int, sys.argv[1:4])
+x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+y = torch.empty(M, N, device="cuda")
+for _ in range(2): pkg.ops.linear(x, w, b, out=y)
+buf = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
+lib.stlt_debug_set_buffer(buf.data_ptr())
+pkg.ops.linear(x, w, b, out=y); torch.cuda.synchronize()
+lib.stlt_debug_set_buffer(None)
+G = min(((M + 255) // 256) * ((N + 127) // 128), 256)
+WAVES = 8
+t = buf[: 4 * G].view(G, 4).cpu()
+t0 = t[:, 0].min()
+st = (t[:, 0] - t0).double() / 100.0  # us
+en = (t[:, 1] - t0).double() / 100.0
+print(f"workgroups={len(t)} tiles/wg min {t[:,3].min()} max {t[:,3].max()}  kernel span {en.max():.1f} us")
+print(f"start: max {st.max():.1f} us ; end: min {en.min():.1f} median {en.median():.1f} max {en.max():.1f} us ; mean idle tail {(en.max()-en).mean():.1f} us")
+for xcc in sorted(set(t[:, 2].tolist())):
+    m = t[:, 2] == xcc
+    print(f"  xcc {xcc}: wgs {int(m.sum()):4d} end min {en[m].min():8.1f} med {en[m].median():8.1f} max {en[m].max():8.1f}")
+import numpy as np
+e = en.numpy()
+hist, edges = np.histogram(e, bins=12)
+print("end-time histogram:", list(zip([f"{x:.0f}" for x in edges[:-1]], hist.tolist())))
+slow = np.nonzero(e > (np.median(e) * 1.1))[0]
+print("slow workgroups (blockIdx):", slow[:64].tolist(), "count", len(slow))
+if os.environ.get("STLT_GEMM_STAMP"):
+    ph = buf[4 * G: 4 * G + G * WAVES * 6].view(G * WAVES, 6).cpu().double()
+    names = ["chunks0-2 (48 MFMA)", "wait vmcnt/lgkm", "barrier", "DMA issue", "chunk3 (16 MFMA)", "epilogue"]
+    tot = ph.sum(1)
+    steps = float(t[:, 3].double().mean()) * (K // 32)
+    print(f"per-wave cycles total median {tot.median():.0f}; per k-step:")
+    for k, n in enumerate(names):
+        print(f"   {n:22s} share {ph[:, k].sum() / tot.sum():.3f}   per-step median {(ph[:, k] / steps).median():8.1f} cycles")
