@@ -169,3 +169,28 @@ def test_state_dict_roundtrip_and_train_flag(pkg):
     m.train(False)
     with torch.no_grad():
         assert torch.equal(a, m(_to(batch))["stlt"])
+
+
+def test_inference_loop_counters_match_oracle(pkg):
+    """A9 counterpart (reference src/inference.py:75-84): eval loop over batches, top-1/top-5 from device counters."""
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    sd, batch, z, meta = golden_case(name)
+    m = _model(pkg, name, sd)
+    batches = []
+    for i, n in enumerate((8, 5)):
+        b = pkg.synth.make_batch(n, c["T"], c["N"], seed=40 + i)
+        with torch.no_grad():
+            ref = O.stlt_forward(sd, b, c["num_attention_heads"])["stlt"]
+        # labels chosen so that top-1 hits, top-5-only hits and misses all occur
+        order = ref.argsort(dim=1, descending=True)
+        b["labels"] = torch.stack([order[j, (0, 3, 20)[j % 3]] for j in range(n)])
+        batches.append((b, ref))
+    res = pkg.infer.run_inference(m, [b for b, _ in batches], DEV, collect_logits=True)
+    ref_all = torch.cat([r for _, r in batches])
+    assert (res["logits"] - ref_all).abs().max().item() <= TOL
+    n = 13
+    exp1 = sum(1 for j in range(8) if j % 3 == 0) + sum(1 for j in range(5) if j % 3 == 0)
+    exp5 = sum(1 for j in range(8) if j % 3 != 2) + sum(1 for j in range(5) if j % 3 != 2)
+    assert res["num_clips"] == n
+    assert res["top1_accuracy"] == round(100.0 * exp1 / n, 2) and res["top5_accuracy"] == round(100.0 * exp5 / n, 2)
