@@ -35,7 +35,10 @@ def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only):
     f = full_sp * tok * per_row
     if full_sp != n_sp:
         f += tok * 4.0 * d * d + bt * 20.0 * d * d  # K,V for every token; Q/out-proj/FFN for the CLS rows
-    f += n_tp * bt * per_row
+    if cls_only and n_tp > 0 and T > 1:  # last temporal layer: QKV for every frame, out-proj/FFN for one row per clip
+        f += (n_tp - 1) * bt * per_row + bt * 6.0 * d * d + B * 18.0 * d * d
+    else:
+        f += n_tp * bt * per_row
     f += B * (2.0 * d * d + 2.0 * d * classes)
     return f
 
@@ -48,7 +51,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--batch", type=int, default=1024, help="clips per GPU per step (1024 makes every cfg2 GEMM a whole number of 256-tile rounds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cls-only", action="store_true", help="run the last spatial layer on every token")
+    ap.add_argument("--no-cls-only", action="store_true", help="dense schedule: run the last spatial / last temporal layer on every token")
     args = ap.parse_args()
 
     import torch
@@ -78,6 +81,7 @@ def main():
     model.train(False)
     model.to(dev)
     model.backbone.cls_only_last_spatial = not args.no_cls_only
+    model.backbone.last_row_only_temporal = not args.no_cls_only
     B, T, N, d = args.batch, c["T"], c["N"], c["hidden_size"]
     cpu_batch = pkg.synth.make_batch(B, T, N, dataset=c["dataset"], seed=1000 + rank)
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}

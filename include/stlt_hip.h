@@ -111,6 +111,7 @@ typedef struct {
 } stlt_inputs;
 
 #define STLT_FLAG_CLS_ONLY_LAST_SPATIAL 1 /* last spatial layer: Q/out-proj/FFN on the CLS rows only (the only rows read, models.py:79) */
+#define STLT_FLAG_LAST_ROW_ONLY_TEMPORAL 2 /* stlt_forward with out_btd == NULL: last temporal layer's out-proj/FFN on the rows at lengths-1 only (models.py:189-192) */
 
 /* bytes of scratch the whole-path calls need for this shape */
 size_t stlt_workspace_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes);

@@ -186,11 +186,13 @@ static int check_params(const stlt_params* p, const stlt_inputs* in, bool need_h
   return 0;
 }
 
-int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
-                          int flags, float* out_btd, stlt_stream_t stream) {
-  TRY(check_params(p, in, false));
-  if (!out_btd) return stlt_set_error(STLT_EINVAL, "stlt_backbone_forward: out_btd is null");
-  hipStream_t s = (hipStream_t)stream;
+}  // extern "C"
+
+// Backbone body.  With last_rows != nullptr the final temporal layer only produces the rows the head reads
+// (Stlt.forward, models.py:189-192: out[lengths-1, arange(B)]) into last_rows (B,d): K/V/Q are projected for every
+// frame, the attention core runs as usual, but out-proj / norm1 / FFN / norm2 run on the B gathered rows only.
+static int backbone_impl(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
+                         int flags, float* out_btd, float* last_rows, hipStream_t s) {
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
   const WsLayout w = ws_layout(B, T, N, d, p->n_classes < 0 ? 0 : p->n_classes);
   if (!workspace || workspace_bytes < w.total)
@@ -239,12 +241,37 @@ int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* wor
   // temporal transformer: sequences = clips (B), tokens = frames (T), causal + key padding.  Layers run in
   // place on tbuf (a layer's input is last read by its norm1), x is the post-norm1 scratch; the last layer
   // writes the caller's buffer.
-  for (int64_t l = 0; l < p->n_temporal; ++l) {
+  const int64_t n_full = last_rows ? p->n_temporal - 1 : p->n_temporal;
+  for (int64_t l = 0; l < n_full; ++l) {
     float* dst = (l == p->n_temporal - 1) ? out_btd : tbuf;
     TRY(encoder_layer(p->temporal[l], d, H, tbuf, BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, qkv, ctx, tmp,
                       x, hh, dst, s));
   }
+  if (last_rows) {
+    const stlt_layer_params& lp = p->temporal[p->n_temporal - 1];
+    float* g_ctx = x;                      // (B,d) gathered attention rows
+    float* g_res = x + (size_t)B * d;      // (B,d) gathered layer-input rows (residual)
+    float* g_x1 = hh + (size_t)B * 4 * d;  // (B,d) post-norm1, behind the (B,4d) FFN hidden (T > 1 => hh holds >= 2*B*4d)
+    TRY(launch_linear(tbuf, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, BT, 3 * d, d, STLT_ACT_NONE, s));
+    TRY(launch_attn(qkv, in->kpm_frames, 1, B, T, H, d / H, ctx, STLT_K_ATTN_TEMPORAL, s));
+    TRY(launch_gather_last(ctx, in->lengths, B, T, d, g_ctx, s));
+    TRY(launch_gather_last(tbuf, in->lengths, B, T, d, g_res, s));
+    TRY(launch_linear(g_ctx, d, lp.out_proj_w, lp.out_proj_b, tmp, d, B, d, d, STLT_ACT_NONE, s));
+    TRY(launch_add_layernorm(tmp, d, g_res, d, lp.norm1_w, lp.norm1_b, 1e-5f, B, d, g_x1, d, s));
+    TRY(launch_linear(g_x1, d, lp.lin1_w, lp.lin1_b, hh, 4 * d, B, 4 * d, d, STLT_ACT_GELU, s));
+    TRY(launch_linear(hh, 4 * d, lp.lin2_w, lp.lin2_b, tmp, d, B, d, 4 * d, STLT_ACT_NONE, s));
+    TRY(launch_add_layernorm(tmp, d, g_x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, B, d, last_rows, d, s));
+  }
   return 0;
+}
+
+extern "C" {
+
+int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
+                          int flags, float* out_btd, stlt_stream_t stream) {
+  TRY(check_params(p, in, false));
+  if (!out_btd) return stlt_set_error(STLT_EINVAL, "stlt_backbone_forward: out_btd is null");
+  return backbone_impl(p, in, workspace, workspace_bytes, flags, out_btd, nullptr, (hipStream_t)stream);
 }
 
 int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes, int flags,
@@ -258,11 +285,16 @@ int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, s
     return stlt_set_error(STLT_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
   char* base = (char*)workspace;
   float* bb_out = out_btd ? out_btd : (float*)(base + w.x1);  // x1 doubles as the in-place temporal buffer
-  TRY(stlt_backbone_forward(p, in, workspace, workspace_bytes, flags, bb_out, stream));
   float* h0 = (float*)(base + w.head);
   float* h1 = h0 + (size_t)B * d;
   float* h2 = h1 + (size_t)B * d;
-  TRY(launch_gather_last(bb_out, in->lengths, B, T, d, h0, s));                                   // models.py:189-192
+  const bool last_only = (flags & STLT_FLAG_LAST_ROW_ONLY_TEMPORAL) && !out_btd && p->n_temporal > 0 && in->T > 1;
+  if (last_only) {  // the caller does not want the (B,T,d) backbone output: produce only the rows the head reads
+    TRY(backbone_impl(p, in, workspace, workspace_bytes, flags, bb_out, h0, s));
+  } else {
+    TRY(backbone_impl(p, in, workspace, workspace_bytes, flags, bb_out, nullptr, s));
+    TRY(launch_gather_last(bb_out, in->lengths, B, T, d, h0, s));                                 // models.py:189-192
+  }
   TRY(launch_linear(h0, d, p->fc1_w, p->fc1_b, h1, d, B, d, d, STLT_ACT_GELU, s));                // gelu(fc1(h))
   TRY(launch_add_layernorm(h1, d, nullptr, 0, p->head_ln_w, p->head_ln_b, p->ln_eps, B, d, h2, d, s));
   TRY(launch_linear(h2, d, p->fc2_w, p->fc2_b, logits, p->n_classes, B, p->n_classes, d, STLT_ACT_NONE, s));

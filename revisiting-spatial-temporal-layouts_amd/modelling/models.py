@@ -181,6 +181,7 @@ class StltBackbone(nn.Module):
         self.frames_embeddings = FramesEmbeddings(config)
         self.transformer = _EncoderStack(_EncoderLayerParams(config.hidden_size), config.num_temporal_layers)
         self.cls_only_last_spatial = True  # exact: only token 0 of the last spatial layer is read (models.py:79)
+        self.last_row_only_temporal = True  # exact, Stlt.forward only: the head reads one row per clip (models.py:189-192)
         self._cache = None
         self._ws = _Workspace()
 
@@ -239,7 +240,8 @@ class StltBackbone(nn.Module):
         return self._cache[1]
 
     def _flags(self) -> int:
-        return L.FLAG_CLS_ONLY_LAST_SPATIAL if self.cls_only_last_spatial else 0
+        return ((L.FLAG_CLS_ONLY_LAST_SPATIAL if self.cls_only_last_spatial else 0)
+                | (L.FLAG_LAST_ROW_ONLY_TEMPORAL if self.last_row_only_temporal else 0))
 
     def _check_mode(self):
         if self.training and self.config.hidden_dropout_prob > 0:

@@ -28,6 +28,7 @@ def test_logits_match_reference_golden(pkg, name, cls_only):
     sd, batch, z, meta = golden_case(name)
     m = _model(pkg, name, sd)
     m.backbone.cls_only_last_spatial = cls_only
+    m.backbone.last_row_only_temporal = cls_only  # both exact work-elision paths on, or the fully dense schedule
     with torch.no_grad():
         out = m(_to(batch))
     assert set(out) == {"stlt"}
