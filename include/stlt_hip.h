@@ -54,6 +54,20 @@ int stlt_embed_fwd(const int64_t* categories, const float* boxes, const float* s
 int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias,
                     float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, stlt_stream_t stream);
 
+/* General product on the same kernel, used by the backward pass of nn.Linear (autograd of F.linear in the reference):
+ *   c (M,N) = opA(a)·opB(b) [+ r]   with contraction length K (multiple of 32)
+ *   transA=0: a is (M,K) row-major, lda;  transA=1: a is (K,M) row-major, lda   (dW = dY^T·X)
+ *   transB=0: b is (N,K) row-major, ldb;  transB=1: b is (K,N) row-major, ldb   (dX = dY·W)
+ * r (nullable, ldr) is added in the epilogue (residual gradient).  n_split > 1 splits the contraction: split s writes
+ * its partial product to c + s*slab_stride; sum them with stlt_reduce_slabs (deterministic, no atomics).
+ * Rows of a contraction-major operand beyond the logical K must be zero-filled by the caller (K is rounded up). */
+int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb,
+              const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride,
+              int64_t M, int64_t N, int64_t K, int n_split, stlt_stream_t stream);
+/* dst[i] = (accumulate ? dst[i] : 0) + sum_s slabs[s*stride + i], i < n */
+int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate,
+                      stlt_stream_t stream);
+
 /* K3 — attention core of F.multi_head_attention_forward as reached from models.py:68-71 (spatial,
  * key-padding mask) and models.py:146-150 (temporal, causal mask of utils/model_utils.py:4-7 + key padding).
  * qkv: (S*L, 3*H*dh) packed rows [q;k;v]; ctx: (S*L, H*dh).  kpm: (S*L) bytes, 1 = key masked.

@@ -49,6 +49,9 @@ SIGNATURES = {
                                  C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_linear_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                   C.c_int, _vp]),
+    "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
+                            C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
+    "stlt_reduce_slabs": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int, _vp]),
     "stlt_attn_core_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_add_layernorm_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_float, C.c_int64, C.c_int64,
                                          _vp, C.c_int64, _vp]),

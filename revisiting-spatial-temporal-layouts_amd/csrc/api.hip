@@ -100,6 +100,18 @@ int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
   return launch_linear(x, ldx, w, bias, y, ldy, M, N, K, act, (hipStream_t)stream);
 }
 
+int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* r, int64_t ldr,
+              float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N, int64_t K, int n_split,
+              stlt_stream_t stream) {
+  return launch_gemm(transA, transB, a, lda, b, ldb, nullptr, r, ldr, c, ldc, slab_stride, M, N, K, n_split,
+                     STLT_ACT_NONE, (hipStream_t)stream);
+}
+
+int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate,
+                      stlt_stream_t stream) {
+  return launch_reduce_slabs(slabs, stride, n_slabs, dst, n, accumulate, (hipStream_t)stream);
+}
+
 int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                        float* ctx, stlt_stream_t stream) {
   return launch_attn(qkv, kpm, causal, S, L, H, dh, ctx, causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL,

@@ -42,6 +42,10 @@ int launch_embed(const int64_t* categories, const float* boxes, const float* sco
                  float* out, hipStream_t s);
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, int act, hipStream_t s);
+int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
+                int64_t K, int n_split, int act, hipStream_t s);
+int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s);
 int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* w, const float* b,

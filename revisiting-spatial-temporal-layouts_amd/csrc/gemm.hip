@@ -21,6 +21,14 @@
 //   * fragments are read one 8-wide k-chunk ahead (ping-pong registers), and the read of the next step's first
 //     chunk sits between the barrier and the last 16 MFMAs of the current step;
 //   * the bias is the accumulators' initial value, fetched one tile ahead.
+//
+// Operand layouts (template flags) for the backward pass of nn.Linear:
+//   TA=0: A stored (M, Kc) k-contiguous      TA=1: A stored (Kc, M) m-contiguous  (dW = dYᵀ·X reads dY this way)
+//   TB=0: B stored (N, Kc) k-contiguous      TB=1: B stored (Kc, N) n-contiguous  (dX = dY·W reads W this way)
+// Contraction-major operands are staged as [32 k][256 m] / [32 k][128 n] images (whole 1-KB / 512-B rows per DMA
+// instruction) and their fragments are four conflict-free ds_read_b32.  n_split > 1 splits the contraction range
+// over work items; split s writes its partial product to C + s*slab_stride (summed by reduce_slabs_kernel:
+// deterministic, no atomics).
 #include <cstdlib>
 #include "common.h"
 
@@ -35,12 +43,14 @@ constexpr int STAGE_FLOATS = (BM + BN) * BK;  // 12288 floats = 48 KB per stage
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-template <int ACT, bool STAMP>
+template <int ACT, bool STAMP, bool TA, bool TB, bool ADD>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
-                                                                  const float* __restrict__ W,
+                                                                  const float* __restrict__ W, int64_t ldw,
                                                                   const float* __restrict__ bias,
-                                                                  float* __restrict__ Y, int64_t ldy, int M, int N,
-                                                                  int K, int tiles_m, int tiles_n,
+                                                                  const float* __restrict__ R, int64_t ldr,
+                                                                  float* __restrict__ Y, int64_t ldy,
+                                                                  int64_t slab_stride, int M, int N, int K,
+                                                                  int tiles_m, int tiles_n, int n_split,
                                                                   unsigned long long* __restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + 2 * BN];  // operand stages + 2 bias strips
 
@@ -49,8 +59,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64x64
   const int lr = lane & 31, lh = lane >> 5;
-  const int nk = K / BK;
-  const int n_tiles = tiles_m * tiles_n;
+  const int nk_total = K / BK;
+  const int nk = nk_total / n_split;          // k-steps per work item (launcher guarantees divisibility)
+  const int n_tiles = tiles_m * tiles_n * n_split;  // work items: (output tile, contraction split), split fastest
 
   // XCD-contiguous tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so virtual id
   // v = (b%8)*(G/8) + b/8 gives each XCD a contiguous run of tiles (N fastest: they share the X panel).
@@ -66,67 +77,106 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   }
   const int total_steps = my_tiles * nk;
 
-  auto tile_origin = [&](int it, int& m0, int& n0) {
-    const int tile = v + it * G;
+  auto tile_origin = [&](int it, int& m0, int& n0, int& split) {
+    const int item = v + it * G;
+    const int tile = item / n_split;
+    split = item - tile * n_split;
     const int tm = tile / tiles_n;
     m0 = tm * BM;
     n0 = (tile - tm * tiles_n) * BN;
   };
 
   // ---- DMA side -------------------------------------------------------------------------------------
-  // wave w stages rows [32w, 32w+32) of the A tile (4 instructions) and rows [16w, 16w+16) of the B tile (2).
-  // Row pointers are computed once per tile; a k-step only adds k0.
+  // Per wave and k-step: 4 instructions for the A stage image, 2 for the B image.  Pointers are computed once
+  // per work item; a k-step only adds the operand's k-stride.
+  //   k-contiguous operand : image [rows][32 k] (swizzled); an instruction covers 8 rows x 128 B
+  //   contraction-major    : image [32 k][256 m | 128 n]; an instruction covers one 1-KB k-row (A) / two 512-B k-rows (B)
   const int drow = lane >> 3, dslot = lane & 7;
   const float* pa[4];
   const float* pb[2];
+  const int64_t a_kstep = TA ? (int64_t)BK * ldx : BK;
+  const int64_t b_kstep = TB ? (int64_t)BK * ldw : BK;
   auto dma_set_tile = [&](int it) {
-    int m0, n0;
-    tile_origin(it, m0, n0);
+    int m0, n0, split;
+    tile_origin(it, m0, n0, split);
+    const int64_t kbase = (int64_t)split * nk * BK;  // first contraction index of this split
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = wave * 32 + i * 8 + drow;      // row inside the A tile
-      int gm = m0 + r;
-      gm = gm < M ? gm : M - 1;                    // ragged tiles re-read the last row; stores are guarded
-      pa[i] = X + (int64_t)gm * ldx + (dslot ^ ((r >> 1) & 7)) * 4;  // source-side swizzle
+      if (TA) {
+        const int kr = wave * 4 + i;                 // k-row inside the step
+        int col = m0 + lane * 4;
+        col = col + 4 <= M ? col : (M >= 4 ? ((M - 4) & ~3) : 0);  // keep the 16-B read inside the row; those output rows are never stored
+        pa[i] = X + (kbase + kr) * ldx + col;
+      } else {
+        const int r = wave * 32 + i * 8 + drow;      // row inside the A tile
+        int gm = m0 + r;
+        gm = gm < M ? gm : M - 1;                    // ragged tiles re-read the last row; stores are guarded
+        pa[i] = X + (int64_t)gm * ldx + kbase + (dslot ^ ((r >> 1) & 7)) * 4;  // source-side swizzle
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = wave * 16 + i * 8 + drow;      // row inside the B tile
-      int gn = n0 + r;
-      gn = gn < N ? gn : N - 1;
-      pb[i] = W + (int64_t)gn * K + (dslot ^ ((r >> 1) & 7)) * 4;
+      if (TB) {
+        const int kr = wave * 4 + i * 2 + (lane >> 5);
+        int col = n0 + (lane & 31) * 4;
+        col = col + 4 <= N ? col : (N >= 4 ? ((N - 4) & ~3) : 0);
+        pb[i] = W + (kbase + kr) * ldw + col;
+      } else {
+        const int r = wave * 16 + i * 8 + drow;      // row inside the B tile
+        int gn = n0 + r;
+        gn = gn < N ? gn : N - 1;
+        pb[i] = W + (int64_t)gn * ldw + kbase + (dslot ^ ((r >> 1) & 7)) * 4;
+      }
     }
   };
-  // One k-step's DMA = 6 instructions per wave, issued in three parts (A rows 0-1, A rows 2-3, B rows) so they
-  // can be spread between the MFMA chunks of the previous step instead of queueing at the TA all at once.
+  // One k-step's DMA = 6 instructions per wave, issued in three parts (A 0-1, A 2-3, B) so they can be spread
+  // between the MFMA chunks of the previous step instead of queueing at the TA all at once.
   auto issue_dma_part = [&](int part, int kt, int stage) {
-    const int k0 = kt * BK;
-    float* sa = smem + stage * STAGE_FLOATS + (wave * 32) * BK;
-    float* sb = smem + stage * STAGE_FLOATS + (BM + wave * 16) * BK;
+    float* sa = smem + stage * STAGE_FLOATS + (TA ? (wave * 4) * BM : (wave * 32) * BK);
+    float* sb = smem + stage * STAGE_FLOATS + BM * BK + (TB ? (wave * 4) * BN : (wave * 16) * BK);
     if (part < 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)(pa[2 * part + i] + k0), (lds_void_ptr)(sa + (2 * part + i) * 8 * BK), 16, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        const int q = 2 * part + i;
+        const float* src = TA ? pa[q] + kt * a_kstep : pa[q] + kt * BK;
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(sa + q * (TA ? BM : 8 * BK)), 16, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)(pb[i] + k0), (lds_void_ptr)(sb + i * 8 * BK), 16, 0, 0);
+      {
+        const float* src = TB ? pb[i] + kt * b_kstep : pb[i] + kt * BK;
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(sb + i * (TB ? 2 * BN : 8 * BK)), 16, 0, 0);
+      }
     }
   };
 
   // ---- fragment side --------------------------------------------------------------------------------
   const int sw = (lr >> 1) & 7;
-  const int a_row = (wm * 64 + lr) * BK;         // + 32*BK for the second M tile
+  const int a_row = (wm * 64 + lr) * BK;         // k-contiguous image; + 32*BK for the second M tile
   const int b_row = (BM + wn * 64 + lr) * BK;    // + 32*BK for the second N tile
+  const int a_col = wm * 64 + lr;                // contraction-major image [32][BM]
+  const int b_col = BM * BK + wn * 64 + lr;      // contraction-major image [32][BN] behind the A image
   struct Frags { f32x4 a0, a1, b0, b1; };
   auto read_frags = [&](int stage, int c) {
     const float* s = smem + stage * STAGE_FLOATS;
     const int off = ((2 * c + lh) ^ sw) * 4;
+    const int kk = 8 * c + 4 * lh;               // first of this lane's 4 contraction indices in the chunk
     Frags f;
-    f.a0 = *reinterpret_cast<const f32x4*>(s + a_row + off);
-    f.a1 = *reinterpret_cast<const f32x4*>(s + a_row + 32 * BK + off);
-    f.b0 = *reinterpret_cast<const f32x4*>(s + b_row + off);
-    f.b1 = *reinterpret_cast<const f32x4*>(s + b_row + 32 * BK + off);
+    if (TA) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f.a0[e] = s[(kk + e) * BM + a_col]; f.a1[e] = s[(kk + e) * BM + a_col + 32]; }
+    } else {
+      f.a0 = *reinterpret_cast<const f32x4*>(s + a_row + off);
+      f.a1 = *reinterpret_cast<const f32x4*>(s + a_row + 32 * BK + off);
+    }
+    if (TB) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f.b0[e] = s[(kk + e) * BN + b_col]; f.b1[e] = s[(kk + e) * BN + b_col + 32]; }
+    } else {
+      f.b0 = *reinterpret_cast<const f32x4*>(s + b_row + off);
+      f.b1 = *reinterpret_cast<const f32x4*>(s + b_row + 32 * BK + off);
+    }
     return f;
   };
 
@@ -139,8 +189,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   float* bias_lds = smem + NSTAGE * STAGE_FLOATS;
   auto dma_bias = [&](int it) {
     if (bias && wave == 0) {
-      int m0, n0;
-      tile_origin(it, m0, n0);
+      int m0, n0, split;
+      tile_origin(it, m0, n0, split);
       float* dst = bias_lds + (it & 1) * BN;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -241,20 +291,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     if (++c_kt == nk) {
       // ---- epilogue of tile c_it (the next tile's first fragments are already in registers, its next two
       // k-steps are in flight).  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-      int m0, n0;
-      tile_origin(c_it, m0, n0);
+      int m0, n0, split;
+      tile_origin(c_it, m0, n0, split);
       const bool interior = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
+      float* Yt = Y + (int64_t)split * slab_stride;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const int n = n0 + wn * 64 + b * 32 + lr;
           const int mb = m0 + wm * 64 + a * 32 + 4 * lh;
-          float* yp = Y + (int64_t)mb * ldy + n;
+          float* yp = Yt + (int64_t)mb * ldy + n;
+          const float* rp = ADD ? R + (int64_t)mb * ldr + n : nullptr;  // add-source (residual gradient)
           if (interior) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               float val = acc[a][b][r];
+              if (ADD) val += rp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldr];
               if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
               yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = val;
             }
@@ -264,7 +317,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
               const int row = (r & 3) + 8 * (r >> 2);
               float val = acc[a][b][r];
               if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
-              if (n < N && mb + row < M) yp[(int64_t)row * ldy] = val;
+              if (n < N && mb + row < M) yp[(int64_t)row * ldy] = ADD ? val + rp[(int64_t)row * ldr] : val;
             }
           }
 #pragma unroll
@@ -286,35 +339,79 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
 
 int g_n_cu = 0;
 
+// dst[i] = (accumulate ? dst[i] : 0) + sum_s slabs[s*stride + i] : the deterministic second half of a split-K product
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int n_slabs,
+                                                           float* __restrict__ dst, int64_t n, int accumulate) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      f32x4 acc = accumulate ? *reinterpret_cast<const f32x4*>(dst + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < n_slabs; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + s * stride + i);
+      *reinterpret_cast<f32x4*>(dst + i) = acc;
+    } else {
+      for (int64_t j = i; j < n; ++j) {
+        float acc = accumulate ? dst[j] : 0.f;
+        for (int s = 0; s < n_slabs; ++s) acc += slabs[s * stride + j];
+        dst[j] = acc;
+      }
+    }
+  }
+}
+
 }  // namespace
 
-int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
-                  int64_t N, int64_t K, int act, hipStream_t s) {
-  if (!x || !w || !y) return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: null pointer");
-  if (M < 0 || N <= 0 || K <= 0 || K % BK != 0)
-    return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: K=%lld must be a positive multiple of %d (N=%lld)", (long long)K, BK, (long long)N);
-  if (ldx % 4 != 0 || ldx < K || ldy < N)
-    return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: ldx=%lld must be a multiple of 4 and >= K, ldy=%lld >= N", (long long)ldx, (long long)ldy);
-  if (M > 0x7fffff00LL || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: M/N too large");
-  if (act != STLT_ACT_NONE && act != STLT_ACT_GELU) return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: unknown activation %d", act);
-  if (M == 0) return 0;
-  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  if (tiles_m * tiles_n > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_linear_fwd: too many tiles");
+static int n_cu() {
   if (g_n_cu == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_n_cu = prop.multiProcessorCount;
     if (g_n_cu <= 0) g_n_cu = 256;
   }
+  return g_n_cu;
+}
+
+// C (M,N) = opA(A)·opB(B) [+ bias | + R], contraction length K (multiple of 32).  n_split > 1: C is a slab buffer.
+int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
+                int64_t K, int n_split, int act, hipStream_t s) {
+  if (!a || !b || !c) return stlt_set_error(STLT_EINVAL, "gemm: null pointer");
+  if (M < 0 || N <= 0 || K <= 0 || K % BK != 0)
+    return stlt_set_error(STLT_EINVAL, "gemm: contraction length K=%lld must be a positive multiple of %d (N=%lld)", (long long)K, BK, (long long)N);
+  if (lda % 4 != 0 || ldb % 4 != 0 || (r && ldr < N) || ldc < N || lda < (transA ? M : K) || ldb < (transB ? N : K))
+    return stlt_set_error(STLT_EINVAL, "gemm: bad leading dimension (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
+  if (M > 0x7fffff00LL || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gemm: M/N too large");
+  if (act != STLT_ACT_NONE && act != STLT_ACT_GELU) return stlt_set_error(STLT_EINVAL, "gemm: unknown activation %d", act);
+  if (n_split < 1 || (K / BK) % n_split != 0) return stlt_set_error(STLT_EINVAL, "gemm: n_split=%d must divide K/32=%lld", n_split, (long long)(K / BK));
+  if (transA && !transB) return stlt_set_error(STLT_EINVAL, "gemm: the (transA, !transB) layout is not built");
+  if ((transA || transB) && (act != STLT_ACT_NONE || bias)) return stlt_set_error(STLT_EINVAL, "gemm: bias/activation only with the forward (NT) layout");
+  if (M == 0) return 0;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  if (tiles_m * tiles_n * n_split > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "gemm: too many tiles");
   // persistent grid: one 144-KB workgroup per CU; no inter-workgroup dependency, so residency is only a speed matter
-  int64_t n_wg = tiles_m * tiles_n;
-  if (n_wg > g_n_cu) n_wg = g_n_cu;
+  int64_t n_wg = tiles_m * tiles_n * n_split;
+  if (n_wg > n_cu()) n_wg = n_cu();
   StltProfScope ps(STLT_K_GEMM, s);
   dim3 grid((unsigned)n_wg), block(GEMM_THREADS);
-#define LAUNCH(ACTV, STAMPV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV>), grid, block, 0, s, x, ldx, w, bias, y, ldy, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, g_stlt_debug_buf)
-  if (g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true);  // diagnostic build path only
-  else if (act == STLT_ACT_GELU) LAUNCH(STLT_ACT_GELU, false);
-  else LAUNCH(STLT_ACT_NONE, false);
+#define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, g_stlt_debug_buf)
+  if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
+  else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
+  else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
+  else if (g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true, false, false, false);  // diagnostic build path only
+  else if (act == STLT_ACT_GELU) LAUNCH(STLT_ACT_GELU, false, false, false, false);
+  else LAUNCH(STLT_ACT_NONE, false, false, false, false);
 #undef LAUNCH
   return stlt_check_launch("gemm_nt_kernel");
+}
+
+int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s) {
+  if (!slabs || !dst || n_slabs < 1) return stlt_set_error(STLT_EINVAL, "reduce_slabs: bad arguments");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, stride, n_slabs, dst, n, accumulate);
+  return stlt_check_launch("reduce_slabs_kernel");
+}
+
+int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
+                  int64_t N, int64_t K, int act, hipStream_t s) {
+  return launch_gemm(0, 0, x, ldx, w, K, bias, nullptr, 0, y, ldy, 0, M, N, K, 1, act, s);
 }

@@ -79,6 +79,33 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: 
     return out
 
 
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
+         add: Optional[torch.Tensor] = None, n_split: int = 1, k: Optional[int] = None):
+    """c = opA(a) @ opB(b) (+ add) on the f32-MFMA kernel (backward layouts of nn.Linear).  a: (M,K) or (K,M) if trans_a;
+    b: (N,K) or (K,N) if trans_b.  With n_split > 1 the contraction is split and summed by the slab reduction.
+    `k` overrides the contraction length (rows of contraction-major operands beyond the logical K must be zero)."""
+    lib = L.load()
+    _chk(a, torch.float32, "a"); _chk(b, torch.float32, "b")
+    M = a.shape[1] if trans_a else a.shape[0]
+    N = b.shape[1] if trans_b else b.shape[0]
+    K = k if k is not None else (a.shape[0] if trans_a else a.shape[1])
+    lda, ldb = a.shape[1], b.shape[1]
+    if add is not None:
+        _chk(add, torch.float32, "add")
+    if n_split == 1:
+        c = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        L.check(lib.stlt_gemm(int(trans_a), int(trans_b), _p(a), lda, _p(b), ldb, _p(add), N, _p(c), N, 0, M, N, K, 1,
+                              _stream()), "stlt_gemm")
+        return c
+    slabs = torch.empty(n_split, M, N, device=a.device, dtype=torch.float32)
+    L.check(lib.stlt_gemm(int(trans_a), int(trans_b), _p(a), lda, _p(b), ldb, None, 0, _p(slabs), N, M * N, M, N, K,
+                          n_split, _stream()), "stlt_gemm")
+    c = add.clone() if add is not None else torch.empty(M, N, device=a.device, dtype=torch.float32)
+    L.check(lib.stlt_reduce_slabs(_p(slabs), M * N, n_split, _p(c), M * N, int(add is not None), _stream()),
+            "stlt_reduce_slabs")
+    return c
+
+
 def attn_core(qkv: torch.Tensor, kpm: torch.Tensor, causal: bool, num_heads: int):
     """K3 — qkv (S,L,3d) packed [q;k;v], kpm (S,L) bool/uint8 (True = key masked). -> ctx (S,L,d)"""
     lib = L.load()

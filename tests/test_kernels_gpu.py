@@ -135,3 +135,30 @@ def test_frames_embed_and_gather(pkg):
 def test_cpu_tensors_are_refused(pkg):
     with pytest.raises(pkg.StltHipError):
         pkg.ops.linear(torch.zeros(4, 32), torch.zeros(8, 32), None)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (1000, 768, 2304), (57, 3072, 768), (512, 132, 64)])
+def test_gemm_nn_dx_layout(pkg, M, N, K):
+    """dX = dY·W (+ residual grad): a (M,K) k-contiguous, b stored (K,N) = torch weight (out=K, in=N)."""
+    a, b, r = _rand(M, K, seed=1), _rand(K, N, seed=2, scale=1 / math.sqrt(K)), _rand(M, N, seed=3)
+    ref = a.double() @ b.double()
+    got = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_b=True).cpu()
+    assert (got.double() - ref).abs().max().item() <= 3e-5
+    got = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_b=True, add=r.to(DEV)).cpu()
+    assert (got.double() - (ref + r.double())).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize("M,N,K,split", [(768, 768, 448, 1), (2304, 768, 1024, 4), (200, 132, 96, 3), (3072, 768, 14336, 14),
+                                         (176, 768, 64, 1)])
+def test_gemm_tn_dw_layout_with_split_k(pkg, M, N, K, split):
+    """dW = dY^T·X: both operands contraction-major ((K,M) and (K,N)); split-K slabs + deterministic reduction."""
+    a, b = _rand(K, M, seed=4), _rand(K, N, seed=5)
+    ref = a.double().t() @ b.double()
+    got = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_a=True, trans_b=True, n_split=split)
+    assert (got.cpu().double() - ref).abs().max().item() <= 2e-5 * math.sqrt(K)
+    again = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_a=True, trans_b=True, n_split=split)
+    assert torch.equal(got, again)  # slab reduction: bitwise reproducible
+    if split > 1:
+        acc = _rand(M, N, seed=6)
+        got2 = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_a=True, trans_b=True, n_split=split, add=acc.to(DEV)).cpu()
+        assert (got2.double() - (ref + acc.double())).abs().max().item() <= 2e-5 * math.sqrt(K)
