@@ -139,6 +139,22 @@ int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* wor
 int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
                  int flags, float* out_btd, float* logits, stlt_stream_t stream);
 
+/* ---- training step (reference src/train.py:119-135: forward, loss.backward(); the optimizer stays in torch) ----
+ * stlt_train_forward runs the dense schedule and records every intermediate the reverse sweep needs in `tape`
+ * (fp32; rows padded to a multiple of 32; the caller allocates it ZERO-FILLED once and the library never writes the
+ * padding).  stlt_train_backward is the reverse sweep: given dlogits (B, n_classes) it ACCUMULATES (+=) parameter
+ * gradients into the buffers named by `grads` — the same struct as the parameters, every pointer being the gradient
+ * buffer of that parameter or NULL to skip it (frozen / unused parameters; models.py:172-174).  `scratch` must be
+ * zero-filled once by the caller as well.  Embedding rows at padding_idx 0 receive no gradient (models.py:22,91).
+ * Dropout is not applied (train with hidden_dropout_prob = 0).  Attention backward supports sequences <= 64 tokens. */
+size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);
+size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories);
+int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape, size_t tape_bytes, float* logits,
+                       stlt_stream_t stream);
+int stlt_train_backward(const stlt_params* p, const stlt_params* grads, const stlt_inputs* in, const void* tape,
+                        size_t tape_bytes, void* scratch, size_t scratch_bytes, const float* dlogits,
+                        stlt_stream_t stream);
+
 /* ---- per-kernel timing (bench.py roofline leg): hipEvents around every launch of the whole-path calls ---- */
 #define STLT_K_EMBED 0
 #define STLT_K_GEMM 1

@@ -1,0 +1,465 @@
+// Backward kernels of the STLT path (what autograd runs for the reference's train step, src/train.py:125-127):
+// LayerNorm backward, bias-gradient column sums, GELU forward/backward, attention-core backward, and the
+// backward of the embedding / frames-embedding / last-state gather.  All parameter-gradient reductions are
+// two-stage (per-wave or per-block partials, then a fixed-order sum): bitwise reproducible, no float atomics.
+// The large products (dX = dY·W, dW = dYᵀ·X) run on the MFMA kernel of gemm.hip.
+#include "common.h"
+
+namespace {
+
+constexpr int RW_WAVES = 4;  // waves per 256-thread block for the row-wise kernels
+
+// ------------------------------------------------------------------ LayerNorm backward
+// y = LN(s) * w + b with s = a (+ b2).  Given dy: ds = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*w;
+// dw = sum_rows dy*xhat, db = sum_rows dy.  One wave per row (row in registers), persistent waves accumulate
+// their dw/db partials in registers and write one partial row pair each.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                     const float* __restrict__ a, int64_t lda,
+                                                     const float* __restrict__ b2, int64_t ldb,
+                                                     const float* __restrict__ w, float eps, int64_t M, int d,
+                                                     float* __restrict__ ds, int64_t ldds,
+                                                     float* __restrict__ partials /* [n_waves][2][d] */) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * RW_WAVES;
+  f32x4 dw_acc[NV], db_acc[NV], wv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    dw_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int e = (i * 64 + lane) * 4;
+    wv[i] = e < d ? *reinterpret_cast<const f32x4*>(w + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (int64_t row = gw; row < M; row += n_waves) {
+    f32x4 x[NV], g[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < d) {
+        x[i] = *reinterpret_cast<const f32x4*>(a + row * lda + e);
+        if (b2) x[i] += *reinterpret_cast<const f32x4*>(b2 + row * ldb + e);
+        g[i] = *reinterpret_cast<const f32x4*>(dy + row * lddy + e);
+        sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+      } else {
+        x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(sum) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < d) {
+        x[i] -= mean;
+        q += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < d) {
+        x[i] *= rstd;                 // xhat
+        db_acc[i] += g[i];
+        dw_acc[i] += g[i] * x[i];
+        g[i] *= wv[i];                // g = dy * w
+        sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        sgx += (g[i].x * x[i].x + g[i].y * x[i].y) + (g[i].z * x[i].z + g[i].w * x[i].w);
+      }
+    }
+    const float mg = wave_sum(sg) * inv_d, mgx = wave_sum(sgx) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < d) *reinterpret_cast<f32x4*>(ds + row * ldds + e) = (g[i] - mg - x[i] * mgx) * rstd;
+    }
+  }
+  if (partials && gw < n_waves) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < d) {
+        *reinterpret_cast<f32x4*>(partials + (gw * 2 + 0) * d + e) = dw_acc[i];
+        *reinterpret_cast<f32x4*>(partials + (gw * 2 + 1) * d + e) = db_acc[i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+// partials[blockIdx.y][n] = sum over this block's row range of x[m][n]; 256 threads = 256 consecutive columns.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N,
+                                                             int64_t rows_per_block, float* __restrict__ partials) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int64_t m = m0; m < m1; ++m) acc += x[m * ld + n];
+  partials[(int64_t)blockIdx.y * N + n] = acc;
+}
+
+// ------------------------------------------------------------------ GELU (exact erf) forward / backward
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ h, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
+    f32x4 o = {gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+    reinterpret_cast<f32x4*>(h)[i] = o;
+  }
+}
+
+__device__ __forceinline__ float gelu_grad(float x) {
+  // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x exp(-x^2/2) / sqrt(2 pi)
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ u,
+                                                       float* __restrict__ du, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(dh)[i];
+    const f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
+    f32x4 o = {g.x * gelu_grad(v.x), g.y * gelu_grad(v.y), g.z * gelu_grad(v.z), g.w * gelu_grad(v.w)};
+    reinterpret_cast<f32x4*>(du)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ attention core backward
+// One 256-thread block per (token group, head); a group = whole sequences totalling GL <= 64 tokens (floor(64/L)
+// sequences when L <= 32, one sequence when 32 < L <= 64).  Everything lives in LDS as fp32; P is recomputed.
+//   dV = P^T dO ; dP = dO V^T ; dS = P * (dP - rowsum(P*dP)) ; dQ = scale dS K ; dK = scale dS^T Q
+constexpr int AB_MAXL = 64, AB_DH = 64, AB_LD = AB_DH + 1, AB_PLD = AB_MAXL + 1;
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                       const uint8_t* __restrict__ kpm, int causal, int64_t n_tokens,
+                                                       int L, int H, int GL, float scale, float* __restrict__ dqkv) {
+  __shared__ float Qs[AB_MAXL * AB_LD], Ks[AB_MAXL * AB_LD], Vs[AB_MAXL * AB_LD], Gs[AB_MAXL * AB_LD];
+  __shared__ float Ps[AB_MAXL * AB_PLD], Ds[AB_MAXL * AB_PLD];
+  __shared__ int meta[AB_MAXL];
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % H;
+  const int64_t g = blockIdx.x / H;
+  const int64_t tok0 = g * GL;
+  const int gv = (int)((n_tokens - tok0) < GL ? (n_tokens - tok0) : GL);
+  const int d = H * AB_DH;
+  const int64_t ld = 3 * (int64_t)d;
+  // load Q, K, V, dO (rows >= gv are zero)
+  for (int idx = tid; idx < GL * AB_DH; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    float q = 0.f, k = 0.f, v = 0.f, go = 0.f;
+    if (r < gv) {
+      const float* row = qkv + (tok0 + r) * ld + head * AB_DH + c;
+      q = row[0]; k = row[d]; v = row[2 * d];
+      go = dctx[(tok0 + r) * (int64_t)d + head * AB_DH + c];
+    }
+    Qs[r * AB_LD + c] = q; Ks[r * AB_LD + c] = k; Vs[r * AB_LD + c] = v; Gs[r * AB_LD + c] = go;
+  }
+  if (tid < GL) {
+    int m = -1;
+    if (tid < gv && kpm[tok0 + tid] == 0) { const int s = tid / L; m = (s << 16) | (tid - s * L); }
+    meta[tid] = m;
+  }
+  __syncthreads();
+  // scores and dP for every (i, j) pair of the group
+  for (int p = tid; p < GL * GL; p += 256) {
+    const int i = p / GL, j = p - i * GL;
+    const int mk = meta[j];
+    const int qs = i / L, qp = i - qs * L;
+    const bool ok = mk >= 0 && (mk >> 16) == qs && (!causal || (mk & 0xffff) <= qp);
+    float s = 0.f, dp = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < AB_DH; ++c) {
+      s += Qs[i * AB_LD + c] * Ks[j * AB_LD + c];
+      dp += Gs[i * AB_LD + c] * Vs[j * AB_LD + c];
+    }
+    Ps[i * AB_PLD + j] = ok ? s * scale : -1e30f;
+    Ds[i * AB_PLD + j] = dp;
+  }
+  __syncthreads();
+  // row softmax, D_i, dS (in place: Ps <- P, Ds <- dS)
+  if (tid < GL) {
+    const int i = tid;
+    float m = -1e30f;
+    for (int j = 0; j < GL; ++j) m = fmaxf(m, Ps[i * AB_PLD + j]);
+    float l = 0.f;
+    for (int j = 0; j < GL; ++j) {
+      const float s = Ps[i * AB_PLD + j];
+      const float e = s > -1e29f ? expf(s - m) : 0.f;
+      Ps[i * AB_PLD + j] = e;
+      l += e;
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float dsum = 0.f;
+    for (int j = 0; j < GL; ++j) {
+      const float pj = Ps[i * AB_PLD + j] * inv;
+      Ps[i * AB_PLD + j] = pj;
+      dsum += pj * Ds[i * AB_PLD + j];
+    }
+    for (int j = 0; j < GL; ++j) Ds[i * AB_PLD + j] = Ps[i * AB_PLD + j] * (Ds[i * AB_PLD + j] - dsum);
+  }
+  __syncthreads();
+  // dQ, dK, dV: thread owns (row r, channel c); consecutive threads -> consecutive channels (coalesced stores)
+  for (int idx = tid; idx < GL * AB_DH; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    if (r >= gv) continue;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < GL; ++j) {
+      dq += Ds[r * AB_PLD + j] * Ks[j * AB_LD + c];   // sum_j dS[r][j] K[j][c]
+      dk += Ds[j * AB_PLD + r] * Qs[j * AB_LD + c];   // sum_i dS[i][r] Q[i][c]
+      dv += Ps[j * AB_PLD + r] * Gs[j * AB_LD + c];   // sum_i P[i][r] dO[i][c]
+    }
+    float* out = dqkv + (tok0 + r) * ld + head * AB_DH + c;
+    out[0] = dq * scale;
+    out[d] = dk * scale;
+    out[2 * d] = dv;
+  }
+}
+
+// ------------------------------------------------------------------ K1 backward (parameter gradients)
+// dx = gradient wrt the pre-LayerNorm embedding sum (tok, d).  Per block: a chunk of tokens; thread = channel.
+// partial layout per block: [C category rows][4 box_w rows][box_b][score_w][score_b] x d
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ categories,
+                                                        const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                        int C, int64_t n_tokens, int d, int64_t tok_per_block,
+                                                        float* __restrict__ partials) {
+  const int64_t t0 = (int64_t)blockIdx.x * tok_per_block;
+  const int64_t t1 = t0 + tok_per_block < n_tokens ? t0 + tok_per_block : n_tokens;
+  float* out = partials + (int64_t)blockIdx.x * (C + 7) * d;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bw3 = 0.f, bb = 0.f, sw = 0.f;
+    for (int k = 0; k < C; ++k) out[(int64_t)k * d + c] = 0.f;
+    for (int64_t t = t0; t < t1; ++t) {
+      const float g = dx[t * d + c];
+      const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + t * 4);
+      bw0 += g * bx.x; bw1 += g * bx.y; bw2 += g * bx.z; bw3 += g * bx.w;
+      bb += g;
+      if (scores) sw += g * scores[t];
+      int64_t cat = categories[t];
+      cat = cat < 0 ? 0 : (cat >= C ? C - 1 : cat);
+      out[cat * d + c] += g;  // same thread owns this (row, channel): plain read-modify-write
+    }
+    out[(int64_t)(C + 0) * d + c] = bw0; out[(int64_t)(C + 1) * d + c] = bw1;
+    out[(int64_t)(C + 2) * d + c] = bw2; out[(int64_t)(C + 3) * d + c] = bw3;
+    out[(int64_t)(C + 4) * d + c] = bb;
+    out[(int64_t)(C + 5) * d + c] = sw;
+    out[(int64_t)(C + 6) * d + c] = bb;  // score_b gradient equals box_b's (both are plain sums)
+  }
+}
+
+// sum the block partials in block order and scatter into the parameter-gradient tensors (accumulating)
+__global__ __launch_bounds__(256) void embed_bwd_finalize_kernel(const float* __restrict__ partials, int n_blocks, int C,
+                                                                 int d, int has_scores, float* __restrict__ g_cat,
+                                                                 float* __restrict__ g_box_w, float* __restrict__ g_box_b,
+                                                                 float* __restrict__ g_score_w,
+                                                                 float* __restrict__ g_score_b) {
+  const int row = blockIdx.y;  // 0..C+6
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  float acc = 0.f;
+  for (int b = 0; b < n_blocks; ++b) acc += partials[((int64_t)b * (C + 7) + row) * d + c];
+  if (row < C) { if (g_cat && row != 0) g_cat[(int64_t)row * d + c] += acc; }   // padding_idx = 0: no gradient (models.py:22)
+  else if (row < C + 4) { if (g_box_w) g_box_w[(int64_t)c * 4 + (row - C)] += acc; }  // box_w is (d,4)
+  else if (row == C + 4) { if (g_box_b) g_box_b[c] += acc; }
+  else if (row == C + 5) { if (has_scores && g_score_w) g_score_w[c] += acc; }    // (d,1)
+  else { if (has_scores && g_score_b) g_score_b[c] += acc; }
+}
+
+// ------------------------------------------------------------------ K7 backward
+// ds (B*T, d) = gradient wrt the pre-LayerNorm frames sum.  d_pos[t] = sum_b ds[b,t]; d_type[ft] = sum ds (row 0 =
+// padding_idx gets none, models.py:91); the CLS rows of the spatial gradient receive ds, the other rows zero.
+__global__ __launch_bounds__(256) void frames_bwd_scatter_kernel(const float* __restrict__ ds, int64_t BT, int N, int d,
+                                                                 float* __restrict__ dx_spatial) {
+  // one block per frame: row 0 <- ds, rows 1..N-1 <- 0
+  const int64_t f = blockIdx.x;
+  for (int idx = threadIdx.x * 4; idx < N * d; idx += 1024) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (idx < d) v = *reinterpret_cast<const f32x4*>(ds + f * d + idx);
+    *reinterpret_cast<f32x4*>(dx_spatial + f * (int64_t)N * d + idx) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void frames_bwd_params_kernel(const float* __restrict__ ds,
+                                                                const int64_t* __restrict__ frame_types, int64_t B, int T,
+                                                                int d, float* __restrict__ g_pos, float* __restrict__ g_type) {
+  // grid.y = T position rows followed by 5 type rows; fixed summation order over clips
+  const int row = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  float acc = 0.f;
+  if (row < T) {
+    for (int64_t b = 0; b < B; ++b) acc += ds[(b * T + row) * d + c];
+    if (g_pos) g_pos[(int64_t)row * d + c] += acc;
+  } else {
+    const int ft = row - T;
+    if (ft == 0 || !g_type) return;
+    for (int64_t i = 0; i < B * T; ++i) {
+      int64_t v = frame_types[i];
+      v = v < 0 ? 0 : (v > 4 ? 4 : v);
+      if (v == ft) acc += ds[i * d + c];
+    }
+    g_type[(int64_t)ft * d + c] += acc;
+  }
+}
+
+// ------------------------------------------------------------------ K8a backward: scatter the head's input gradient
+__global__ __launch_bounds__(256) void scatter_last_kernel(const float* __restrict__ dh, const int64_t* __restrict__ lengths,
+                                                           int T, int d, float* __restrict__ dout /* (B,T,d), pre-zeroed */) {
+  const int64_t b = blockIdx.x;
+  int64_t t = lengths[b] - 1;
+  t = t < 0 ? t + T : t;
+  t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+  for (int e = threadIdx.x * 4; e < d; e += 1024)
+    *reinterpret_cast<f32x4*>(dout + (b * T + t) * (int64_t)d + e) = *reinterpret_cast<const f32x4*>(dh + b * d + e);
+}
+
+// ------------------------------------------------------------------ small dense products (prediction head: M = B rows, N = 174 ...)
+// c[m][n] (+)= sum_k a[m*sam + k*sak] * b[k*sbk + n*sbn]; one thread per output element; any layout via strides.
+__global__ __launch_bounds__(256) void small_gemm_kernel(const float* __restrict__ a, int64_t sam, int64_t sak,
+                                                         const float* __restrict__ b, int64_t sbk, int64_t sbn,
+                                                         float* __restrict__ c, int64_t ldc, int M, int N, int K,
+                                                         int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc += a[m * sam + k * sak] * b[k * sbk + n * sbn];
+  float* o = c + (int64_t)m * ldc + n;
+  *o = accumulate ? *o + acc : acc;
+}
+
+inline int nv_for(int64_t d) { return (int)((d + 255) / 256); }
+
+}  // namespace
+
+#define DISPATCH_NV(nv, ...)                                   \
+  switch (nv) {                                                \
+    case 1: { constexpr int NV = 1; __VA_ARGS__; } break;      \
+    case 2: { constexpr int NV = 2; __VA_ARGS__; } break;      \
+    case 3: { constexpr int NV = 3; __VA_ARGS__; } break;      \
+    case 4: { constexpr int NV = 4; __VA_ARGS__; } break;      \
+    default: { constexpr int NV = 8; __VA_ARGS__; } break;     \
+  }
+
+// ds = dLN(dy; s = a (+ b2)); parameter gradients ACCUMULATE into g_w / g_b (either may be null).
+// scratch: >= ln_bwd_scratch_floats(d) floats.
+int64_t ln_bwd_scratch_floats(int64_t d) { return 1024 * 2 * d; }
+
+int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
+                  float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
+                  hipStream_t s) {
+  if (!dy || !a || !w || !ds || !scratch) return stlt_set_error(STLT_EINVAL, "ln_bwd: null pointer");
+  if (d <= 0 || d % 4 || d > 2048) return stlt_set_error(STLT_EINVAL, "ln_bwd: bad d=%lld", (long long)d);
+  if (M == 0) return 0;
+  int64_t blocks = (M + RW_WAVES - 1) / RW_WAVES;
+  if (blocks > 256) blocks = 256;  // 1024 persistent waves
+  const int64_t n_waves = blocks * RW_WAVES;
+  StltProfScope ps(STLT_K_ADDLN, s);
+  DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
+                                            ldb, w, eps, M, (int)d, ds, ldds, scratch));
+  if (int e = stlt_check_launch("ln_bwd_kernel")) return e;
+  // partial rows are interleaved [wave][dw|db][d]: two strided reductions
+  if (g_w) { if (int e = launch_reduce_slabs(scratch, 2 * d, (int)n_waves, g_w, d, 1, s)) return e; }
+  if (g_b) { if (int e = launch_reduce_slabs(scratch + d, 2 * d, (int)n_waves, g_b, d, 1, s)) return e; }
+  return 0;
+}
+
+// g[n] += sum_m x[m][n]   (scratch >= 64*N floats)
+int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g, float* scratch, hipStream_t s) {
+  if (!x || !g || !scratch) return stlt_set_error(STLT_EINVAL, "colsum: null pointer");
+  if (M == 0 || N == 0) return 0;
+  int parts = (int)((M + 255) / 256);
+  if (parts > 64) parts = 64;
+  const int64_t rows = (M + parts - 1) / parts;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)parts), dim3(256), 0, s, x, ld, M, (int)N,
+                     rows, scratch);
+  if (int e = stlt_check_launch("colsum_partial_kernel")) return e;
+  return launch_reduce_slabs(scratch, N, parts, g, N, 1, s);
+}
+
+int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s) {
+  if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
+  if (n == 0) return 0;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, u, h, n / 4);
+  return stlt_check_launch("gelu_fwd_kernel");
+}
+
+int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s) {
+  if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
+  if (n == 0) return 0;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dh, u, du, n / 4);
+  return stlt_check_launch("gelu_bwd_kernel");
+}
+
+int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
+                    int64_t dh, float* dqkv, hipStream_t s) {
+  if (!qkv || !dctx || !kpm || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
+  if (dh != AB_DH) return stlt_set_error(STLT_EINVAL, "attn_bwd: head dim must be 64");
+  if (L <= 0 || L > AB_MAXL)
+    return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld); training with longer layouts is not built yet", AB_MAXL, (long long)L);
+  if (S == 0) return 0;
+  const int P = (int)(AB_MAXL / L);
+  const int GL = P * (int)L;
+  const int64_t groups = (S + P - 1) / P;
+  if (groups * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "attn_bwd: too many groups");
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(groups * H)), dim3(256), 0, s, qkv, dctx, kpm, causal, S * L, (int)L, (int)H,
+                     GL, 1.0f / sqrtf((float)dh), dqkv);
+  return stlt_check_launch("attn_bwd_kernel");
+}
+
+int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d) {
+  const int64_t blocks = (n_tokens + 127) / 128 > 512 ? 512 : (n_tokens + 127) / 128;
+  return (blocks > 0 ? blocks : 1) * (C + 7) * d;
+}
+
+int launch_embed_bwd(const float* dx, const int64_t* categories, const float* boxes, const float* scores, int64_t C,
+                     int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,
+                     float* g_score_b, float* scratch, hipStream_t s) {
+  if (!dx || !categories || !boxes || !scratch) return stlt_set_error(STLT_EINVAL, "embed_bwd: null pointer");
+  if (n_tokens == 0) return 0;
+  int64_t blocks = (n_tokens + 127) / 128;
+  if (blocks > 512) blocks = 512;
+  const int64_t tpb = (n_tokens + blocks - 1) / blocks;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dx, categories, boxes, scores, (int)C, n_tokens,
+                     (int)d, tpb, scratch);
+  if (int e = stlt_check_launch("embed_bwd_kernel")) return e;
+  hipLaunchKernelGGL(embed_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)(C + 7)), dim3(256), 0, s, scratch,
+                     (int)blocks, (int)C, (int)d, scores ? 1 : 0, g_cat, g_box_w, g_box_b, g_score_w, g_score_b);
+  return stlt_check_launch("embed_bwd_finalize_kernel");
+}
+
+int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
+                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s) {
+  if (!ds || !frame_types || !dx_spatial) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
+  if (B * T == 0) return 0;
+  hipLaunchKernelGGL(frames_bwd_scatter_kernel, dim3((unsigned)(B * T)), dim3(256), 0, s, ds, B * T, (int)N, (int)d, dx_spatial);
+  if (int e = stlt_check_launch("frames_bwd_scatter_kernel")) return e;
+  hipLaunchKernelGGL(frames_bwd_params_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)(T + 5)), dim3(256), 0, s, ds,
+                     frame_types, B, (int)T, (int)d, g_pos, g_type);
+  return stlt_check_launch("frames_bwd_params_kernel");
+}
+
+int launch_scatter_last(const float* dh, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* dout, hipStream_t s) {
+  if (!dh || !lengths || !dout) return stlt_set_error(STLT_EINVAL, "scatter_last: null pointer");
+  if (B == 0) return 0;
+  if (hipError_t e = hipMemsetAsync(dout, 0, (size_t)B * T * d * sizeof(float), s); e != hipSuccess)
+    return stlt_set_error((int)e, "scatter_last: memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(scatter_last_kernel, dim3((unsigned)B), dim3(256), 0, s, dh, lengths, (int)T, (int)d, dout);
+  return stlt_check_launch("scatter_last_kernel");
+}
+
+int launch_small_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk, int64_t sbn, float* c,
+                      int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t s) {
+  if (!a || !b || !c) return stlt_set_error(STLT_EINVAL, "small_gemm: null pointer");
+  if (M * N == 0) return 0;
+  hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, a, sam, sak, b, sbk, sbn, c, ldc,
+                     (int)M, (int)N, (int)K, accumulate);
+  return stlt_check_launch("small_gemm_kernel");
+}

@@ -39,7 +39,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 int launch_embed(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
                  int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
                  const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
-                 float* out, hipStream_t s);
+                 float* out, hipStream_t s, float* pre_out = nullptr);
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, int act, hipStream_t s);
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -52,6 +52,26 @@ int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
                          float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s);
 int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
                         const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
-                        int64_t d, float* out, hipStream_t s);
+                        int64_t d, float* out, hipStream_t s, float* pre_out = nullptr);
 int launch_gather_last(const float* x, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* out,
                        hipStream_t s);
+
+// backward kernels (backward.hip)
+int64_t ln_bwd_scratch_floats(int64_t d);
+int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
+                  float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
+                  hipStream_t s);
+int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g, float* scratch, hipStream_t s);
+int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s);
+int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s);
+int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
+                    int64_t dh, float* dqkv, hipStream_t s);
+int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d);
+int launch_embed_bwd(const float* dx, const int64_t* categories, const float* boxes, const float* scores, int64_t C,
+                     int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,
+                     float* g_score_b, float* scratch, hipStream_t s);
+int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
+                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s);
+int launch_scatter_last(const float* dh, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* dout, hipStream_t s);
+int launch_small_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk, int64_t sbn, float* c,
+                      int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t s);

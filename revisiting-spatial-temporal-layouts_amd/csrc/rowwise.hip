@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
                                                     const float* __restrict__ score_w,
                                                     const float* __restrict__ score_b, const float* __restrict__ ln_w,
                                                     const float* __restrict__ ln_b, float eps, int64_t n_tokens, int d,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, float* __restrict__ pre_out) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= n_tokens) return;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
         x += sc * ws + bs;
       }
       v[i] = x;
+      if (pre_out) *reinterpret_cast<f32x4*>(pre_out + row * d + e) = x;  // training tape: pre-LayerNorm sum
     } else {
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void frames_embed_kernel(const float* __restri
                                                            const float* __restrict__ type_table,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            float eps, int64_t BT, int T, int d,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ pre_out) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= BT) return;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void frames_embed_kernel(const float* __restri
       f32x4 p = *reinterpret_cast<const f32x4*>(pos_table + (int64_t)t * d + e);
       f32x4 f = *reinterpret_cast<const f32x4*>(type_table + ft * d + e);
       v[i] = (a + p) + f;  // models.py:108 evaluation order
+      if (pre_out) *reinterpret_cast<f32x4*>(pre_out + row * d + e) = v[i];
     } else {
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -177,7 +179,7 @@ inline int check_d(int64_t d) {
 int launch_embed(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
                  int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
                  const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
-                 float* out, hipStream_t s) {
+                 float* out, hipStream_t s, float* pre_out) {
   if (int e = check_d(d)) return e;
   if (!categories || !boxes || !cat_table || !box_w || !box_b || !ln_w || !ln_b || !out || n_categories <= 0)
     return stlt_set_error(STLT_EINVAL, "stlt_embed_fwd: null pointer / empty table");
@@ -187,7 +189,7 @@ int launch_embed(const int64_t* categories, const float* boxes, const float* sco
   dim3 grid((unsigned)((n_tokens + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((embed_kernel<NV>), grid, dim3(256), 0, s, categories, boxes, scores,
                                             cat_table, (int)n_categories, box_w, box_b, score_w, score_b, ln_w, ln_b,
-                                            eps, n_tokens, (int)d, out));
+                                            eps, n_tokens, (int)d, out, pre_out));
   return stlt_check_launch("embed_kernel");
 }
 
@@ -206,7 +208,7 @@ int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
 
 int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
                         const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
-                        int64_t d, float* out, hipStream_t s) {
+                        int64_t d, float* out, hipStream_t s, float* pre_out) {
   if (int e = check_d(d)) return e;
   if (!spatial || !frame_types || !pos_table || !type_table || !ln_w || !ln_b || !out)
     return stlt_set_error(STLT_EINVAL, "stlt_frames_embed_fwd: null pointer");
@@ -216,7 +218,7 @@ int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t*
   dim3 grid((unsigned)((B * T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((frames_embed_kernel<NV>), grid, dim3(256), 0, s, spatial, row_stride,
                                             frame_types, pos_table, type_table, ln_w, ln_b, eps, B * T, (int)T, (int)d,
-                                            out));
+                                            out, pre_out));
   return stlt_check_launch("frames_embed_kernel");
 }
 

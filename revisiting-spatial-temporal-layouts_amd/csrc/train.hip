@@ -1,0 +1,264 @@
+// Training step of the STLT path in native code: the forward that records a tape, and the reverse sweep that
+// autograd would run for the reference's `loss.backward()` (src/train.py:125-127).  Both are fixed launch
+// sequences on the caller's stream (no allocation, no synchronisation).
+//
+// Tape (fp32, rows padded to a multiple of 32 and zero beyond the logical row count — the caller allocates it
+// zero-filled and the kernels never write the padding, which is what lets dW = dYᵀ·X run with a rounded-up
+// contraction length):
+//   s_embed (tok,d) | per spatial layer: x, qkv(3d), ctx, a, x1, u(4d), h(4d), f | x_sp_out | s_frames (BT,d)
+//   | per temporal layer: same 8 buffers on BT rows | x_tp_out | head: h0, u0, z1, z2 (B rows)
+//   layer math:  qkv = x·Winᵀ+b ; ctx = attn(qkv) ; a = ctx·Woᵀ+bo ; x1 = LN1(x+a) ; u = x1·W1ᵀ+b1 ; h = gelu(u) ;
+//                f = h·W2ᵀ+b2 ; y = LN2(x1+f)   (y is the next layer's x)
+#include "common.h"
+
+namespace {
+
+inline int64_t up32(int64_t v) { return (v + 31) / 32 * 32; }
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct LayerTape { float *x, *qkv, *ctx, *a, *x1, *u, *h, *f; };
+
+struct Tape {
+  int64_t tokp, btp, bp;
+  float* s_embed;
+  LayerTape sp[64];
+  float* sp_out;
+  float* s_frames;
+  LayerTape tp[64];
+  float* tp_out;
+  float *h0, *u0, *z1, *z2;
+  size_t bytes;
+};
+
+// carve the tape; base may be null to just size it
+static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_sp, int64_t n_tp) {
+  Tape t;
+  t.tokp = up32(B * T * N); t.btp = up32(B * T); t.bp = up32(B);
+  size_t off = 0;
+  auto take = [&](int64_t rows, int64_t width) { float* p = (float*)(base + off); off = align256(off + (size_t)rows * width * sizeof(float)); return p; };
+  t.s_embed = take(t.tokp, d);
+  auto take_layer = [&](LayerTape& l, int64_t rows) {
+    l.x = take(rows, d); l.qkv = take(rows, 3 * d); l.ctx = take(rows, d); l.a = take(rows, d);
+    l.x1 = take(rows, d); l.u = take(rows, 4 * d); l.h = take(rows, 4 * d); l.f = take(rows, d);
+  };
+  for (int64_t l = 0; l < n_sp; ++l) take_layer(t.sp[l], t.tokp);
+  t.sp_out = take(t.tokp, d);
+  t.s_frames = take(t.btp, d);
+  for (int64_t l = 0; l < n_tp; ++l) take_layer(t.tp[l], t.btp);
+  t.tp_out = take(t.btp, d);
+  t.h0 = take(t.bp, d); t.u0 = take(t.bp, d); t.z1 = take(t.bp, d); t.z2 = take(t.bp, d);
+  t.bytes = off;
+  return t;
+}
+
+// backward scratch: gradient buffers for the spatial phase (tok rows) and, separately, the temporal phase (BT
+// rows) so that each one's row padding stays zero; split-K slabs; reduction scratch.
+struct Scratch {
+  float *sA, *sB, *sC, *sQKV, *sH;  // spatial: (tokp,d) x3, (tokp,3d), (tokp,4d)
+  float *tA, *tB, *tC, *tQKV, *tH;  // temporal
+  float *hA, *hB;                   // head: (bp,d) x2
+  float* slabs;
+  float* red;
+  size_t slab_floats, bytes;
+};
+
+constexpr int MAX_SPLIT = 32;
+
+static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, int64_t C) {
+  Scratch s;
+  const int64_t tokp = up32(B * T * N), btp = up32(B * T), bp = up32(B);
+  size_t off = 0;
+  auto take = [&](int64_t floats) { float* p = (float*)(base + off); off = align256(off + (size_t)floats * sizeof(float)); return p; };
+  s.sA = take(tokp * d); s.sB = take(tokp * d); s.sC = take(tokp * d); s.sQKV = take(tokp * 3 * d); s.sH = take(tokp * 4 * d);
+  s.tA = take(btp * d); s.tB = take(btp * d); s.tC = take(btp * d); s.tQKV = take(btp * 3 * d); s.tH = take(btp * 4 * d);
+  s.hA = take(bp * d); s.hB = take(bp * d);
+  s.slab_floats = (size_t)MAX_SPLIT * 4 * d * d;
+  s.slabs = take((int64_t)s.slab_floats);
+  int64_t red = ln_bwd_scratch_floats(d);
+  if (64 * 4 * d > red) red = 64 * 4 * d;
+  const int64_t eb = embed_bwd_scratch_floats(B * T * N, C, d);
+  if (eb > red) red = eb;
+  s.red = take(red);
+  s.bytes = off;
+  return s;
+}
+
+#define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+static int n_cu_cached() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+// g_w (n_out, k_in) += dYᵀ·X with dY (Mp, n_out), X (Mp, k_in): split the token contraction so the persistent grid is full
+static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k_in, int64_t Mp, float* g_w, const Scratch& sc,
+                       hipStream_t s) {
+  if (!g_w) return 0;
+  const int64_t tiles = ((n_out + 255) / 256) * ((k_in + 127) / 128);
+  const int64_t steps = Mp / 32;
+  int64_t want = (2 * n_cu_cached() + tiles - 1) / tiles;
+  if (want > MAX_SPLIT) want = MAX_SPLIT;
+  int split = 1;
+  for (int64_t c = 1; c <= want; ++c) if (steps % c == 0) split = (int)c;
+  TRY(launch_gemm(1, 1, dy, n_out, x, k_in, nullptr, nullptr, 0, sc.slabs, k_in, n_out * k_in, n_out, k_in, Mp, split,
+                  STLT_ACT_NONE, s));
+  return launch_reduce_slabs(sc.slabs, n_out * k_in, split, g_w, n_out * k_in, 1, s);
+}
+
+// backward of one encoder layer.  dy: gradient wrt the layer output (M,d) in bufA; on return bufA holds the gradient
+// wrt the layer input.  bufB / bufC (M,d), bufQ (M,3d), bufH (M,4d) are scratch with zero row padding.
+static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
+                          int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, float* bufA, float* bufB,
+                          float* bufC, float* bufQ, float* bufH, const Scratch& sc, hipStream_t s) {
+  auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
+  // y = LN2(x1 + f)
+  TRY(launch_ln_bwd(bufA, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm2_w),
+                    G(&stlt_layer_params::norm2_b), sc.red, s));                                   // bufB = ds2
+  // f = h·W2ᵀ + b2
+  TRY(weight_grad(bufB, d, t.h, 4 * d, Mp, G(&stlt_layer_params::lin2_w), sc, s));
+  if (float* gb = G(&stlt_layer_params::lin2_b)) TRY(launch_colsum_acc(bufB, d, M, d, gb, sc.red, s));
+  TRY(launch_gemm(0, 1, bufB, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, M, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
+  // h = gelu(u)
+  TRY(launch_gelu_bwd(bufH, t.u, bufH, M * 4 * d, s));                                            // bufH = du
+  // u = x1·W1ᵀ + b1
+  TRY(weight_grad(bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w), sc, s));
+  if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_colsum_acc(bufH, 4 * d, M, 4 * d, gb, sc.red, s));
+  TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, M, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
+  // x1 = LN1(x + a)
+  TRY(launch_ln_bwd(bufC, d, t.x, d, t.a, d, lp.norm1_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm1_w),
+                    G(&stlt_layer_params::norm1_b), sc.red, s));                                   // bufB = ds1
+  // a = ctx·Woᵀ + bo
+  TRY(weight_grad(bufB, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w), sc, s));
+  if (float* gb = G(&stlt_layer_params::out_proj_b)) TRY(launch_colsum_acc(bufB, d, M, d, gb, sc.red, s));
+  TRY(launch_gemm(0, 1, bufB, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
+  // ctx = attention(qkv)
+  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s));                        // bufQ = dqkv
+  // qkv = x·Winᵀ + bin
+  TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
+  if (float* gb = G(&stlt_layer_params::in_proj_b)) TRY(launch_colsum_acc(bufQ, 3 * d, M, 3 * d, gb, sc.red, s));
+  TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, bufB, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
+  return 0;
+}
+
+static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
+                         const uint8_t* kpm, int causal, int kid, float* y, hipStream_t s) {
+  TRY(launch_linear(t.x, d, lp.in_proj_w, lp.in_proj_b, t.qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
+  TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s));
+  TRY(launch_linear(t.ctx, d, lp.out_proj_w, lp.out_proj_b, t.a, d, M, d, d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(t.a, d, t.x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, t.x1, d, s));
+  TRY(launch_linear(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, 4 * d, M, 4 * d, d, STLT_ACT_NONE, s));
+  TRY(launch_gelu_fwd(t.u, t.h, M * 4 * d, s));
+  TRY(launch_linear(t.h, 4 * d, lp.lin2_w, lp.lin2_b, t.f, d, M, d, 4 * d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(t.f, d, t.x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, M, d, y, d, s));
+  return 0;
+}
+
+static int check_train(const stlt_params* p, const stlt_inputs* in) {
+  if (!p || !in) return stlt_set_error(STLT_EINVAL, "null params/inputs");
+  if (p->d <= 0 || p->H <= 0 || p->d % p->H != 0 || p->d / p->H != 64) return stlt_set_error(STLT_EINVAL, "head dim must be 64");
+  if (p->n_spatial < 0 || p->n_spatial > 64 || p->n_temporal < 0 || p->n_temporal > 64) return stlt_set_error(STLT_EINVAL, "layer count out of range");
+  if (in->B <= 0 || in->T <= 0 || in->N <= 0 || in->T > p->n_positions) return stlt_set_error(STLT_EINVAL, "bad batch shape");
+  if (!in->categories || !in->boxes || !in->kpm_boxes || !in->frame_types || !in->kpm_frames || !in->lengths)
+    return stlt_set_error(STLT_EINVAL, "null input tensor");
+  if (!p->fc1_w || !p->fc2_w || p->n_classes <= 0) return stlt_set_error(STLT_EINVAL, "prediction head missing");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal) {
+  if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || n_spatial < 0 || n_spatial > 64 || n_temporal < 0 || n_temporal > 64) return 0;
+  return tape_layout(nullptr, B, T, N, d, n_spatial, n_temporal).bytes;
+}
+
+size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories) {
+  if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || n_categories <= 0) return 0;
+  return scratch_layout(nullptr, B, T, N, d, n_categories).bytes;
+}
+
+int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_mem, size_t tape_bytes, float* logits,
+                       stlt_stream_t stream) {
+  TRY(check_train(p, in));
+  if (!logits || !tape_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_forward: null logits/tape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
+  const Tape t = tape_layout((char*)tape_mem, B, T, N, d, p->n_spatial, p->n_temporal);
+  if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
+  const int64_t tok = B * T * N, BT = B * T;
+  float* x0 = p->n_spatial > 0 ? t.sp[0].x : t.sp_out;
+  TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
+                   p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x0, s, t.s_embed));
+  for (int64_t l = 0; l < p->n_spatial; ++l) {
+    float* y = l + 1 < p->n_spatial ? t.sp[l + 1].x : t.sp_out;
+    TRY(layer_forward(p->spatial[l], d, H, t.sp[l], tok, BT, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, y, s));
+  }
+  float* g0 = p->n_temporal > 0 ? t.tp[0].x : t.tp_out;
+  TRY(launch_frames_embed(t.sp_out, N * d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b,
+                          p->ln_eps, B, T, d, g0, s, t.s_frames));
+  for (int64_t l = 0; l < p->n_temporal; ++l) {
+    float* y = l + 1 < p->n_temporal ? t.tp[l + 1].x : t.tp_out;
+    TRY(layer_forward(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, y, s));
+  }
+  TRY(launch_gather_last(t.tp_out, in->lengths, B, T, d, t.h0, s));
+  TRY(launch_linear(t.h0, d, p->fc1_w, p->fc1_b, t.u0, d, B, d, d, STLT_ACT_NONE, s));
+  TRY(launch_gelu_fwd(t.u0, t.z1, B * d, s));
+  TRY(launch_add_layernorm(t.z1, d, nullptr, 0, p->head_ln_w, p->head_ln_b, p->ln_eps, B, d, t.z2, d, s));
+  TRY(launch_linear(t.z2, d, p->fc2_w, p->fc2_b, logits, p->n_classes, B, p->n_classes, d, STLT_ACT_NONE, s));
+  return 0;
+}
+
+int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_inputs* in, const void* tape_mem,
+                        size_t tape_bytes, void* scratch_mem, size_t scratch_bytes, const float* dlogits,
+                        stlt_stream_t stream) {
+  TRY(check_train(p, in));
+  if (!g || !dlogits || !tape_mem || !scratch_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H, K = p->n_classes;
+  const Tape t = tape_layout((char*)const_cast<void*>(tape_mem), B, T, N, d, p->n_spatial, p->n_temporal);
+  if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
+  const Scratch sc = scratch_layout((char*)scratch_mem, B, T, N, d, p->n_categories);
+  if (scratch_bytes < sc.bytes) return stlt_set_error(STLT_EWORKSPACE, "scratch %zu B < required %zu B", scratch_bytes, sc.bytes);
+  const int64_t tok = B * T * N, BT = B * T;
+  auto W = [](const float* q) { return const_cast<float*>(q); };
+
+  // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
+  if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
+  if (g->fc2_b) TRY(launch_colsum_acc(dlogits, K, B, K, W(g->fc2_b), sc.red, s));
+  TRY(launch_small_gemm(dlogits, K, 1, p->fc2_w, d, 1, sc.hA, d, B, d, K, 0, s));                   // hA = dz2
+  TRY(launch_ln_bwd(sc.hA, d, t.z1, d, nullptr, 0, p->head_ln_w, p->ln_eps, B, d, sc.hB, d, W(g->head_ln_w), W(g->head_ln_b),
+                    sc.red, s));                                                                    // hB = dz1
+  TRY(launch_gelu_bwd(sc.hB, t.u0, sc.hB, B * d, s));                                               // hB = du0
+  if (g->fc1_w) TRY(launch_small_gemm(sc.hB, 1, d, t.h0, d, 1, W(g->fc1_w), d, d, d, B, 1, s));     // (d,d) += du0ᵀ·h0
+  if (g->fc1_b) TRY(launch_colsum_acc(sc.hB, d, B, d, W(g->fc1_b), sc.red, s));
+  TRY(launch_small_gemm(sc.hB, d, 1, p->fc1_w, d, 1, sc.hA, d, B, d, d, 0, s));                     // hA = dh0
+  TRY(launch_scatter_last(sc.hA, in->lengths, B, T, d, sc.tA, s));                                  // tA = d(backbone out)
+
+  // ---- temporal transformer
+  for (int64_t l = p->n_temporal - 1; l >= 0; --l)
+    TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, t.btp, B, T, in->kpm_frames, 1,
+                       sc.tA, sc.tB, sc.tC, sc.tQKV, sc.tH, sc, s));
+  // ---- frames embeddings (models.py:98-111)
+  TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, sc.tB, d, W(g->frames_ln_w),
+                    W(g->frames_ln_b), sc.red, s));
+  TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, sc.sA, W(g->pos_emb), W(g->type_emb), s));   // sA = d(spatial out), CLS rows only
+  // ---- spatial transformer
+  for (int64_t l = p->n_spatial - 1; l >= 0; --l)
+    TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, t.tokp, BT, N, in->kpm_boxes, 0,
+                       sc.sA, sc.sB, sc.sC, sc.sQKV, sc.sH, sc, s));
+  // ---- category / box / score embeddings (models.py:29-39)
+  TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sB, d, W(g->emb_ln_w), W(g->emb_ln_b),
+                    sc.red, s));
+  TRY(launch_embed_bwd(sc.sB, in->categories, in->boxes, in->scores, p->n_categories, tok, d, W(g->cat_emb), W(g->box_w),
+                       W(g->box_b), W(g->score_w), W(g->score_b), sc.red, s));
+  return 0;
+}
+
+}  // extern "C"

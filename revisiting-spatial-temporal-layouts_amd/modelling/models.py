@@ -189,6 +189,7 @@ class StltBackbone(nn.Module):
         state = self.__dict__.copy()
         state["_cache"] = None
         state["_ws"] = _Workspace()
+        state.pop("_train_bufs", None)
         return state
 
     @classmethod
@@ -207,16 +208,23 @@ class StltBackbone(nn.Module):
         w1 = self.transformer.layers[-1].norm2.bias if len(self.transformer.layers) else w0
         return (w0.data_ptr(), w1.data_ptr(), w0.device)
 
-    def c_params(self, head: Optional["ClassificationHead"] = None):
-        key = (self._sentinel(), None if head is None else head.fc2.weight.data_ptr())
-        if self._cache is not None and self._cache[0] == key:
-            return self._cache[1]
+    def _build_struct(self, head: Optional["ClassificationHead"], ptr):
+        """Fill a stlt_params table; `ptr(tensor)` yields the device pointer to store for that parameter (its data
+        for the forward tables, its gradient buffer — or None — for the backward's gradient table)."""
         cfg = self.config
         fe = self.frames_embeddings
         le = fe.layout_embedding
         cbe = le.category_box_embeddings
-        sp = (L.LayerParams * max(1, len(le.transformer.layers)))(*[l.c_struct() for l in le.transformer.layers])
-        tp = (L.LayerParams * max(1, len(self.transformer.layers)))(*[l.c_struct() for l in self.transformer.layers])
+
+        def layer_struct(l):
+            sa = l.self_attn
+            ts = (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, l.linear1.weight,
+                  l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm1.weight, l.norm1.bias, l.norm2.weight,
+                  l.norm2.bias)
+            return L.LayerParams(*[ptr(t) for t in ts])
+
+        sp = (L.LayerParams * max(1, len(le.transformer.layers)))(*[layer_struct(l) for l in le.transformer.layers])
+        tp = (L.LayerParams * max(1, len(self.transformer.layers)))(*[layer_struct(l) for l in self.transformer.layers])
         p = L.Params()
         p.d, p.H = cfg.hidden_size, cfg.num_attention_heads
         p.n_categories = cbe.category_embeddings.weight.shape[0]
@@ -230,14 +238,29 @@ class StltBackbone(nn.Module):
                         ("emb_ln_b", cbe.layer_norm.bias), ("pos_emb", fe.position_embeddings.weight),
                         ("type_emb", fe.frame_type_embedding.weight), ("frames_ln_w", fe.layer_norm.weight),
                         ("frames_ln_b", fe.layer_norm.bias)):
-            setattr(p, name, _dev_ptr(t))
+            setattr(p, name, ptr(t))
         p.spatial, p.temporal = sp, tp
         if head is not None:
             for name, t in (("fc1_w", head.fc1.weight), ("fc1_b", head.fc1.bias), ("head_ln_w", head.layer_norm.weight),
                             ("head_ln_b", head.layer_norm.bias), ("fc2_w", head.fc2.weight), ("fc2_b", head.fc2.bias)):
-                setattr(p, name, _dev_ptr(t))
-        self._cache = (key, (p, sp, tp))  # keep the layer arrays alive with the struct
+                setattr(p, name, ptr(t))
+        return p, sp, tp  # keep the layer arrays alive with the struct
+
+    def c_params(self, head: Optional["ClassificationHead"] = None):
+        key = (self._sentinel(), None if head is None else head.fc2.weight.data_ptr())
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1]
+        self._cache = (key, self._build_struct(head, _dev_ptr))
         return self._cache[1]
+
+    def _train_buf(self, name: str, nbytes: int, device) -> torch.Tensor:
+        """Zero-filled tape / scratch of the training step, allocated once per shape (the library relies on the row
+        padding staying zero and never writes it)."""
+        bufs = self.__dict__.setdefault("_train_bufs", {})
+        cur = bufs.get(name)
+        if cur is None or cur.device != device or cur.numel() != nbytes:
+            bufs[name] = cur = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        return cur
 
     def _flags(self) -> int:
         return ((L.FLAG_CLS_ONLY_LAST_SPATIAL if self.cls_only_last_spatial else 0)
@@ -292,9 +315,22 @@ class Stlt(nn.Module):
             self.backbone.train(False)
         return self  # the reference returns None here; returning self is a superset
 
+    def _grad_params(self, has_scores: bool):
+        """ids of the parameters the forward actually uses (the others get no gradient, like in the reference: the
+        dead `encoder_layer` copy, and `score_embeddings` when the batch has no scores — SURVEY.md §5)."""
+        le = self.backbone.frames_embeddings.layout_embedding
+        skip = {id(q) for q in le.encoder_layer.parameters()}
+        if not has_scores:
+            skip |= {id(q) for q in le.category_box_embeddings.score_embeddings.parameters()}
+        return {id(q) for q in self.parameters()} - skip
+
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         bb = self.backbone
         bb._check_mode()
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            params = tuple(self.parameters())
+            logits = _StltTrainFn.apply(self, batch, *params)
+            return {k: v for k, v in zip(self.logit_names, (logits,))}
         lib = L.load()
         inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=True)
         device = batch["categories"].device
@@ -307,6 +343,57 @@ class Stlt(nn.Module):
             L.check(lib.stlt_forward(C.byref(p), C.byref(inp), ws.data_ptr(), ws.numel(), bb._flags(), None,
                                      logits.data_ptr(), torch.cuda.current_stream().cuda_stream), "stlt_forward")
         return {k: v for k, v in zip(self.logit_names, (logits,))}
+
+
+class _StltTrainFn(torch.autograd.Function):
+    """Autograd shell of the native training step: forward = stlt_train_forward (records the tape), backward =
+    stlt_train_backward (the reverse sweep in HIP).  The parameters are passed as inputs only so that autograd
+    routes their gradients; all arithmetic happens behind the C-ABI."""
+
+    @staticmethod
+    def forward(ctx, model, batch, *params):
+        lib = L.load()
+        bb = model.backbone
+        inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=True)
+        device = batch["categories"].device
+        p, _, _ = bb.c_params(model.prediction_head)
+        cfg = model.config
+        d, K = cfg.hidden_size, model.prediction_head.fc2.weight.shape[0]
+        n_sp, n_tp = p.n_spatial, p.n_temporal
+        tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, n_sp, n_tp)), device)
+        logits = torch.empty(B, K, device=device, dtype=torch.float32)
+        with torch.cuda.device(device):
+            L.check(lib.stlt_train_forward(C.byref(p), C.byref(inp), tape.data_ptr(), tape.numel(), logits.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "stlt_train_forward")
+        ctx.model, ctx.batch, ctx.shape, ctx.params = model, batch, (B, T, N, d), params
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = L.load()
+        model, batch = ctx.model, ctx.batch
+        bb = model.backbone
+        B, T, N, d = ctx.shape
+        device = dlogits.device
+        inp, keep, _ = _prep_inputs(batch, need_lengths=True)
+        p, _, _ = bb.c_params(model.prediction_head)
+        used = model._grad_params("scores" in batch)
+        want = [prm for prm in ctx.params if prm.requires_grad and id(prm) in used]
+        flat = torch.zeros(sum(q.numel() for q in want), device=device, dtype=torch.float32)
+        views, off = {}, 0
+        for q in want:
+            views[id(q)] = flat[off: off + q.numel()].view_as(q)
+            off += q.numel()
+        g, gsp, gtp = bb._build_struct(model.prediction_head, lambda t: views[id(t)].data_ptr() if id(t) in views else None)
+        tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, p.n_spatial, p.n_temporal)), device)
+        scratch = bb._train_buf("scratch", int(lib.stlt_train_scratch_bytes(B, T, N, d, p.n_categories)), device)
+        dl = dlogits.contiguous().float()
+        with torch.cuda.device(device):
+            L.check(lib.stlt_train_backward(C.byref(p), C.byref(g), C.byref(inp), tape.data_ptr(), tape.numel(),
+                                            scratch.data_ptr(), scratch.numel(), dl.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
+        model._last_flat_grad = flat  # one contiguous buffer: what a data-parallel wrapper all-reduces
+        return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)
 
 
 models_factory = {"stlt": Stlt}

@@ -1,0 +1,96 @@
+"""Training step parity: the native forward/backward against torch autograd on the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden_case
+from oracle import stlt_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _oracle_grads(sd, batch, H, labels, dtype=torch.float64):
+    leaves = {k: (v.detach().to(dtype).requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    b = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in batch.items()}
+    logits = O.stlt_forward(leaves, b, H, dtype=dtype)["stlt"]
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    return loss.item(), logits.detach(), {k: v.grad for k, v in leaves.items() if v.is_floating_point()}
+
+
+@pytest.mark.parametrize("name,B,with_scores", [("cfg1", 3, False), ("cfg1", 5, True), ("cfg2", 2, False)])
+def test_gradients_match_oracle_autograd(pkg, name, B, with_scores):
+    c = pkg.synth.CONFIGS[name]
+    H = c["num_attention_heads"]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=31, gain=1.5)
+    m.load_state_dict(sd)
+    m.train(True)  # hidden_dropout_prob = 0 in model_kwargs
+    m.to(DEV)
+    batch = pkg.synth.make_batch(B, c["T"], c["N"], dataset=c["dataset"], seed=77, with_scores=with_scores)
+    labels = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(5))
+    ref_loss, ref_logits, ref_g = _oracle_grads(sd, batch, H, labels)
+
+    out = m({k: v.to(DEV) for k, v in batch.items()})["stlt"]
+    assert out.requires_grad
+    assert (out.detach().cpu().double() - ref_logits).abs().max().item() <= 1e-4
+    loss = F.cross_entropy(out, labels.to(DEV))
+    assert abs(loss.item() - ref_loss) <= 1e-5
+    loss.backward()
+
+    worst = ("", 0.0)
+    n_checked = 0
+    for k, p in m.named_parameters():
+        g_ref = ref_g[k]
+        dead = "encoder_layer." in k or ("score_embeddings" in k and not with_scores)
+        if dead:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            assert g_ref is None or g_ref.abs().max().item() == 0.0, k
+            continue
+        assert p.grad is not None, k
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        err = (p.grad.cpu().double() - g_ref).abs().max().item() / scale
+        n_checked += 1
+        if err > worst[1]:
+            worst = (k, err)
+        assert err <= 2e-4, f"{k}: relative grad error {err:.2e} (|g|max={scale:.2e})"
+    print(f"{name} B={B}: {n_checked} gradients checked, worst {worst[0]} rel err {worst[1]:.2e}")
+    # padding_idx rows get no gradient (models.py:22,91)
+    assert m.backbone.frames_embeddings.frame_type_embedding.weight.grad[0].abs().max().item() == 0.0
+    assert m.backbone.frames_embeddings.layout_embedding.category_box_embeddings.category_embeddings.weight.grad[0].abs().max().item() == 0.0
+
+
+def test_backward_is_bitwise_reproducible_and_accumulates(pkg):
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    sd, batch, z, meta = golden_case(name)
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.load_state_dict(sd)
+    m.train(True).to(DEV)
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    labels = torch.arange(batch["categories"].shape[0], device=DEV) % c["num_classes"]
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        F.cross_entropy(m(b)["stlt"], labels).backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])  # slab reductions, no float atomics
+    F.cross_entropy(m(b)["stlt"], labels).backward()  # second backward without zero_grad: autograd accumulates
+    k0 = "prediction_head.fc2.weight"
+    assert (dict(m.named_parameters())[k0].grad - 2 * grads[0][k0]).abs().max().item() <= 1e-6 * grads[0][k0].abs().max().item() + 1e-9
+
+
+def test_frozen_backbone_trains_head_only(pkg, tmp_path):
+    kw = pkg.synth.model_kwargs("cfg1")
+    c = pkg.synth.CONFIGS["cfg1"]
+    bb = pkg.StltBackbone(pkg.StltModelConfig(**kw))
+    path = str(tmp_path / "bb.pt")
+    torch.save(bb.state_dict(), path)
+    m = pkg.Stlt(pkg.StltModelConfig(**kw, load_backbone_path=path, freeze_backbone=True))
+    m.train(True).to(DEV)
+    batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(4, c["T"], c["N"], seed=3).items()}
+    F.cross_entropy(m(batch)["stlt"], torch.tensor([1, 2, 3, 4], device=DEV)).backward()
+    assert all(p.grad is None for p in m.backbone.parameters())
+    assert all(p.grad is not None and p.grad.abs().max().item() > 0 for p in m.prediction_head.parameters())
