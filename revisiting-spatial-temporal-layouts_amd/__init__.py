@@ -3,7 +3,7 @@
 The directory name carries a hyphen, so import it with
 ``importlib.import_module("revisiting-spatial-temporal-layouts_amd")``.
 """
-from . import _lib, dist, infer, ops, synth  # noqa: F401
+from . import _lib, dist, infer, ops, synth, train  # noqa: F401
 from ._lib import StltHipError  # noqa: F401
 from .modelling.configs import StltModelConfig, model_configs_factory  # noqa: F401
 from .modelling.models import (  # noqa: F401
@@ -18,4 +18,4 @@ from .modelling.models import (  # noqa: F401
 from .utils.model_utils import generate_square_subsequent_mask  # noqa: F401
 
 __all__ = ["Stlt", "StltBackbone", "StltModelConfig", "models_factory", "model_configs_factory", "StltHipError",
-           "ops", "synth", "dist", "infer"]
+           "ops", "synth", "dist", "infer", "train"]

@@ -94,3 +94,35 @@ def test_frozen_backbone_trains_head_only(pkg, tmp_path):
     F.cross_entropy(m(batch)["stlt"], torch.tensor([1, 2, 3, 4], device=DEV)).backward()
     assert all(p.grad is None for p in m.backbone.parameters())
     assert all(p.grad is not None and p.grad.abs().max().item() > 0 for p in m.prediction_head.parameters())
+
+
+def test_three_training_steps_match_reference_golden(pkg):
+    """Reference train step (train.py:119-135 with parser defaults, warm-up 2 of 10 steps) captured by
+    tools/gen_golden_train.py: loss, clip_grad_norm_ value and parameter slices after each step."""
+    from conftest import GOLDEN
+    import os
+    z = np.load(os.path.join(GOLDEN, "train_cfg1.npz"))
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    B = int(z["batch"][0])
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    tr = pkg.train.Trainer(m, "something", learning_rate=5e-5, weight_decay=1e-3, clip_val=5.0, warmup_steps=2, total_steps=10)
+    watch = ["prediction_head.fc2.bias", "prediction_head.fc2.weight",
+             "backbone.frames_embeddings.layout_embedding.category_box_embeddings.category_embeddings.weight",
+             "backbone.frames_embeddings.layout_embedding.transformer.layers.0.self_attn.in_proj_weight",
+             "backbone.transformer.layers.7.linear2.weight", "backbone.frames_embeddings.position_embeddings.weight",
+             "backbone.transformer.layers.3.norm1.weight"]
+    params = dict(m.named_parameters())
+    for s in range(int(z["steps"][0])):
+        batch = pkg.synth.make_batch(B, c["T"], c["N"], seed=500 + s)
+        batch["labels"] = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(900 + s))
+        out = tr.step({k: v.to(DEV) for k, v in batch.items()})
+        assert abs(float(out["loss"]) - float(z[f"loss{s}"][0])) <= 2e-5, s
+        assert abs(float(out["grad_norm"]) - float(z[f"gnorm{s}"][0])) <= 2e-4 * float(z[f"gnorm{s}"][0]), s
+        for i, k in enumerate(watch):
+            got = params[k].detach().reshape(-1)[:64].cpu().numpy()
+            assert np.abs(got - z[f"p{s}_{i}"]).max() <= 2.5e-5, (s, k)  # < lr/2 (Adam amplifies last-bit gradient noise)
+    assert sum(1 for p in m.parameters() if p.grad is None) == int(z["n_grad_none"][0])  # 14 dead / unused parameters
