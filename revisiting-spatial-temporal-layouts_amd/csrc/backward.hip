@@ -354,8 +354,9 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   if (!dy || !a || !w || !ds || !scratch) return stlt_set_error(STLT_EINVAL, "ln_bwd: null pointer");
   if (d <= 0 || d % 4 || d > 2048) return stlt_set_error(STLT_EINVAL, "ln_bwd: bad d=%lld", (long long)d);
   if (M == 0) return 0;
-  int64_t blocks = (M + RW_WAVES - 1) / RW_WAVES;
-  if (blocks > 256) blocks = 256;  // 1024 persistent waves
+  int64_t blocks = (M + 64 * RW_WAVES - 1) / (64 * RW_WAVES);  // ~64 rows per persistent wave
+  if (blocks < 16) blocks = M >= 16 * RW_WAVES ? 16 : (M + RW_WAVES - 1) / RW_WAVES;
+  if (blocks > 256) blocks = 256;  // at most 1024 persistent waves (scratch is sized for that)
   const int64_t n_waves = blocks * RW_WAVES;
   StltProfScope ps(STLT_K_ADDLN, s);
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,

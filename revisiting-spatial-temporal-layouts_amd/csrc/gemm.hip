@@ -357,6 +357,26 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   }
 }
 
+// Many partial rows, few columns (LayerNorm dw/db and bias-gradient partials): a block owns 16 columns, its 16
+// "slab lanes" each sum every 16th partial row, then a fixed-order LDS pass adds the 16 lanes: deterministic.
+__global__ __launch_bounds__(256) void reduce_tall_kernel(const float* __restrict__ slabs, int64_t stride, int n_slabs,
+                                                          float* __restrict__ dst, int64_t n, int accumulate) {
+  __shared__ float part[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t j = (int64_t)blockIdx.x * 16 + col;
+  float acc = 0.f;
+  if (j < n)
+    for (int s = sl; s < n_slabs; s += 16) acc += slabs[s * stride + j];
+  part[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && j < n) {
+    float t = accumulate ? dst[j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][col];
+    dst[j] = t;
+  }
+}
+
 }  // namespace
 
 static int n_cu() {
@@ -405,6 +425,10 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s) {
   if (!slabs || !dst || n_slabs < 1) return stlt_set_error(STLT_EINVAL, "reduce_slabs: bad arguments");
   if (n == 0) return 0;
+  if (n_slabs > 32 && n <= 16384) {
+    hipLaunchKernelGGL(reduce_tall_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, slabs, stride, n_slabs, dst, n, accumulate);
+    return stlt_check_launch("reduce_tall_kernel");
+  }
   int64_t blocks = (n + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, stride, n_slabs, dst, n, accumulate);
