@@ -146,14 +146,18 @@ int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, s
  * gradients into the buffers named by `grads` — the same struct as the parameters, every pointer being the gradient
  * buffer of that parameter or NULL to skip it (frozen / unused parameters; models.py:172-174).  `scratch` must be
  * zero-filled once by the caller as well.  Embedding rows at padding_idx 0 receive no gradient (models.py:22,91).
- * Dropout is not applied (train with hidden_dropout_prob = 0).  Attention backward supports sequences <= 64 tokens. */
+ * Dropout (nn.Dropout after both embedding LayerNorms; attention probabilities, dropout1, FFN dropout and dropout2 of
+ * every encoder layer — SURVEY.md App. B) is a counter-based mask: element idx of site s is kept iff the high 32 bits of
+ * splitmix64(idx + seed*0x9E3779B97F4A7C15 + s*0xD1B54A32D192ED03) are >= p*2^32, kept values are scaled by 1/(1-p).
+ * The backward recomputes the masks from (p, seed): pass the same values to both calls.  p = 0 disables it.
+ * Attention backward supports sequences <= 64 tokens. */
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);
 size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories);
 int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape, size_t tape_bytes, float* logits,
-                       stlt_stream_t stream);
+                       float dropout_p, uint64_t dropout_seed, stlt_stream_t stream);
 int stlt_train_backward(const stlt_params* p, const stlt_params* grads, const stlt_inputs* in, const void* tape,
                         size_t tape_bytes, void* scratch, size_t scratch_bytes, const float* dlogits,
-                        stlt_stream_t stream);
+                        float dropout_p, uint64_t dropout_seed, stlt_stream_t stream);
 
 /* ---- per-kernel timing (bench.py roofline leg): hipEvents around every launch of the whole-path calls ---- */
 #define STLT_K_EMBED 0

@@ -34,6 +34,55 @@ _LAYER_KEYS = (
 )
 
 
+# ---- train-mode dropout: the build's counter-based masks restated (include/stlt_hip.h, "training step") -------------
+# The reference uses nn.Dropout at six sites; its Philox stream cannot be reproduced, so the mask
+# DEFINITION is the build's own: keep iff high32(mix(idx + seed*G1 + site*G2)) >= p*2^32 with the splitmix64 finaliser.
+_M64 = (1 << 64) - 1
+
+
+def dropout_keep(p: float, seed: int, site: int, idx: "np.ndarray"):
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & _M64) + np.uint64((site * 0xD1B54A32D192ED03) & _M64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    thr = min(int(p * 4294967296.0), 4294967295)
+    return (z >> np.uint64(32)) >= np.uint64(thr)
+
+
+class Dropout:
+    """p, seed -> multiplicative masks (kept entries carry float32(1/(1-p)), as the kernels multiply by it)."""
+
+    def __init__(self, p: float, seed: int):
+        self.p, self.seed = float(p), int(seed)
+        import numpy as np
+        self.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+    def elementwise(self, site: int, x: torch.Tensor) -> torch.Tensor:
+        import numpy as np
+        if self.p <= 0:
+            return x
+        idx = np.arange(x.numel(), dtype=np.uint64)
+        keep = dropout_keep(self.p, self.seed, site, idx).reshape(tuple(x.shape))
+        return x * (torch.from_numpy(keep).to(x.dtype) * self.scale)
+
+    def attention(self, site: int, probs: torch.Tensor) -> torch.Tensor:
+        """probs (S,H,L,L): element (s,h,i,j) has idx = (((s*L+i)*H + h) << 8) | j."""
+        import numpy as np
+        if self.p <= 0:
+            return probs
+        S, H, L, _ = probs.shape
+        s_, h_, i_, j_ = np.meshgrid(np.arange(S, dtype=np.uint64), np.arange(H, dtype=np.uint64),
+                                     np.arange(L, dtype=np.uint64), np.arange(L, dtype=np.uint64), indexing="ij")
+        idx = ((((s_ * np.uint64(L) + i_) * np.uint64(H)) + h_) << np.uint64(8)) | j_
+        keep = dropout_keep(self.p, self.seed, site, idx)
+        return probs * (torch.from_numpy(keep).to(probs.dtype) * self.scale)
+
+
+SITE_EMBED, SITE_FRAMES = 0xE0, 0xE1
+
+
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
     """nn.LayerNorm over the last dim: biased variance, eps inside the sqrt."""
     mu = x.mean(dim=-1, keepdim=True)
@@ -59,7 +108,8 @@ def category_box_embeddings(sd: Dict[str, torch.Tensor], prefix: str, batch: Dic
     return layer_norm(x, sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], eps)
 
 
-def attention_core(qkv: torch.Tensor, mask_add: torch.Tensor, H: int) -> torch.Tensor:
+def attention_core(qkv: torch.Tensor, mask_add: torch.Tensor, H: int, drop: Optional["Dropout"] = None, site: int = 0
+                   ) -> torch.Tensor:
     """softmax(QK^T/sqrt(dh) + M) V per head.  qkv (S,L,3d) packed [q;k;v]; mask_add (S,L,L) of {0,-inf}."""
     S, L, d3 = qkv.shape
     d = d3 // 3
@@ -71,20 +121,23 @@ def attention_core(qkv: torch.Tensor, mask_add: torch.Tensor, H: int) -> torch.T
     s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh)) + mask_add.unsqueeze(1)
     p = torch.softmax(s, dim=-1)
     p = torch.nan_to_num(p, nan=0.0)  # fully-masked rows -> 0 (torch>=2 behaviour; cannot occur under §8b invariants)
+    if drop is not None:
+        p = drop.attention(site, p)
     return (p @ v).transpose(1, 2).reshape(S, L, d)
 
 
-def encoder_layer(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, mask_add: torch.Tensor, H: int
-                  ) -> torch.Tensor:
+def encoder_layer(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, mask_add: torch.Tensor, H: int,
+                  drop: Optional["Dropout"] = None, site0: int = 0) -> torch.Tensor:
     """nn.TransformerEncoderLayer as configured at models.py:46-52,118-124:
     post-norm, gelu, dim_feedforward=4d, LN eps = torch default 1e-5 (config eps is NOT forwarded)."""
     p = lambda k: sd[prefix + k]
     qkv = x @ p("self_attn.in_proj_weight").t() + p("self_attn.in_proj_bias")
-    a = attention_core(qkv, mask_add, H)
-    x = layer_norm(x + a @ p("self_attn.out_proj.weight").t() + p("self_attn.out_proj.bias"),
+    dz = (lambda k, t: drop.elementwise(site0 + k, t)) if drop is not None else (lambda k, t: t)
+    a = attention_core(qkv, mask_add, H, drop, site0)
+    x = layer_norm(x + dz(1, a @ p("self_attn.out_proj.weight").t() + p("self_attn.out_proj.bias")),
                    p("norm1.weight"), p("norm1.bias"), 1e-5)
-    h = gelu(x @ p("linear1.weight").t() + p("linear1.bias"))
-    x = layer_norm(x + h @ p("linear2.weight").t() + p("linear2.bias"), p("norm2.weight"), p("norm2.bias"), 1e-5)
+    h = dz(2, gelu(x @ p("linear1.weight").t() + p("linear1.bias")))
+    x = layer_norm(x + dz(3, h @ p("linear2.weight").t() + p("linear2.bias")), p("norm2.weight"), p("norm2.bias"), 1e-5)
     return x
 
 
@@ -94,7 +147,7 @@ def _neg_inf_mask(masked: torch.Tensor, dtype) -> torch.Tensor:
 
 def backbone_forward(sd: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], num_heads: int,
                      layer_norm_eps: float = 1e-12, prefix: str = "", dtype=torch.float32,
-                     taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                     taps: Optional[Dict[str, torch.Tensor]] = None, drop: Optional["Dropout"] = None) -> torch.Tensor:
     """StltBackbone.forward — models.py:136-152 — returned batch-major (B,T,d)
     (the reference returns the (T,B,d) transpose of this)."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items() if k.startswith(prefix)}
@@ -103,6 +156,8 @@ def backbone_forward(sd: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]
     B, T, N = batch["categories"].shape
     # --- SpatialTransformer.forward models.py:57-81
     x = category_box_embeddings(sd, LE + "category_box_embeddings.", batch, layer_norm_eps)  # (B,T,N,d)
+    if drop is not None:
+        x = drop.elementwise(SITE_EMBED, x)
     if taps is not None:
         taps["embed"] = x.clone()
     d = x.shape[-1]
@@ -111,7 +166,7 @@ def backbone_forward(sd: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]
     m_sp = _neg_inf_mask(kpm[:, None, :].expand(B * T, N, N), x.dtype)
     n_sp = 0
     while f"{LE}transformer.layers.{n_sp}.norm1.weight" in sd:
-        x = encoder_layer(x, sd, f"{LE}transformer.layers.{n_sp}.", m_sp, num_heads)
+        x = encoder_layer(x, sd, f"{LE}transformer.layers.{n_sp}.", m_sp, num_heads, drop, 8 * (n_sp + 1))
         if taps is not None:
             taps[f"spatial{n_sp}"] = x.reshape(B, T, N, d).clone()
         n_sp += 1
@@ -121,6 +176,8 @@ def backbone_forward(sd: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]
     F_ = sd[FE + "frame_type_embedding.weight"]
     g = layer_norm(f + P[:T][None] + F_[batch["frame_types"]], sd[FE + "layer_norm.weight"],
                    sd[FE + "layer_norm.bias"], layer_norm_eps)
+    if drop is not None:
+        g = drop.elementwise(SITE_FRAMES, g)
     if taps is not None:
         taps["frames"] = g.clone()
     # --- temporal transformer models.py:140-150; causal mask utils/model_utils.py:4-7 (True strictly above diag)
@@ -130,7 +187,7 @@ def backbone_forward(sd: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]
     n_tp = 0
     x = g
     while f"{prefix}transformer.layers.{n_tp}.norm1.weight" in sd:
-        x = encoder_layer(x, sd, f"{prefix}transformer.layers.{n_tp}.", m_tp, num_heads)
+        x = encoder_layer(x, sd, f"{prefix}transformer.layers.{n_tp}.", m_tp, num_heads, drop, 8 * (n_sp + n_tp + 1))
         if taps is not None:
             taps[f"temporal{n_tp}"] = x.clone()
         n_tp += 1
@@ -148,9 +205,9 @@ def head_forward(sd: Dict[str, torch.Tensor], h: torch.Tensor, layer_norm_eps: f
 
 def stlt_forward(sd: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], num_heads: int,
                  layer_norm_eps: float = 1e-12, dtype=torch.float32,
-                 taps: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                 taps: Optional[Dict[str, torch.Tensor]] = None, drop: Optional["Dropout"] = None) -> Dict[str, torch.Tensor]:
     """Stlt.forward — models.py:185-195. -> {"stlt": (B,num_classes)}"""
-    out = backbone_forward(sd, batch, num_heads, layer_norm_eps, prefix="backbone.", dtype=dtype, taps=taps)
+    out = backbone_forward(sd, batch, num_heads, layer_norm_eps, prefix="backbone.", dtype=dtype, taps=taps, drop=drop)
     B = out.shape[0]
     h = out[torch.arange(B), batch["lengths"] - 1]  # models.py:189-192
     logits = head_forward(sd, h, layer_norm_eps)

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
                                                                   int64_t n_tokens, int64_t n_items, int L, int H,
                                                                   int GL, int nt, float scale,
                                                                   float* __restrict__ ctx,
-                                                                  unsigned long long* __restrict__ stamps) {
+                                                                  unsigned long long* __restrict__ stamps, StltDrop dr,
+                                                                  uint32_t site) {
   __shared__ __attribute__((aligned(16))) float smem_all[WAVES * WAVE_LDS_FLOATS];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* smem = smem_all + wave * WAVE_LDS_FLOATS;
@@ -213,8 +214,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
       const float* vrow = Vs + j * DH + (li & 3);
       const float v0 = vrow[swz(j, li >> 2) * 4];
       const float v1 = vrow[swz(j, 8 + (li >> 2)) * 4];
-      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, p[r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, p[r], o1, 0, 0, 0);
+      float pr = p[r];
+      if (dr.thr) {  // train-mode dropout of the attention probabilities: the denominator keeps the undropped sum
+        const uint64_t idx = ((((uint64_t)(s.tok0 + qi)) * H + s.head) << 8) | (uint64_t)(meta[r] & 0xff);
+        pr = stlt_keep(dr, site, idx) ? pr * dr.scale : 0.f;
+      }
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, pr, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, pr, o1, 0, 0, 0);
     }
     if (STAMP) asm volatile("" :: "v"(o0[0]), "v"(o1[15]));
     STAMP_AT(5);
@@ -261,9 +267,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
 
 
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
-                float* ctx, int kid, hipStream_t s) {
+                float* ctx, int kid, hipStream_t s, StltDrop dr, uint32_t site) {
   if (!qkv || !kpm || !ctx) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: null pointer");
   if (dh != DH) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: head dim %lld unsupported (kernel is built for dh=64)", (long long)dh);
+  if (dr.thr && L > 256) return stlt_set_error(STLT_EINVAL, "attention dropout supports sequences of at most 256 tokens");
   if (L <= 0 || L > 32768 || H <= 0 || H > 65535) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: bad L=%lld H=%lld", (long long)L, (long long)H);
   if (S == 0) return 0;
   const int P = L <= 16 ? (int)(TILE / L) : 1;  // sequences packed per 32-token tile
@@ -291,9 +298,9 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
   dim3 grid((unsigned)n_wg);
   if (g_stlt_debug_buf)  // diagnostic build path only (tools/attn_stamps.py); never set by the product
     hipLaunchKernelGGL(attn_core_kernel<true>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
-                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, g_stlt_debug_buf);
+                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, g_stlt_debug_buf, dr, site);
   else
     hipLaunchKernelGGL(attn_core_kernel<false>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
-                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr);
+                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, dr, site);
   return stlt_check_launch("attn_core_kernel");
 }

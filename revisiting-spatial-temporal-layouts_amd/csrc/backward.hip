@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ b2, int64_t ldb,
                                                      const float* __restrict__ w, float eps, int64_t M, int d,
                                                      float* __restrict__ ds, int64_t ldds,
-                                                     float* __restrict__ partials /* [n_waves][2][d] */) {
+                                                     float* __restrict__ partials /* [n_waves][2][d] */, StltDrop dr,
+                                                     uint32_t site_b2, float* __restrict__ ds_drop, uint32_t site_dy) {
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * RW_WAVES;
@@ -40,8 +41,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       const int e = (i * 64 + lane) * 4;
       if (e < d) {
         x[i] = *reinterpret_cast<const f32x4*>(a + row * lda + e);
-        if (b2) x[i] += *reinterpret_cast<const f32x4*>(b2 + row * ldb + e);
+        if (b2) {
+          f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + row * ldb + e);
+          if (dr.thr && site_b2) bv = stlt_drop4(dr, site_b2, (uint64_t)row * d + e, bv);  // the forward added drop(b2)
+          x[i] += bv;
+        }
         g[i] = *reinterpret_cast<const f32x4*>(dy + row * lddy + e);
+        if (dr.thr && site_dy) g[i] = stlt_drop4(dr, site_dy, (uint64_t)row * d + e, g[i]);  // dropout on the LN output
         sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
       } else {
         x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -76,7 +82,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = (i * 64 + lane) * 4;
-      if (e < d) *reinterpret_cast<f32x4*>(ds + row * ldds + e) = (g[i] - mg - x[i] * mgx) * rstd;
+      if (e < d) {
+        const f32x4 o = (g[i] - mg - x[i] * mgx) * rstd;
+        *reinterpret_cast<f32x4*>(ds + row * ldds + e) = o;
+        if (ds_drop) *reinterpret_cast<f32x4*>(ds_drop + row * ldds + e) = stlt_drop4(dr, site_b2, (uint64_t)row * d + e, o);  // gradient wrt the un-dropped b2
+      }
     }
   }
   if (partials && gw < n_waves) {
@@ -105,10 +115,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ GELU (exact erf) forward / backward
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ h, int64_t n4) {
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ h, int64_t n4,
+                                                       StltDrop dr, uint32_t site) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
     f32x4 o = {gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+    if (dr.thr) o = stlt_drop4(dr, site, (uint64_t)i * 4, o);
     reinterpret_cast<f32x4*>(h)[i] = o;
   }
 }
@@ -119,9 +131,10 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ u,
-                                                       float* __restrict__ du, int64_t n4) {
+                                                       float* __restrict__ du, int64_t n4, StltDrop dr, uint32_t site) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const f32x4 g = reinterpret_cast<const f32x4*>(dh)[i];
+    f32x4 g = reinterpret_cast<const f32x4*>(dh)[i];
+    if (dr.thr) g = stlt_drop4(dr, site, (uint64_t)i * 4, g);
     const f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
     f32x4 o = {g.x * gelu_grad(v.x), g.y * gelu_grad(v.y), g.z * gelu_grad(v.z), g.w * gelu_grad(v.w)};
     reinterpret_cast<f32x4*>(du)[i] = o;
@@ -136,7 +149,8 @@ constexpr int AB_MAXL = 64, AB_DH = 64, AB_LD = AB_DH + 1, AB_PLD = AB_MAXL + 1;
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                        const uint8_t* __restrict__ kpm, int causal, int64_t n_tokens,
-                                                       int L, int H, int GL, float scale, float* __restrict__ dqkv) {
+                                                       int L, int H, int GL, float scale, float* __restrict__ dqkv,
+                                                       StltDrop dr, uint32_t site) {
   __shared__ float Qs[AB_MAXL * AB_LD], Ks[AB_MAXL * AB_LD], Vs[AB_MAXL * AB_LD], Gs[AB_MAXL * AB_LD];
   __shared__ float Ps[AB_MAXL * AB_PLD], Ds[AB_MAXL * AB_PLD];
   __shared__ int meta[AB_MAXL];
@@ -176,6 +190,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       s += Qs[i * AB_LD + c] * Ks[j * AB_LD + c];
       dp += Gs[i * AB_LD + c] * Vs[j * AB_LD + c];
     }
+    if (dr.thr) {  // dPd -> dP: the forward multiplied P by the dropout mask before the P·V product
+      const uint64_t idx = ((((uint64_t)(tok0 + i)) * H + head) << 8) | (uint64_t)((j - (j / L) * L) & 0xff);
+      dp = stlt_keep(dr, site, idx) ? dp * dr.scale : 0.f;
+    }
     Ps[i * AB_PLD + j] = ok ? s * scale : -1e30f;
     Ds[i * AB_PLD + j] = dp;
   }
@@ -210,7 +228,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int j = 0; j < GL; ++j) {
       dq += Ds[r * AB_PLD + j] * Ks[j * AB_LD + c];   // sum_j dS[r][j] K[j][c]
       dk += Ds[j * AB_PLD + r] * Qs[j * AB_LD + c];   // sum_i dS[i][r] Q[i][c]
-      dv += Ps[j * AB_PLD + r] * Gs[j * AB_LD + c];   // sum_i P[i][r] dO[i][c]
+      float pd = Ps[j * AB_PLD + r];                  // P[i=j][key r] (dropped like in the forward for dV)
+      if (dr.thr) {
+        const uint64_t idx = ((((uint64_t)(tok0 + j)) * H + head) << 8) | (uint64_t)((r - (r / L) * L) & 0xff);
+        pd = stlt_keep(dr, site, idx) ? pd * dr.scale : 0.f;
+      }
+      dv += pd * Gs[j * AB_LD + c];                   // sum_i Pd[i][r] dO[i][c]
     }
     float* out = dqkv + (tok0 + r) * ld + head * AB_DH + c;
     out[0] = dq * scale;
@@ -350,7 +373,7 @@ int64_t ln_bwd_scratch_floats(int64_t d) { return 1024 * 2 * d; }
 
 int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
                   float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
-                  hipStream_t s) {
+                  hipStream_t s, StltDrop dr, uint32_t site_b2, float* ds_drop, uint32_t site_dy) {
   if (!dy || !a || !w || !ds || !scratch) return stlt_set_error(STLT_EINVAL, "ln_bwd: null pointer");
   if (d <= 0 || d % 4 || d > 2048) return stlt_set_error(STLT_EINVAL, "ln_bwd: bad d=%lld", (long long)d);
   if (M == 0) return 0;
@@ -360,7 +383,8 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   const int64_t n_waves = blocks * RW_WAVES;
   StltProfScope ps(STLT_K_ADDLN, s);
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
-                                            ldb, w, eps, M, (int)d, ds, ldds, scratch));
+                                            ldb, w, eps, M, (int)d, ds, ldds, scratch, dr, site_b2,
+                                            (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy));
   if (int e = stlt_check_launch("ln_bwd_kernel")) return e;
   // partial rows are interleaved [wave][dw|db][d]: two strided reductions
   if (g_w) { if (int e = launch_reduce_slabs(scratch, 2 * d, (int)n_waves, g_w, d, 1, s)) return e; }
@@ -381,26 +405,26 @@ int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g
   return launch_reduce_slabs(scratch, N, parts, g, N, 1, s);
 }
 
-int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s) {
+int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr, uint32_t site) {
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, u, h, n / 4);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, u, h, n / 4, dr, site);
   return stlt_check_launch("gelu_fwd_kernel");
 }
 
-int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s) {
+int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr, uint32_t site) {
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dh, u, du, n / 4);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dh, u, du, n / 4, dr, site);
   return stlt_check_launch("gelu_bwd_kernel");
 }
 
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
-                    int64_t dh, float* dqkv, hipStream_t s) {
+                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr, uint32_t site) {
   if (!qkv || !dctx || !kpm || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
   if (dh != AB_DH) return stlt_set_error(STLT_EINVAL, "attn_bwd: head dim must be 64");
   if (L <= 0 || L > AB_MAXL)
@@ -411,7 +435,7 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
   const int64_t groups = (S + P - 1) / P;
   if (groups * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "attn_bwd: too many groups");
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(groups * H)), dim3(256), 0, s, qkv, dctx, kpm, causal, S * L, (int)L, (int)H,
-                     GL, 1.0f / sqrtf((float)dh), dqkv);
+                     GL, 1.0f / sqrtf((float)dh), dqkv, dr, site);
   return stlt_check_launch("attn_bwd_kernel");
 }
 

@@ -35,11 +35,36 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// Counter-based dropout: keep element `idx` of site `site` iff splitmix64(seed, site, idx) >= thr (thr = p * 2^32).
+// No mask is stored: the backward recomputes it.  Sites per encoder layer g (0.. spatial, then temporal):
+// 8g+0 attention probabilities, 8g+1 after out-proj, 8g+2 FFN hidden, 8g+3 after linear2; 0xE0 / 0xE1 = embedding outputs.
+struct StltDrop { uint32_t thr; float scale; uint64_t seed; };  // thr == 0: dropout off
+__device__ __forceinline__ bool stlt_keep(const StltDrop& dr, uint32_t site, uint64_t idx) {
+  uint64_t z = idx + dr.seed * 0x9E3779B97F4A7C15ull + (uint64_t)site * 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32) >= dr.thr;
+}
+__device__ __forceinline__ f32x4 stlt_drop4(const StltDrop& dr, uint32_t site, uint64_t idx0, f32x4 v) {
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = stlt_keep(dr, site, idx0 + k) ? v[k] * dr.scale : 0.f;
+  return o;
+}
+inline StltDrop stlt_drop_make(float p, uint64_t seed) {
+  StltDrop d{0u, 1.0f, seed};
+  if (p > 0.f) { double t = (double)p * 4294967296.0; d.thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t; d.scale = 1.0f / (1.0f - p); }
+  return d;
+}
+#define STLT_SITE_EMBED 0xE0u
+#define STLT_SITE_FRAMES 0xE1u
+
 // internal launchers shared between the per-kernel C-ABI and the whole-path entry points
 int launch_embed(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
                  int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
                  const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
-                 float* out, hipStream_t s, float* pre_out = nullptr);
+                 float* out, hipStream_t s, float* pre_out = nullptr, StltDrop dr = StltDrop{0u, 1.0f, 0ull});
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, int act, hipStream_t s);
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -47,12 +72,13 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
                 int64_t K, int n_split, int act, hipStream_t s);
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
-                float* ctx, int kid, hipStream_t s);
+                float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* w, const float* b,
-                         float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s);
+                         float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
+                         uint32_t site = 0);
 int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
                         const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
-                        int64_t d, float* out, hipStream_t s, float* pre_out = nullptr);
+                        int64_t d, float* out, hipStream_t s, float* pre_out = nullptr, StltDrop dr = StltDrop{0u, 1.0f, 0ull});
 int launch_gather_last(const float* x, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* out,
                        hipStream_t s);
 
@@ -60,12 +86,14 @@ int launch_gather_last(const float* x, const int64_t* lengths, int64_t B, int64_
 int64_t ln_bwd_scratch_floats(int64_t d);
 int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
                   float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
-                  hipStream_t s);
+                  hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site_b2 = 0, float* ds_drop = nullptr,
+                  uint32_t site_dy = 0);
 int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g, float* scratch, hipStream_t s);
-int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s);
-int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s);
+int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
+int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
+                    uint32_t site = 0);
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
-                    int64_t dh, float* dqkv, hipStream_t s);
+                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d);
 int launch_embed_bwd(const float* dx, const int64_t* categories, const float* boxes, const float* scores, int64_t C,
                      int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,

@@ -11,7 +11,8 @@ constexpr int ROWS_PER_BLOCK = 4;  // 4 waves / 256 threads
 
 template <int NV>
 __device__ __forceinline__ void ln_store(f32x4 (&v)[NV], int lane, int d, const float* __restrict__ w,
-                                         const float* __restrict__ b, float eps, float* __restrict__ out) {
+                                         const float* __restrict__ b, float eps, float* __restrict__ out,
+                                         const StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0, uint64_t row_idx0 = 0) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -37,7 +38,9 @@ __device__ __forceinline__ void ln_store(f32x4 (&v)[NV], int lane, int d, const 
     if (e < d) {
       f32x4 ww = *reinterpret_cast<const f32x4*>(w + e);
       f32x4 bb = *reinterpret_cast<const f32x4*>(b + e);
-      *reinterpret_cast<f32x4*>(out + e) = v[i] * rstd * ww + bb;
+      f32x4 o = v[i] * rstd * ww + bb;
+      if (dr.thr) o = stlt_drop4(dr, site, row_idx0 + e, o);  // train-mode dropout on the LayerNorm output
+      *reinterpret_cast<f32x4*>(out + e) = o;
     }
   }
 }
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
                                                     const float* __restrict__ score_w,
                                                     const float* __restrict__ score_b, const float* __restrict__ ln_w,
                                                     const float* __restrict__ ln_b, float eps, int64_t n_tokens, int d,
-                                                    float* __restrict__ out, float* __restrict__ pre_out) {
+                                                    float* __restrict__ out, float* __restrict__ pre_out, StltDrop dr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= n_tokens) return;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  ln_store<NV>(v, lane, d, ln_w, ln_b, eps, out + row * d);
+  ln_store<NV>(v, lane, d, ln_w, ln_b, eps, out + row * d, dr, STLT_SITE_EMBED, (uint64_t)row * d);
 }
 
 // ---------------------------------------------------------------- residual + LN
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ x
                                                      const float* __restrict__ res, int64_t ldres,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float eps, int64_t M, int d, float* __restrict__ out,
-                                                     int64_t ldout) {
+                                                     int64_t ldout, StltDrop dr, uint32_t site) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ x
     int e = (i * 64 + lane) * 4;
     if (e < d) {
       v[i] = *reinterpret_cast<const f32x4*>(x + row * ldx + e);
+      if (dr.thr) v[i] = stlt_drop4(dr, site, (uint64_t)row * d + e, v[i]);  // dropout1 / dropout2 of the encoder layer (before the residual)
       if (res) v[i] += *reinterpret_cast<const f32x4*>(res + row * ldres + e);
     } else {
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void frames_embed_kernel(const float* __restri
                                                            const float* __restrict__ type_table,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            float eps, int64_t BT, int T, int d,
-                                                           float* __restrict__ out, float* __restrict__ pre_out) {
+                                                           float* __restrict__ out, float* __restrict__ pre_out, StltDrop dr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= BT) return;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void frames_embed_kernel(const float* __restri
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  ln_store<NV>(v, lane, d, w, b, eps, out + row * d);
+  ln_store<NV>(v, lane, d, w, b, eps, out + row * d, dr, STLT_SITE_FRAMES, (uint64_t)row * d);
 }
 
 // ---------------------------------------------------------------- K8a
@@ -179,7 +183,7 @@ inline int check_d(int64_t d) {
 int launch_embed(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
                  int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
                  const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
-                 float* out, hipStream_t s, float* pre_out) {
+                 float* out, hipStream_t s, float* pre_out, StltDrop dr) {
   if (int e = check_d(d)) return e;
   if (!categories || !boxes || !cat_table || !box_w || !box_b || !ln_w || !ln_b || !out || n_categories <= 0)
     return stlt_set_error(STLT_EINVAL, "stlt_embed_fwd: null pointer / empty table");
@@ -189,12 +193,12 @@ int launch_embed(const int64_t* categories, const float* boxes, const float* sco
   dim3 grid((unsigned)((n_tokens + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((embed_kernel<NV>), grid, dim3(256), 0, s, categories, boxes, scores,
                                             cat_table, (int)n_categories, box_w, box_b, score_w, score_b, ln_w, ln_b,
-                                            eps, n_tokens, (int)d, out, pre_out));
+                                            eps, n_tokens, (int)d, out, pre_out, dr));
   return stlt_check_launch("embed_kernel");
 }
 
 int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* w, const float* b,
-                         float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s) {
+                         float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s, StltDrop dr, uint32_t site) {
   if (int e = check_d(d)) return e;
   if (!x || !w || !b || !out) return stlt_set_error(STLT_EINVAL, "stlt_add_layernorm_fwd: null pointer");
   if (ldx % 4 || ldout % 4 || (res && ldres % 4)) return stlt_set_error(STLT_EINVAL, "stlt_add_layernorm_fwd: leading dims must be multiples of 4");
@@ -202,13 +206,13 @@ int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
   StltProfScope ps(STLT_K_ADDLN, s);
   dim3 grid((unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((add_ln_kernel<NV>), grid, dim3(256), 0, s, x, ldx, res, ldres, w, b, eps,
-                                            M, (int)d, out, ldout));
+                                            M, (int)d, out, ldout, dr, site));
   return stlt_check_launch("add_ln_kernel");
 }
 
 int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
                         const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
-                        int64_t d, float* out, hipStream_t s, float* pre_out) {
+                        int64_t d, float* out, hipStream_t s, float* pre_out, StltDrop dr) {
   if (int e = check_d(d)) return e;
   if (!spatial || !frame_types || !pos_table || !type_table || !ln_w || !ln_b || !out)
     return stlt_set_error(STLT_EINVAL, "stlt_frames_embed_fwd: null pointer");
@@ -218,7 +222,7 @@ int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t*
   dim3 grid((unsigned)((B * T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((frames_embed_kernel<NV>), grid, dim3(256), 0, s, spatial, row_stride,
                                             frame_types, pos_table, type_table, ln_w, ln_b, eps, B * T, (int)T, (int)d,
-                                            out, pre_out));
+                                            out, pre_out, dr));
   return stlt_check_launch("frames_embed_kernel");
 }
 

@@ -54,8 +54,8 @@ static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, 
 // backward scratch: gradient buffers for the spatial phase (tok rows) and, separately, the temporal phase (BT
 // rows) so that each one's row padding stays zero; split-K slabs; reduction scratch.
 struct Scratch {
-  float *sA, *sB, *sC, *sQKV, *sH;  // spatial: (tokp,d) x3, (tokp,3d), (tokp,4d)
-  float *tA, *tB, *tC, *tQKV, *tH;  // temporal
+  float *sA, *sB, *sC, *sD, *sQKV, *sH;  // spatial: (tokp,d) x4, (tokp,3d), (tokp,4d)
+  float *tA, *tB, *tC, *tD, *tQKV, *tH;  // temporal
   float *hA, *hB;                   // head: (bp,d) x2
   float* slabs;
   float* red;
@@ -69,8 +69,8 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   const int64_t tokp = up32(B * T * N), btp = up32(B * T), bp = up32(B);
   size_t off = 0;
   auto take = [&](int64_t floats) { float* p = (float*)(base + off); off = align256(off + (size_t)floats * sizeof(float)); return p; };
-  s.sA = take(tokp * d); s.sB = take(tokp * d); s.sC = take(tokp * d); s.sQKV = take(tokp * 3 * d); s.sH = take(tokp * 4 * d);
-  s.tA = take(btp * d); s.tB = take(btp * d); s.tC = take(btp * d); s.tQKV = take(btp * 3 * d); s.tH = take(btp * 4 * d);
+  s.sA = take(tokp * d); s.sB = take(tokp * d); s.sC = take(tokp * d); s.sD = take(tokp * d); s.sQKV = take(tokp * 3 * d); s.sH = take(tokp * 4 * d);
+  s.tA = take(btp * d); s.tB = take(btp * d); s.tC = take(btp * d); s.tD = take(btp * d); s.tQKV = take(btp * 3 * d); s.tH = take(btp * 4 * d);
   s.hA = take(bp * d); s.hB = take(bp * d);
   s.slab_floats = (size_t)MAX_SPLIT * 4 * d * d;
   s.slabs = take((int64_t)s.slab_floats);
@@ -112,33 +112,37 @@ static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k
 }
 
 // backward of one encoder layer.  dy: gradient wrt the layer output (M,d) in bufA; on return bufA holds the gradient
-// wrt the layer input.  bufB / bufC (M,d), bufQ (M,3d), bufH (M,4d) are scratch with zero row padding.
+// wrt the layer input.  bufB / bufC / bufD (M,d), bufQ (M,3d), bufH (M,4d) are scratch with zero row padding.
+// With dropout on, bufD receives the gradient wrt the un-dropped branch output (ds * mask / (1-p)) while bufB keeps
+// the residual-path gradient.
 static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
                           int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, float* bufA, float* bufB,
-                          float* bufC, float* bufQ, float* bufH, const Scratch& sc, hipStream_t s) {
+                          float* bufC, float* bufD, float* bufQ, float* bufH, const Scratch& sc, StltDrop dr, uint32_t site0,
+                          hipStream_t s) {
   auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
-  // y = LN2(x1 + f)
+  float* br = dr.thr ? bufD : bufB;  // branch gradient (after the dropout mask)
+  // y = LN2(x1 + drop(f))
   TRY(launch_ln_bwd(bufA, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm2_w),
-                    G(&stlt_layer_params::norm2_b), sc.red, s));                                   // bufB = ds2
+                    G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD));              // bufB = ds2, br = df
   // f = h·W2ᵀ + b2
-  TRY(weight_grad(bufB, d, t.h, 4 * d, Mp, G(&stlt_layer_params::lin2_w), sc, s));
-  if (float* gb = G(&stlt_layer_params::lin2_b)) TRY(launch_colsum_acc(bufB, d, M, d, gb, sc.red, s));
-  TRY(launch_gemm(0, 1, bufB, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, M, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
-  // h = gelu(u)
-  TRY(launch_gelu_bwd(bufH, t.u, bufH, M * 4 * d, s));                                            // bufH = du
+  TRY(weight_grad(br, d, t.h, 4 * d, Mp, G(&stlt_layer_params::lin2_w), sc, s));
+  if (float* gb = G(&stlt_layer_params::lin2_b)) TRY(launch_colsum_acc(br, d, M, d, gb, sc.red, s));
+  TRY(launch_gemm(0, 1, br, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, M, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
+  // h = drop(gelu(u))
+  TRY(launch_gelu_bwd(bufH, t.u, bufH, M * 4 * d, s, dr, site0 + 2));                             // bufH = du
   // u = x1·W1ᵀ + b1
   TRY(weight_grad(bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w), sc, s));
   if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_colsum_acc(bufH, 4 * d, M, 4 * d, gb, sc.red, s));
   TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, M, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
-  // x1 = LN1(x + a)
+  // x1 = LN1(x + drop(a))
   TRY(launch_ln_bwd(bufC, d, t.x, d, t.a, d, lp.norm1_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm1_w),
-                    G(&stlt_layer_params::norm1_b), sc.red, s));                                   // bufB = ds1
+                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufD));              // bufB = ds1, br = da
   // a = ctx·Woᵀ + bo
-  TRY(weight_grad(bufB, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w), sc, s));
-  if (float* gb = G(&stlt_layer_params::out_proj_b)) TRY(launch_colsum_acc(bufB, d, M, d, gb, sc.red, s));
-  TRY(launch_gemm(0, 1, bufB, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
-  // ctx = attention(qkv)
-  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s));                        // bufQ = dqkv
+  TRY(weight_grad(br, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w), sc, s));
+  if (float* gb = G(&stlt_layer_params::out_proj_b)) TRY(launch_colsum_acc(br, d, M, d, gb, sc.red, s));
+  TRY(launch_gemm(0, 1, br, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
+  // ctx = attention(qkv) with dropout on the probabilities
+  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0));             // bufQ = dqkv
   // qkv = x·Winᵀ + bin
   TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
   if (float* gb = G(&stlt_layer_params::in_proj_b)) TRY(launch_colsum_acc(bufQ, 3 * d, M, 3 * d, gb, sc.red, s));
@@ -147,15 +151,15 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
 }
 
 static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
-                         const uint8_t* kpm, int causal, int kid, float* y, hipStream_t s) {
+                         const uint8_t* kpm, int causal, int kid, float* y, StltDrop dr, uint32_t site0, hipStream_t s) {
   TRY(launch_linear(t.x, d, lp.in_proj_w, lp.in_proj_b, t.qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
-  TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s));
+  TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s, dr, site0));
   TRY(launch_linear(t.ctx, d, lp.out_proj_w, lp.out_proj_b, t.a, d, M, d, d, STLT_ACT_NONE, s));
-  TRY(launch_add_layernorm(t.a, d, t.x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, t.x1, d, s));
+  TRY(launch_add_layernorm(t.a, d, t.x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, t.x1, d, s, dr, site0 + 1));
   TRY(launch_linear(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, 4 * d, M, 4 * d, d, STLT_ACT_NONE, s));
-  TRY(launch_gelu_fwd(t.u, t.h, M * 4 * d, s));
+  TRY(launch_gelu_fwd(t.u, t.h, M * 4 * d, s, dr, site0 + 2));
   TRY(launch_linear(t.h, 4 * d, lp.lin2_w, lp.lin2_b, t.f, d, M, d, 4 * d, STLT_ACT_NONE, s));
-  TRY(launch_add_layernorm(t.f, d, t.x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, M, d, y, d, s));
+  TRY(launch_add_layernorm(t.f, d, t.x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, M, d, y, d, s, dr, site0 + 3));
   return 0;
 }
 
@@ -185,7 +189,7 @@ size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int6
 }
 
 int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_mem, size_t tape_bytes, float* logits,
-                       stlt_stream_t stream) {
+                       float dropout_p, uint64_t dropout_seed, stlt_stream_t stream) {
   TRY(check_train(p, in));
   if (!logits || !tape_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_forward: null logits/tape");
   hipStream_t s = (hipStream_t)stream;
@@ -193,19 +197,22 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
   const Tape t = tape_layout((char*)tape_mem, B, T, N, d, p->n_spatial, p->n_temporal);
   if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
   const int64_t tok = B * T * N, BT = B * T;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
+  const StltDrop dr = stlt_drop_make(dropout_p, dropout_seed);
   float* x0 = p->n_spatial > 0 ? t.sp[0].x : t.sp_out;
   TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
-                   p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x0, s, t.s_embed));
+                   p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x0, s, t.s_embed, dr));
   for (int64_t l = 0; l < p->n_spatial; ++l) {
     float* y = l + 1 < p->n_spatial ? t.sp[l + 1].x : t.sp_out;
-    TRY(layer_forward(p->spatial[l], d, H, t.sp[l], tok, BT, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, y, s));
+    TRY(layer_forward(p->spatial[l], d, H, t.sp[l], tok, BT, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, y, dr, (uint32_t)(8 * (l + 1)), s));
   }
   float* g0 = p->n_temporal > 0 ? t.tp[0].x : t.tp_out;
   TRY(launch_frames_embed(t.sp_out, N * d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b,
-                          p->ln_eps, B, T, d, g0, s, t.s_frames));
+                          p->ln_eps, B, T, d, g0, s, t.s_frames, dr));
   for (int64_t l = 0; l < p->n_temporal; ++l) {
     float* y = l + 1 < p->n_temporal ? t.tp[l + 1].x : t.tp_out;
-    TRY(layer_forward(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, y, s));
+    TRY(layer_forward(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, y, dr,
+                      (uint32_t)(8 * (p->n_spatial + l + 1)), s));
   }
   TRY(launch_gather_last(t.tp_out, in->lengths, B, T, d, t.h0, s));
   TRY(launch_linear(t.h0, d, p->fc1_w, p->fc1_b, t.u0, d, B, d, d, STLT_ACT_NONE, s));
@@ -217,7 +224,7 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
 
 int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_inputs* in, const void* tape_mem,
                         size_t tape_bytes, void* scratch_mem, size_t scratch_bytes, const float* dlogits,
-                        stlt_stream_t stream) {
+                        float dropout_p, uint64_t dropout_seed, stlt_stream_t stream) {
   TRY(check_train(p, in));
   if (!g || !dlogits || !tape_mem || !scratch_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: null argument");
   hipStream_t s = (hipStream_t)stream;
@@ -227,6 +234,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   const Scratch sc = scratch_layout((char*)scratch_mem, B, T, N, d, p->n_categories);
   if (scratch_bytes < sc.bytes) return stlt_set_error(STLT_EWORKSPACE, "scratch %zu B < required %zu B", scratch_bytes, sc.bytes);
   const int64_t tok = B * T * N, BT = B * T;
+  const StltDrop dr = stlt_drop_make(dropout_p, dropout_seed);
   auto W = [](const float* q) { return const_cast<float*>(q); };
 
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
@@ -244,18 +252,18 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // ---- temporal transformer
   for (int64_t l = p->n_temporal - 1; l >= 0; --l)
     TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, t.btp, B, T, in->kpm_frames, 1,
-                       sc.tA, sc.tB, sc.tC, sc.tQKV, sc.tH, sc, s));
+                       sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s));
   // ---- frames embeddings (models.py:98-111)
   TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, sc.tB, d, W(g->frames_ln_w),
-                    W(g->frames_ln_b), sc.red, s));
+                    W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));
   TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, sc.sA, W(g->pos_emb), W(g->type_emb), s));   // sA = d(spatial out), CLS rows only
   // ---- spatial transformer
   for (int64_t l = p->n_spatial - 1; l >= 0; --l)
     TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, t.tokp, BT, N, in->kpm_boxes, 0,
-                       sc.sA, sc.sB, sc.sC, sc.sQKV, sc.sH, sc, s));
+                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s));
   // ---- category / box / score embeddings (models.py:29-39)
   TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sB, d, W(g->emb_ln_w), W(g->emb_ln_b),
-                    sc.red, s));
+                    sc.red, s, dr, 0, nullptr, STLT_SITE_EMBED));
   TRY(launch_embed_bwd(sc.sB, in->categories, in->boxes, in->scores, p->n_categories, tok, d, W(g->cat_emb), W(g->box_w),
                        W(g->box_b), W(g->score_w), W(g->score_b), sc.red, s));
   return 0;

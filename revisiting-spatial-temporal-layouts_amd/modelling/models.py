@@ -266,10 +266,10 @@ class StltBackbone(nn.Module):
         return ((L.FLAG_CLS_ONLY_LAST_SPATIAL if self.cls_only_last_spatial else 0)
                 | (L.FLAG_LAST_ROW_ONLY_TEMPORAL if self.last_row_only_temporal else 0))
 
-    def _check_mode(self):
-        if self.training and self.config.hidden_dropout_prob > 0:
-            raise L.StltHipError("train-mode dropout is not implemented in the HIP path yet: build the model with "
-                                 "hidden_dropout_prob=0 or call model.train(False)")
+    def _check_mode(self, grad_path: bool = False):
+        if self.training and self.config.hidden_dropout_prob > 0 and not grad_path:
+            raise L.StltHipError("train-mode dropout runs only in the autograd (training) path: call model.train(False) "
+                                 "for inference, or enable grad")
 
     def forward_batch_major(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """HIP forward, batch-major (B,T,d) result (the layout the kernels compute in)."""
@@ -326,8 +326,9 @@ class Stlt(nn.Module):
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         bb = self.backbone
-        bb._check_mode()
-        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+        grad_path = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
+        bb._check_mode(grad_path)
+        if grad_path:
             params = tuple(self.parameters())
             logits = _StltTrainFn.apply(self, batch, *params)
             return {k: v for k, v in zip(self.logit_names, (logits,))}
@@ -362,10 +363,15 @@ class _StltTrainFn(torch.autograd.Function):
         n_sp, n_tp = p.n_spatial, p.n_temporal
         tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, n_sp, n_tp)), device)
         logits = torch.empty(B, K, device=device, dtype=torch.float32)
+        # train-mode dropout (reference default hidden_dropout_prob = 0.1): counter-based masks from one seed per
+        # forward, drawn from torch's CPU generator (so torch.manual_seed makes runs repeatable)
+        drop_p = float(cfg.hidden_dropout_prob) if bb.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0
+        seed = getattr(model, "_dropout_seed_override", None) or seed
         with torch.cuda.device(device):
             L.check(lib.stlt_train_forward(C.byref(p), C.byref(inp), tape.data_ptr(), tape.numel(), logits.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream), "stlt_train_forward")
-        ctx.model, ctx.batch, ctx.shape, ctx.params = model, batch, (B, T, N, d), params
+                                           drop_p, seed, torch.cuda.current_stream().cuda_stream), "stlt_train_forward")
+        ctx.model, ctx.batch, ctx.shape, ctx.params, ctx.drop = model, batch, (B, T, N, d), params, (drop_p, seed)
         return logits
 
     @staticmethod
@@ -390,7 +396,7 @@ class _StltTrainFn(torch.autograd.Function):
         dl = dlogits.contiguous().float()
         with torch.cuda.device(device):
             L.check(lib.stlt_train_backward(C.byref(p), C.byref(g), C.byref(inp), tape.data_ptr(), tape.numel(),
-                                            scratch.data_ptr(), scratch.numel(), dl.data_ptr(),
+                                            scratch.data_ptr(), scratch.numel(), dl.data_ptr(), ctx.drop[0], ctx.drop[1],
                                             torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
         model._last_flat_grad = flat  # one contiguous buffer: what a data-parallel wrapper all-reduces
         return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)

@@ -160,12 +160,12 @@ def test_state_dict_roundtrip_and_train_flag(pkg):
         assert torch.equal(sd[k], sd2[k])
     # backbone-only dict (train.py:152 / models.py:130-134): 168 keys
     assert len(m.backbone.state_dict()) == 168
-    # p=0 -> train mode runs the same math; p>0 in train mode is refused, not silently wrong
+    # p=0 -> train mode runs the same math; p>0 in train mode WITHOUT grad (no training path) is refused, not silently wrong
     m.train(True)
     with torch.no_grad():
         a = m(_to(batch))["stlt"]
     m.backbone.config.hidden_dropout_prob = 0.1
-    with pytest.raises(pkg.StltHipError):
+    with pytest.raises(pkg.StltHipError), torch.no_grad():
         m(_to(batch))
     m.train(False)
     with torch.no_grad():

@@ -126,3 +126,43 @@ def test_three_training_steps_match_reference_golden(pkg):
             got = params[k].detach().reshape(-1)[:64].cpu().numpy()
             assert np.abs(got - z[f"p{s}_{i}"]).max() <= 2.5e-5, (s, k)  # < lr/2 (Adam amplifies last-bit gradient noise)
     assert sum(1 for p in m.parameters() if p.grad is None) == int(z["n_grad_none"][0])  # 14 dead / unused parameters
+
+
+@pytest.mark.parametrize("name,B,p", [("cfg1", 3, 0.1), ("cfg1", 2, 0.5)])
+def test_dropout_forward_and_gradients_match_masked_oracle(pkg, name, B, p):
+    """hidden_dropout_prob > 0 in train mode: the six dropout sites of the reference (both embedding outputs, attention
+    probabilities, dropout1, FFN dropout, dropout2) with the build's counter-based masks, against the oracle applying
+    the same masks under torch autograd."""
+    c = pkg.synth.CONFIGS[name]
+    H = c["num_attention_heads"]
+    kw = dict(pkg.synth.model_kwargs(name), hidden_dropout_prob=p)
+    m = pkg.Stlt(pkg.StltModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=41, gain=1.5)
+    m.load_state_dict(sd)
+    m.train(True).to(DEV)
+    seed = 123456789
+    m._dropout_seed_override = seed
+    batch = pkg.synth.make_batch(B, c["T"], c["N"], seed=9)
+    labels = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(1))
+    drop = O.Dropout(p, seed)
+    leaves = {k: (v.detach().double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    ref_logits = O.stlt_forward(leaves, b64, H, dtype=torch.float64, drop=drop)["stlt"]
+    F.cross_entropy(ref_logits, labels).backward()
+
+    out = m({k: v.to(DEV) for k, v in batch.items()})["stlt"]
+    assert (out.detach().cpu().double() - ref_logits.detach()).abs().max().item() <= 2e-4
+    F.cross_entropy(out, labels.to(DEV)).backward()
+    for k, prm in m.named_parameters():
+        if "encoder_layer." in k or "score_embeddings" in k:
+            continue
+        g_ref = leaves[k].grad
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        assert (prm.grad.cpu().double() - g_ref).abs().max().item() / scale <= 5e-4, k
+    # dropout really is on: a different seed changes the logits, eval mode ignores it, and the rate is right
+    m._dropout_seed_override = seed + 1
+    with torch.enable_grad():
+        other = m({k: v.to(DEV) for k, v in batch.items()})["stlt"]
+    assert (other - out).abs().max().item() > 1e-3
+    keep = O.dropout_keep(p, seed, 17, np.arange(200000, dtype=np.uint64))
+    assert abs(1.0 - keep.mean() - p) < 0.01
