@@ -34,6 +34,10 @@
 
 namespace {
 
+#ifndef STLT_GEMM_PRIO_MODE
+#define STLT_GEMM_PRIO_MODE 0  // 0 off (measured best: 134.4 TF); 1 static priority for waves 4-7 (134); 2 SIMD partners alternate priority per half k-step (133.7)
+#endif
+
 constexpr int BM = 256, BN = 128, BK = 32;
 constexpr int GEMM_WAVES = 8;
 constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
@@ -52,6 +56,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
                                                                   int64_t slab_stride, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, int n_split,
                                                                   unsigned long long* __restrict__ dbg) {
+  constexpr int prio = STLT_GEMM_PRIO_MODE;
   __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + 2 * BN];  // operand stages + 2 bias strips
 
   const int tid = threadIdx.x;
@@ -255,7 +260,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
 #define GSTAMP(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); t_acc[k] += t_now - t_prev; t_prev = t_now; __builtin_amdgcn_sched_barrier(0); } } while (0)
   if (STAMP) { t_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+  if (prio == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // static: the second-dispatched half wins arbitration
   for (int step = 0; step < total_steps; ++step) {
+    if (prio == 2) { if (wave < 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     const int next_stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     const bool prefetch = step + 2 < total_steps;  // step+2's operands go to the stage retired by the previous barrier
     const bool bias_step = c_kt == nk - 1 && c_it + 1 < my_tiles;
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     if (prefetch) dma_part(0);
     fa = read_frags(stage, 2);
     mfma_chunk(fb);
+    if (prio == 2) { if (wave < 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
     if (prefetch) dma_part(1);
     fb = read_frags(stage, 3);
     mfma_chunk(fa);
