@@ -93,6 +93,17 @@ int stlt_frames_embed_fwd(const float* spatial, int64_t row_stride, const int64_
 int stlt_gather_last_fwd(const float* x, const int64_t* lengths, int64_t B, int64_t T, int64_t d,
                          float* out, stlt_stream_t stream);
 
+/* Collater on the device — padding + mask half of StltCollater.__call__, src/modelling/datasets.py:243-288 (pad_sequence:
+ * src/utils/data_utils.py:93-102).  Inputs are the per-video tensors of StltDataset.__getitem__ (datasets.py:52-125)
+ * concatenated along the frame axis: video b owns frames [frame_offsets[b], frame_offsets[b+1]); outputs are the padded
+ * (B,T,N,.) batch and both key-padding masks (uint8, 1 = padded).  Frames past a video's length carry the CLS object in
+ * slot 0 (category cls_id, box [0,0,1,1], score 1) and frame type 0.  scores_ragged/scores are NULL together
+ * (datasets.py:253-260 keeps scores only for action_genome). */
+int stlt_collate_fwd(const int64_t* categories_ragged, const float* boxes_ragged, const float* scores_ragged,
+                     const int64_t* frame_types_ragged, const int64_t* frame_offsets, int64_t B, int64_t T, int64_t N,
+                     int64_t cls_id, int64_t* categories, float* boxes, float* scores, int64_t* frame_types,
+                     uint8_t* kpm_boxes, uint8_t* kpm_frames, stlt_stream_t stream);
+
 /* ---- whole-path entry points (host-side orchestration in native code) ---- */
 
 typedef struct {

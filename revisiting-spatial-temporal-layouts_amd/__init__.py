@@ -3,7 +3,7 @@
 The directory name carries a hyphen, so import it with
 ``importlib.import_module("revisiting-spatial-temporal-layouts_amd")``.
 """
-from . import _lib, dist, infer, ops, synth, train  # noqa: F401
+from . import _lib, collate, dist, infer, ops, synth, train  # noqa: F401
 from ._lib import StltHipError  # noqa: F401
 from .modelling.configs import StltModelConfig, model_configs_factory  # noqa: F401
 from .modelling.models import (  # noqa: F401

@@ -58,6 +58,8 @@ SIGNATURES = {
     "stlt_frames_embed_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64,
                                         C.c_int64, _vp, _vp]),
     "stlt_gather_last_fwd": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
+    "stlt_collate_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp]),
     "stlt_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "stlt_backbone_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp]),
     "stlt_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),

@@ -163,6 +163,20 @@ def make_batch(
     return batch
 
 
+def make_video_samples(dataset: str, n_videos: int, N: int, seed: int):
+    """Seeded per-video dicts shaped like ``StltDataset.__getitem__`` output (reference datasets.py:52-125): variable
+    frame counts, fixed N object slots, last frame = extract.  Input of the collater (device or reference)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for i in range(n_videos):
+        n_frames = int(rng.integers(2, 9))
+        b = make_batch(1, n_frames, N, dataset=dataset, seed=seed * 100 + i, with_scores=True, min_len=n_frames)
+        label = torch.tensor(int(rng.integers(0, 174))) if dataset == "something" else torch.from_numpy(rng.random(157).astype(np.float32))
+        out.append({"video_id": f"vid{i}", "categories": b["categories"][0], "boxes": b["boxes"][0], "scores": b["scores"][0],
+                    "frame_types": b["frame_types"][0], "lengths": torch.tensor(n_frames), "labels": label})
+    return out
+
+
 # Named shape configurations (BASELINE.json "configs"; SURVEY.md §8d)
 CONFIGS = {
     "micro": dict(T=5, N=3, hidden_size=32, num_attention_heads=4, num_spatial_layers=1, num_temporal_layers=1,
