@@ -32,6 +32,7 @@ extern "C" {
 
 #define STLT_ACT_NONE 0
 #define STLT_ACT_GELU 1  /* exact erf GELU */
+#define STLT_ACT_RELU 2  /* nn.TransformerEncoderLayer default activation (appearance branch, models.py:239-246) */
 
 typedef void* stlt_stream_t; /* hipStream_t */
 
@@ -75,6 +76,13 @@ int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* ds
  * Rows whose keys are all masked produce zeros.  dh == 64. */
 int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal,
                        int64_t S, int64_t L, int64_t H, int64_t dh, float* ctx, stlt_stream_t stream);
+
+/* Cross-attention core (CrossAttentionLayer of CAF/CACNF, models.py:362-382; also self-attention on unpacked buffers):
+ * queries q (S*Lq rows, stride ldq floats) attend to keys k / values v (S*Lk rows, stride ldkv).  kpm: (S*Lk) bytes over
+ * the KEY tokens (pass zeros for no padding mask).  ctx: (S*Lq, H*dh).  causal requires Lq == Lk. */
+int stlt_attn_cross_fwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm,
+                        int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx,
+                        stlt_stream_t stream);
 
 /* Residual + LayerNorm (norm1/norm2 of nn.TransformerEncoderLayer, eps 1e-5; ClassificationHead.layer_norm
  * models.py:159,163 with res == NULL).  out[m,:] = LN_eps( x[m*ldx + :] + res[m*ldres + :] ). */

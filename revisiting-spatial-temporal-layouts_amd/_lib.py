@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("STLT_HIP_LIB") or os.path.join(HERE, "libstlt_hip.so"
 K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "frames_embed", "gather_last")
 FLAG_CLS_ONLY_LAST_SPATIAL = 1
 FLAG_LAST_ROW_ONLY_TEMPORAL = 2
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _f = C.POINTER(C.c_float)
 _i64 = C.POINTER(C.c_int64)
@@ -53,6 +53,8 @@ SIGNATURES = {
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
     "stlt_reduce_slabs": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int, _vp]),
     "stlt_attn_core_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
+    "stlt_attn_cross_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                      C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_add_layernorm_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_float, C.c_int64, C.c_int64,
                                          _vp, C.c_int64, _vp]),
     "stlt_frames_embed_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64,

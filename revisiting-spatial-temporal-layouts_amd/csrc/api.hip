@@ -118,6 +118,12 @@ int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal, int64_t
                      (hipStream_t)stream);
 }
 
+int stlt_attn_cross_fwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm, int causal,
+                        int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx, stlt_stream_t stream) {
+  return launch_attn_general(q, ldq, k, v, ldkv, kpm, causal, S, Lq, Lk, H, dh, ctx,
+                             causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL, (hipStream_t)stream);
+}
+
 int stlt_add_layernorm_fwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* ln_w,
                            const float* ln_b, float eps, int64_t M, int64_t d, float* out, int64_t ldout,
                            stlt_stream_t stream) {

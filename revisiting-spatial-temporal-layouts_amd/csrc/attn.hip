@@ -66,34 +66,48 @@ constexpr int WAVE_LDS_FLOATS = 2 * TILE_FLOATS + TILE;    // two V buffers + ke
 // waves of a workgroup read adjacent 256-B head slices of the same rows.
 struct StepGeo {
   int head, qb, q_first, q_rows, k_first, k_rows, kt_end;
-  int64_t tok0;
+  int64_t q_tok0, k_tok0;
 };
 
-__device__ __forceinline__ StepGeo step_geo(int64_t item, int kt, int64_t n_tokens, int L, int H, int GL, int nt,
-                                            int causal) {
+// Problem geometry.  Self-attention on a packed (tokens, 3d) buffer is q = qkv, k = qkv + d, v = qkv + 2d,
+// ldq = ldkv = 3d, Lq = Lk.  Cross-attention (CAF, reference models.py:362-382) has its own key/value token space.
+struct AttnGeo {
+  const float* q; const float* k; const float* v;
+  int64_t ldq, ldkv;             // row strides in floats
+  int64_t nq_tokens, nk_tokens;  // S*Lq, S*Lk
+  int Lq, Lk, GLq, GLk, ntq, ntk, H, causal;
+};
+
+__device__ __forceinline__ StepGeo step_geo(int64_t item, int kt, const AttnGeo& a) {
   StepGeo s;
-  s.head = (int)(item % H);
-  const int64_t tile_id = item / H;
-  const int64_t g = tile_id / nt;
-  s.qb = (int)(tile_id % nt);
-  s.tok0 = g * GL;
-  const int gvalid = (int)((n_tokens - s.tok0) < GL ? (n_tokens - s.tok0) : GL);
+  s.head = (int)(item % a.H);
+  const int64_t tile_id = item / a.H;
+  const int64_t g = tile_id / a.ntq;
+  s.qb = (int)(tile_id % a.ntq);
+  s.q_tok0 = g * a.GLq;
+  s.k_tok0 = g * a.GLk;
+  const int gq = (int)((a.nq_tokens - s.q_tok0) < a.GLq ? (a.nq_tokens - s.q_tok0) : a.GLq);
+  const int gk = (int)((a.nk_tokens - s.k_tok0) < a.GLk ? (a.nk_tokens - s.k_tok0) : a.GLk);
   s.q_first = s.qb * TILE;
-  s.q_rows = gvalid - s.q_first < TILE ? gvalid - s.q_first : TILE;
+  s.q_rows = gq - s.q_first < TILE ? gq - s.q_first : TILE;
   s.k_first = kt * TILE;
-  s.k_rows = gvalid - s.k_first < TILE ? gvalid - s.k_first : TILE;
-  s.kt_end = (causal && GL == L) ? s.qb + 1 : nt;  // causal: key tiles past the query tile are fully masked
+  s.k_rows = gk - s.k_first < TILE ? gk - s.k_first : TILE;
+  s.kt_end = (a.causal && a.GLq == a.Lq) ? s.qb + 1 : a.ntk;  // causal: key tiles past the query tile are fully masked
   return s;
 }
 
 template <bool STAMP>
-__global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* __restrict__ qkv,
-                                                                  const uint8_t* __restrict__ kpm, int causal,
-                                                                  int64_t n_tokens, int64_t n_items, int L, int H,
-                                                                  int GL, int nt, float scale,
+__global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo geo,
+                                                                  const uint8_t* __restrict__ kpm,
+                                                                  int64_t n_items, float scale,
                                                                   float* __restrict__ ctx,
                                                                   unsigned long long* __restrict__ stamps, StltDrop dr,
                                                                   uint32_t site) {
+  const int H = geo.H, causal = geo.causal;
+  const float* __restrict__ gq = geo.q;
+  const float* __restrict__ gk = geo.k;
+  const float* __restrict__ gv = geo.v;
+  const int64_t ldq = geo.ldq, ldkv = geo.ldkv;
   __shared__ __attribute__((aligned(16))) float smem_all[WAVES * WAVE_LDS_FLOATS];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* smem = smem_all + wave * WAVE_LDS_FLOATS;
@@ -102,7 +116,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int d = H * DH;
-  const int64_t ld = 3 * (int64_t)d;
   const int64_t stride = (int64_t)gridDim.x * WAVES;  // persistent waves: item, item + stride, ...
   int64_t item = (int64_t)blockIdx.x * WAVES + wave;
   if (item >= n_items) return;
@@ -115,18 +128,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
   int kt = 0, buf = 0;
   uint8_t pad;
   {  // prologue: first step's loads
-    const StepGeo s0 = step_geo(item, 0, n_tokens, L, H, GL, nt, causal);
-    frag_load(qf, qkv + (s0.tok0 + s0.q_first) * ld + s0.head * DH, ld, s0.q_rows, li, lh);
-    frag_load(kf, qkv + (s0.tok0 + s0.k_first) * ld + d + s0.head * DH, ld, s0.k_rows, li, lh);
-    tile_dma(smem, qkv + (s0.tok0 + s0.k_first) * ld + 2 * d + s0.head * DH, ld, s0.k_rows, lane);
-    pad = kpm[s0.tok0 + s0.k_first + (li < s0.k_rows ? li : 0)];
+    const StepGeo s0 = step_geo(item, 0, geo);
+    frag_load(qf, gq + (s0.q_tok0 + s0.q_first) * ldq + s0.head * DH, ldq, s0.q_rows, li, lh);
+    frag_load(kf, gk + (s0.k_tok0 + s0.k_first) * ldkv + s0.head * DH, ldkv, s0.k_rows, li, lh);
+    tile_dma(smem, gv + (s0.k_tok0 + s0.k_first) * ldkv + s0.head * DH, ldkv, s0.k_rows, lane);
+    pad = kpm[s0.k_tok0 + s0.k_first + (li < s0.k_rows ? li : 0)];
   }
 
   f32x16 o0, o1;
   float m_run = -1e30f, l_run = 0.f;
 
   for (;;) {
-    const StepGeo s = step_geo(item, kt, n_tokens, L, H, GL, nt, causal);
+    const StepGeo s = step_geo(item, kt, geo);
     float* Vs = smem + buf * TILE_FLOATS;
     STAMP_AT(1);
     wave_mem_sync();  // this step's fragments + V tile have landed (and the previous item's stores retired)
@@ -134,8 +147,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
     {
       // key metadata for the mask: -1 = masked/absent, else (sequence id << 16) | position in sequence
       const int kj = s.k_first + li;
-      const int ks = kj / L;
-      if (lane < TILE) kmeta[lane] = (li < s.k_rows && pad == 0) ? ((ks << 16) | (kj - ks * L)) : -1;
+      const int ks = kj / geo.Lk;
+      if (lane < TILE) kmeta[lane] = (li < s.k_rows && pad == 0) ? ((ks << 16) | (kj - ks * geo.Lk)) : -1;
     }
     if (kt == 0) {
 #pragma unroll
@@ -162,11 +175,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
     const bool have_next = n_item < n_items;
     uint8_t n_pad = 0;
     if (have_next) {
-      const StepGeo sn = step_geo(n_item, n_kt, n_tokens, L, H, GL, nt, causal);
-      if (n_kt == 0) frag_load(qf, qkv + (sn.tok0 + sn.q_first) * ld + sn.head * DH, ld, sn.q_rows, li, lh);
-      frag_load(kf, qkv + (sn.tok0 + sn.k_first) * ld + d + sn.head * DH, ld, sn.k_rows, li, lh);
-      tile_dma(smem + (buf ^ 1) * TILE_FLOATS, qkv + (sn.tok0 + sn.k_first) * ld + 2 * d + sn.head * DH, ld, sn.k_rows, lane);
-      n_pad = kpm[sn.tok0 + sn.k_first + (li < sn.k_rows ? li : 0)];
+      const StepGeo sn = step_geo(n_item, n_kt, geo);
+      if (n_kt == 0) frag_load(qf, gq + (sn.q_tok0 + sn.q_first) * ldq + sn.head * DH, ldq, sn.q_rows, li, lh);
+      frag_load(kf, gk + (sn.k_tok0 + sn.k_first) * ldkv + sn.head * DH, ldkv, sn.k_rows, li, lh);
+      tile_dma(smem + (buf ^ 1) * TILE_FLOATS, gv + (sn.k_tok0 + sn.k_first) * ldkv + sn.head * DH, ldkv, sn.k_rows, lane);
+      n_pad = kpm[sn.k_tok0 + sn.k_first + (li < sn.k_rows ? li : 0)];
     }
     if (STAMP) asm volatile("" :: "v"(st[0]), "v"(st[15]));
     STAMP_AT(3);
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
     // mask + online softmax; register r <-> key j = (r&3) + 8*(r>>2) + 4*lh.  Branch-free: all 16 metadata
     // words are fetched first (two addresses per instruction -> LDS broadcast).
     const int qi = s.q_first + li;
-    const int q_seq = qi / L, q_pos = qi - q_seq * L;
+    const int q_seq = qi / geo.Lq, q_pos = qi - q_seq * geo.Lq;
     const int q_hi = q_seq << 16;
     const int pos_lim = causal ? q_pos : 0xffff;
     int meta[16];
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
       const float v1 = vrow[swz(j, 8 + (li >> 2)) * 4];
       float pr = p[r];
       if (dr.thr) {  // train-mode dropout of the attention probabilities: the denominator keeps the undropped sum
-        const uint64_t idx = ((((uint64_t)(s.tok0 + qi)) * H + s.head) << 8) | (uint64_t)(meta[r] & 0xff);
+        const uint64_t idx = ((((uint64_t)(s.q_tok0 + qi)) * H + s.head) << 8) | (uint64_t)(meta[r] & 0xff);
         pr = stlt_keep(dr, site, idx) ? pr * dr.scale : 0.f;
       }
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, pr, o0, 0, 0, 0);
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
         *reinterpret_cast<f32x4*>(Vs + li * DH + swz(li, 8 + 2 * q + lh) * 4) = b;
       }
       STAMP_AT(6);
-      float* obase = ctx + (s.tok0 + s.q_first) * (int64_t)d + s.head * DH;
+      float* obase = ctx + (s.q_tok0 + s.q_first) * (int64_t)d + s.head * DH;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = 4 * i + (lane >> 4), chunk = lane & 15;
@@ -266,21 +279,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const float* _
 }  // namespace
 
 
-int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
-                float* ctx, int kid, hipStream_t s, StltDrop dr, uint32_t site) {
-  if (!qkv || !kpm || !ctx) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: null pointer");
+// General entry: queries (S*Lq rows of q, stride ldq) attend to keys/values (S*Lk rows of k / v, stride ldkv).
+int launch_attn_general(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm,
+                        int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx, int kid,
+                        hipStream_t s, StltDrop dr, uint32_t site) {
+  if (!q || !k || !v || !kpm || !ctx) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: null pointer");
   if (dh != DH) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: head dim %lld unsupported (kernel is built for dh=64)", (long long)dh);
-  if (dr.thr && L > 256) return stlt_set_error(STLT_EINVAL, "attention dropout supports sequences of at most 256 tokens");
-  if (L <= 0 || L > 32768 || H <= 0 || H > 65535) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: bad L=%lld H=%lld", (long long)L, (long long)H);
+  if (dr.thr && Lk > 256) return stlt_set_error(STLT_EINVAL, "attention dropout supports sequences of at most 256 tokens");
+  if (Lq <= 0 || Lk <= 0 || Lq > 32768 || Lk > 32768 || H <= 0 || H > 65535) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: bad L/H");
+  if (causal && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: causal masking needs Lq == Lk");
+  if (ldq % 4 || ldkv % 4) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: strides must be multiples of 4 floats");
   if (S == 0) return 0;
-  const int P = L <= 16 ? (int)(TILE / L) : 1;  // sequences packed per 32-token tile
-  const int GL = P * (int)L;
-  const int nt = (GL + TILE - 1) / TILE;
-  const int64_t n_tokens = S * L;
+  // sequences packed per 32-token tile (short self-attention sequences only)
+  const int P = (Lq == Lk && Lq <= 16) ? (int)(TILE / Lq) : 1;
+  AttnGeo g;
+  g.q = q; g.k = k; g.v = v; g.ldq = ldq; g.ldkv = ldkv;
+  g.nq_tokens = S * Lq; g.nk_tokens = S * Lk;
+  g.Lq = (int)Lq; g.Lk = (int)Lk; g.GLq = P * (int)Lq; g.GLk = P * (int)Lk;
+  g.ntq = (g.GLq + TILE - 1) / TILE; g.ntk = (g.GLk + TILE - 1) / TILE;
+  g.H = (int)H; g.causal = causal;
   const int64_t groups = (S + P - 1) / P;
-  if (groups * nt * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles");
+  if (groups * g.ntq * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles");
   StltProfScope ps(kid, s);
-  const int64_t n_items = groups * nt * H;
+  const int64_t n_items = groups * g.ntq * H;
   // persistent waves: as many workgroups as are resident at once (occupancy API x CU count), each wave strides
   // over the items; there is no inter-workgroup dependency, so a wrong residency guess only costs speed
   static int n_cu = 0, wg_per_cu = 0;
@@ -296,11 +317,17 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
   int64_t n_wg = (n_items + WAVES - 1) / WAVES;
   if (n_wg > (int64_t)wg_per_cu * n_cu) n_wg = (int64_t)wg_per_cu * n_cu;
   dim3 grid((unsigned)n_wg);
-  if (g_stlt_debug_buf)  // diagnostic build path only (tools/attn_stamps.py); never set by the product
-    hipLaunchKernelGGL(attn_core_kernel<true>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
-                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, g_stlt_debug_buf, dr, site);
+  const float scale = 1.0f / sqrtf((float)dh);
+  if (g_stlt_debug_buf && !getenv("STLT_GEMM_STAMP"))  // diagnostic build path only (tools/attn_stamps.py); never set by the product
+    hipLaunchKernelGGL(attn_core_kernel<true>, grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, g_stlt_debug_buf, dr, site);
   else
-    hipLaunchKernelGGL(attn_core_kernel<false>, grid, dim3(64 * WAVES), 0, s, qkv, kpm, causal, n_tokens, n_items, (int)L,
-                       (int)H, GL, nt, 1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, dr, site);
+    hipLaunchKernelGGL(attn_core_kernel<false>, grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, (unsigned long long*)nullptr, dr, site);
   return stlt_check_launch("attn_core_kernel");
+}
+
+int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
+                float* ctx, int kid, hipStream_t s, StltDrop dr, uint32_t site) {
+  if (!qkv) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: null pointer");
+  const int64_t d = H * dh;
+  return launch_attn_general(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, kpm, causal, S, L, L, H, dh, ctx, kid, s, dr, site);
 }

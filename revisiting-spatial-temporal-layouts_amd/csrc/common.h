@@ -73,6 +73,9 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
+int launch_attn_general(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm,
+                        int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx, int kid,
+                        hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* w, const float* b,
                          float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
                          uint32_t site = 0);

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
               float val = acc[a][b][r];
               if (ADD) val += rp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldr];
               if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+              if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
               yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = val;
             }
           } else {
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
               const int row = (r & 3) + 8 * (r >> 2);
               float val = acc[a][b][r];
               if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+              if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
               if (n < N && mb + row < M) yp[(int64_t)row * ldy] = ADD ? val + rp[(int64_t)row * ldr] : val;
             }
           }
@@ -407,7 +409,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   if (lda % 4 != 0 || ldb % 4 != 0 || (r && ldr < N) || ldc < N || lda < (transA ? M : K) || ldb < (transB ? N : K))
     return stlt_set_error(STLT_EINVAL, "gemm: bad leading dimension (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
   if (M > 0x7fffff00LL || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gemm: M/N too large");
-  if (act != STLT_ACT_NONE && act != STLT_ACT_GELU) return stlt_set_error(STLT_EINVAL, "gemm: unknown activation %d", act);
+  if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU) return stlt_set_error(STLT_EINVAL, "gemm: unknown activation %d", act);
   if (n_split < 1 || (K / BK) % n_split != 0) return stlt_set_error(STLT_EINVAL, "gemm: n_split=%d must divide K/32=%lld", n_split, (long long)(K / BK));
   if (transA && !transB) return stlt_set_error(STLT_EINVAL, "gemm: the (transA, !transB) layout is not built");
   if ((transA || transB) && (act != STLT_ACT_NONE || bias)) return stlt_set_error(STLT_EINVAL, "gemm: bias/activation only with the forward (NT) layout");
@@ -425,6 +427,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
   else if (g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true, false, false, false);  // diagnostic build path only
   else if (act == STLT_ACT_GELU) LAUNCH(STLT_ACT_GELU, false, false, false, false);
+  else if (act == STLT_ACT_RELU) LAUNCH(STLT_ACT_RELU, false, false, false, false);
   else LAUNCH(STLT_ACT_NONE, false, false, false, false);
 #undef LAUNCH
   return stlt_check_launch("gemm_nt_kernel");

@@ -119,6 +119,21 @@ def attn_core(qkv: torch.Tensor, kpm: torch.Tensor, causal: bool, num_heads: int
     return ctx
 
 
+def attn_cross(q: torch.Tensor, kv: torch.Tensor, kpm_k: Optional[torch.Tensor], num_heads: int, causal: bool = False):
+    """Cross-attention core: q (S,Lq,d) projected queries, kv (S,Lk,2d) packed [k;v], kpm_k (S,Lk) over the keys or None."""
+    lib = L.load()
+    _chk(q, torch.float32, "q"); _chk(kv, torch.float32, "kv")
+    S, Lq, d = q.shape
+    Lk = kv.shape[1]
+    if kpm_k is None:
+        kpm_k = torch.zeros(S, Lk, dtype=torch.uint8, device=q.device)
+    kpm_k = _mask_u8(kpm_k, "kpm")
+    ctx = torch.empty(S, Lq, d, device=q.device, dtype=torch.float32)
+    L.check(lib.stlt_attn_cross_fwd(_p(q), d, _p(kv), kv.data_ptr() + 4 * d, 2 * d, _p(kpm_k), int(bool(causal)), S, Lq, Lk,
+                                    num_heads, d // num_heads, _p(ctx), _stream()), "stlt_attn_cross_fwd")
+    return ctx
+
+
 def add_layernorm(x: torch.Tensor, res: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, eps: float):
     """out = LayerNorm_eps(x + res) over the last dim (res may be None)."""
     lib = L.load()

@@ -162,3 +162,32 @@ def test_gemm_tn_dw_layout_with_split_k(pkg, M, N, K, split):
         acc = _rand(M, N, seed=6)
         got2 = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_a=True, trans_b=True, n_split=split, add=acc.to(DEV)).cpu()
         assert (got2.double() - (ref + acc.double())).abs().max().item() <= 2e-5 * math.sqrt(K)
+
+
+@pytest.mark.parametrize("Lq,Lk", [(32, 33), (33, 32), (17, 5), (5, 70), (64, 64)])
+def test_attn_cross(pkg, Lq, Lk):
+    """Queries and keys from different token spaces (CAF cross-attention), key padding on the key side only."""
+    S, H = 5, 4
+    d = 64 * H
+    q = _rand(S, Lq, d, seed=Lq, scale=1.5)
+    kv = _rand(S, Lk, 2 * d, seed=100 + Lk, scale=1.5)
+    kpm = torch.rand(S, Lk, generator=torch.Generator().manual_seed(3)) < 0.3
+    kpm[:, 0] = False
+    for mask in (kpm, None):
+        got = pkg.ops.attn_cross(q.to(DEV), kv.to(DEV), None if mask is None else mask.to(DEV), H).cpu()
+        k, v = kv[..., :d], kv[..., d:]
+        qh = q.double().reshape(S, Lq, H, 64).transpose(1, 2)
+        kh = k.double().reshape(S, Lk, H, 64).transpose(1, 2)
+        vh = v.double().reshape(S, Lk, H, 64).transpose(1, 2)
+        sc = qh @ kh.transpose(-1, -2) / 8.0
+        if mask is not None:
+            sc = sc.masked_fill(mask[:, None, None, :], float("-inf"))
+        ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(S, Lq, d)
+        assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+def test_linear_relu(pkg):
+    x, w, b = _rand(300, 256, seed=1), _rand(512, 256, seed=2, scale=1 / 16), _rand(512, seed=3, scale=0.1)
+    y = pkg.ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=2).cpu()
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    assert (y.double() - ref).abs().max().item() <= 2e-5
