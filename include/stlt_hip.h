@@ -158,6 +158,44 @@ int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* wor
 int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,
                  int flags, float* out_btd, float* logits, stlt_stream_t stream);
 
+/* ---- CAF / CACNF on precomputed appearance features (reference models.py:230-271, 286-298, 328-549) ----
+ * The layout branch is the StltBackbone above; the appearance branch starts from the R3D-50 feature map the reference's
+ * Resnet3D.forward_features returns, (B, 2048, 2,4,4) = (B, feat_channels, app_tokens) row-major, given by the caller. */
+typedef struct {  /* SelfAttentionLayer / CrossAttentionLayer: nn.MultiheadAttention + LayerNorm(eps = ln_eps), models.py:345-382 */
+  const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *ln_w, *ln_b;
+} stlt_attn_block_params;
+typedef struct {  /* FeedforwardModule, models.py:328-342 */
+  const float *lin1_w, *lin1_b, *lin2_w, *lin2_b, *ln_w, *ln_b;
+} stlt_ffn_block_params;
+typedef struct {  /* CrossModalModule, models.py:385-431; cross_attn is shared by both directions, appearance_ffn IS a self-attention layer */
+  stlt_attn_block_params cross_attn, layout_attn, appearance_attn, appearance_ffn;
+  stlt_ffn_block_params layout_ffn;
+} stlt_crossmodal_params;
+typedef struct {  /* ClassificationHead (d->d->K) or FusionHead (2d->d->K): fc1, LayerNorm(ln_eps), fc2 */
+  const float *fc1_w, *fc1_b, *ln_w, *ln_b, *fc2_w, *fc2_b;
+} stlt_head_params;
+typedef struct {
+  stlt_params layout;                 /* layout_branch (head fields unused) */
+  int64_t feat_channels, app_tokens;  /* 2048, 32 */
+  const float *proj_w, *proj_b;       /* projector Conv3d 1x1x1 == Linear (d, feat_channels), models.py:236-238 */
+  const float *cls_token, *pos_embed; /* (d), (app_tokens+1, d), models.py:247-250 */
+  int64_t n_app_layers;
+  const stlt_layer_params* app_layers; /* HOST array; ReLU encoder layers, LN eps 1e-5, models.py:239-246 */
+  int64_t n_fusion;
+  const stlt_crossmodal_params* fusion; /* HOST array */
+  stlt_head_params fusion_head;        /* FusionHead: classifier (CAF) / fusion_classifier (CACNF) */
+  stlt_head_params layout_head, appearance_head; /* CACNF only (ClassificationHead x2); fc1_w == NULL for CAF */
+} stlt_caf_params;
+
+size_t stlt_caf_workspace_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t feat_channels, int64_t app_tokens,
+                                int64_t n_classes);
+/* CrossAttentionFusion.forward (models.py:486-498) -> logits_caf (B,K).  With the two extra heads given it is
+ * CrossAttentionCentralNetFusion.forward (models.py:520-549): logits_stlt, logits_resnet3d, logits_caf and
+ * logits_ensemble = their mean (all (B,K); the three extra outputs may be NULL for CAF). */
+int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const float* appearance_features, void* workspace,
+                     size_t workspace_bytes, float* logits_caf, float* logits_stlt, float* logits_resnet3d,
+                     float* logits_ensemble, stlt_stream_t stream);
+
 /* ---- training step (reference src/train.py:119-135: forward, loss.backward(); the optimizer stays in torch) ----
  * stlt_train_forward runs the dense schedule and records every intermediate the reverse sweep needs in `tape`
  * (fp32; rows padded to a multiple of 32; the caller allocates it ZERO-FILLED once and the library never writes the

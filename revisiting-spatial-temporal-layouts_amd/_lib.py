@@ -36,6 +36,30 @@ class Params(C.Structure):
     )
 
 
+class AttnBlockParams(C.Structure):
+    _fields_ = [(n, _vp) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln_w", "ln_b")]
+
+
+class FfnBlockParams(C.Structure):
+    _fields_ = [(n, _vp) for n in ("lin1_w", "lin1_b", "lin2_w", "lin2_b", "ln_w", "ln_b")]
+
+
+class CrossModalParams(C.Structure):
+    _fields_ = [("cross_attn", AttnBlockParams), ("layout_attn", AttnBlockParams), ("appearance_attn", AttnBlockParams),
+                ("appearance_ffn", AttnBlockParams), ("layout_ffn", FfnBlockParams)]
+
+
+class HeadParams(C.Structure):
+    _fields_ = [(n, _vp) for n in ("fc1_w", "fc1_b", "ln_w", "ln_b", "fc2_w", "fc2_b")]
+
+
+class CafParams(C.Structure):
+    _fields_ = [("layout", Params), ("feat_channels", C.c_int64), ("app_tokens", C.c_int64), ("proj_w", _vp), ("proj_b", _vp),
+                ("cls_token", _vp), ("pos_embed", _vp), ("n_app_layers", C.c_int64), ("app_layers", C.POINTER(LayerParams)),
+                ("n_fusion", C.c_int64), ("fusion", C.POINTER(CrossModalParams)), ("fusion_head", HeadParams),
+                ("layout_head", HeadParams), ("appearance_head", HeadParams)]
+
+
 class Inputs(C.Structure):
     _fields_ = [("B", C.c_int64), ("T", C.c_int64), ("N", C.c_int64)] + [
         (n, _vp) for n in ("categories", "boxes", "scores", "kpm_boxes", "frame_types", "kpm_frames", "lengths")]
@@ -65,6 +89,8 @@ SIGNATURES = {
     "stlt_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "stlt_backbone_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp]),
     "stlt_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
+    "stlt_caf_workspace_bytes": (C.c_size_t, [C.c_int64] * 7),
+    "stlt_caf_forward": (C.c_int, [C.c_void_p, C.POINTER(Inputs), _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp]),
     "stlt_train_tape_bytes": (C.c_size_t, [C.c_int64] * 6),
     "stlt_train_scratch_bytes": (C.c_size_t, [C.c_int64] * 5),
     "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, _vp]),

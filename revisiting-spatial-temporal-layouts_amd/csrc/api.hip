@@ -283,6 +283,16 @@ static int backbone_impl(const stlt_params* p, const stlt_inputs* in, void* work
   return 0;
 }
 
+// exported to caf.hip (same library, C++ linkage)
+int backbone_impl_public(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes, int flags,
+                         float* out_btd, hipStream_t s) {
+  TRY(check_params(p, in, false));
+  return backbone_impl(p, in, workspace, workspace_bytes, flags, out_btd, nullptr, s);
+}
+size_t stlt_workspace_bytes_public(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes) {
+  return ws_layout(B, T, N, d, n_classes < 0 ? 0 : n_classes).total;
+}
+
 extern "C" {
 
 int stlt_backbone_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes,

@@ -36,4 +36,27 @@ class StltModelConfig:
         return "\n".join(f"- {k}: {v}" for k, v in rows)
 
 
-model_configs_factory = {"stlt": StltModelConfig}
+class MultimodalModelConfig:
+    """Attribute surface of the reference's ``MultimodalModelConfig`` (src/modelling/configs.py:128-175) for CAF / CACNF
+    on precomputed appearance features: ``stlt_config`` for the layout branch plus the appearance / fusion sizes.
+    ``resnet_model_path`` is accepted and ignored (the R3D-50 trunk does not run here)."""
+
+    def __init__(self, **kwargs):
+        self.stlt_config = StltModelConfig(**dict(kwargs))
+        self.num_classes = self.stlt_config.num_classes
+        self.hidden_size = self.stlt_config.hidden_size
+        self.hidden_dropout_prob = self.stlt_config.hidden_dropout_prob
+        self.layer_norm_eps = self.stlt_config.layer_norm_eps
+        self.num_attention_heads = self.stlt_config.num_attention_heads
+        self.appearance_num_frames = kwargs.pop("appearance_num_frames", None)
+        assert self.appearance_num_frames, "appearance_num_frames must not be None!"
+        self.resnet_model_path = kwargs.pop("resnet_model_path", None)
+        self.num_appearance_layers = kwargs.pop("num_appearance_layers", 4)
+        self.num_fusion_layers = kwargs.pop("num_fusion_layers", 4)
+        self.load_backbone_path = kwargs.pop("load_backbone_path", None)
+        self.freeze_backbone = kwargs.pop("freeze_backbone", False)
+        self.appearance_config = self
+        self.stlt_config.load_backbone_path = None  # the fusion models build a fresh layout branch (models.py:439)
+
+
+model_configs_factory = {"stlt": StltModelConfig, "caf": MultimodalModelConfig, "cacnf": MultimodalModelConfig}

@@ -402,4 +402,4 @@ class _StltTrainFn(torch.autograd.Function):
         return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)
 
 
-models_factory = {"stlt": Stlt}
+models_factory = {"stlt": Stlt}  # "caf" / "cacnf" are added by modelling/fusion.py at package import

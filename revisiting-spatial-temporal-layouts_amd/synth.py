@@ -83,7 +83,10 @@ def make_state_dict(shapes: Dict[str, tuple], seed: int = 1234, gain: float = 1.
             continue
         leaf = name.rsplit(".", 1)[-1]
         parent = name.rsplit(".", 2)[-2] if name.count(".") >= 1 else ""
-        if parent in ("norm1", "norm2", "layer_norm"):
+        if leaf in ("cls_token", "pos_embed"):
+            out[name] = _sym(key, shape, 0.5)
+            continue
+        if parent in ("norm1", "norm2", "layer_norm", "ln"):
             if leaf == "weight":
                 out[name] = 1.0 + _sym(key, shape, 0.1)
             else:
@@ -94,7 +97,7 @@ def make_state_dict(shapes: Dict[str, tuple], seed: int = 1234, gain: float = 1.
             out[name] = _sym(key, shape, gain * (6.0 / (shape[0] + shape[1])) ** 0.5 * 1.5)
         elif leaf in ("in_proj_bias",) or leaf == "bias":
             out[name] = _sym(key, shape, 0.05)
-        elif leaf == "weight" and len(shape) == 2:
+        elif leaf == "weight" and len(shape) in (2, 5):  # Linear, or the 1x1x1 Conv3d projector
             out[name] = _sym(key, shape, 1.0 / (shape[1] ** 0.5))
         else:
             raise KeyError(f"no init rule for {name} {shape}")
@@ -203,6 +206,13 @@ def model_kwargs(name: str) -> dict:
         num_temporal_layers=c["num_temporal_layers"],
         hidden_dropout_prob=0.0,
     )
+
+
+def make_appearance_features(B: int, seed: int = 0, channels: int = 2048) -> torch.Tensor:
+    """Stand-in for the R3D-50 feature map of Resnet3D.forward_features (reference models.py:221-222):
+    (B, 2048, 2, 4, 4), non-negative like a post-ReLU map."""
+    u = uniform01(fnv1a64("appearance_features") ^ (seed * 0x9E3779B97F4A7C15 & _MASK64), B * channels * 32)
+    return torch.from_numpy((u * 1.5).astype(np.float32).reshape(B, channels, 2, 4, 4))
 
 
 def flops_per_clip(T: int, N: int, d: int, n_sp: int, n_tp: int, classes: int) -> float:
