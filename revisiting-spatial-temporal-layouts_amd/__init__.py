@@ -16,6 +16,7 @@ from .modelling.models import (  # noqa: F401
     StltBackbone,
     models_factory,
 )
+from .utils.evaluation import evaluators_factory  # noqa: F401
 from .utils.model_utils import generate_square_subsequent_mask  # noqa: F401
 
 __all__ = ["Stlt", "StltBackbone", "StltModelConfig", "models_factory", "model_configs_factory", "StltHipError",

@@ -81,3 +81,49 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _eval_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    D = importlib.import_module(PKG_NAME + ".dist")
+    E = importlib.import_module(PKG_NAME + ".utils.evaluation")
+    D.init_distributed("gloo")
+    G = np.load(os.path.join(ROOT, "tests", "golden", "evaluation.npz"))
+    n = G["sth_labels"].shape[0]
+    lo, hi = D.shard_bounds(n, rank, world)
+    ev = E.EvaluatorSomething(n, 174, ("stlt", "caf"))
+    ev.process({"stlt": torch.from_numpy(G["sth_logits_a"][lo:hi]), "caf": torch.from_numpy(G["sth_logits_b"][lo:hi])}, torch.from_numpy(G["sth_labels"][lo:hi]))
+    m = ev.evaluate()
+    keep = [j for j in range(157) if j != 11]
+    lg, gt = G["ag_logits"][:119, keep], G["ag_truths"][:119, keep]  # 119 clips: uneven shards
+    lo, hi = D.shard_bounds(119, rank, world)
+    ag = E.EvaluatorActionGenome(119, len(keep), ("stlt",))
+    ag.process({"stlt": torch.from_numpy(lg[lo:hi])}, torch.from_numpy(gt[lo:hi]))
+    got = ag.evaluate()["map"]
+    if rank == 0:
+        one = E.EvaluatorActionGenome(119, len(keep), ("stlt",))
+        one.predictions = torch.from_numpy(lg).sigmoid().double()
+        one.ground_truths = torch.from_numpy(gt).double()
+        one.index = 119
+        ref = float(E.charades_map(one.predictions, one.ground_truths)[0])
+        q.put((m, got, ref))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_evaluators_match_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    m, got, ref = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    G = np.load(os.path.join(ROOT, "tests", "golden", "evaluation.npz"))
+    assert [m["stlt_top1_accuracy"], m["stlt_top5_accuracy"], m["caf_top1_accuracy"], m["caf_top5_accuracy"]] == G["sth_metrics"].tolist()
+    assert abs(got - ref) < 1e-12

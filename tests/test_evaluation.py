@@ -1,0 +1,90 @@
+"""Evaluators against goldens captured from the reference's evaluation.py and against the oracle."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("revisiting-spatial-temporal-layouts_amd")
+E = importlib.import_module("revisiting-spatial-temporal-layouts_amd.utils.evaluation")
+from oracle import evaluation_oracle as O  # noqa: E402
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "evaluation.npz"))
+
+
+def _run_something(device):
+    n = G["sth_labels"].shape[0]
+    ev = E.evaluators_factory["something"](n, 174, ("stlt", "caf"))
+    for lo, hi in ((0, 10), (10, 64), (64, n)):
+        ev.process({"stlt": torch.from_numpy(G["sth_logits_a"][lo:hi]).to(device), "caf": torch.from_numpy(G["sth_logits_b"][lo:hi]).to(device)},
+                   torch.from_numpy(G["sth_labels"][lo:hi]))
+    return ev
+
+
+def _run_ag(device, cols=None):
+    lg, gt = G["ag_logits"], G["ag_truths"]
+    if cols is not None:
+        lg, gt = lg[:, cols], gt[:, cols]
+    ev = E.evaluators_factory["action_genome"](lg.shape[0], lg.shape[1], ("stlt",))
+    for lo, hi in ((0, 7), (7, 100), (100, lg.shape[0])):
+        ev.process({"stlt": torch.from_numpy(lg[lo:hi]).to(device)}, torch.from_numpy(gt[lo:hi]))
+    return ev
+
+
+def test_oracle_matches_reference_golden():
+    a, b, y = G["sth_logits_a"], G["sth_logits_b"], G["sth_labels"]
+    got = [O.topk_correct(a, y, 1) / len(y), O.topk_correct(a, y, 5) / len(y), O.topk_correct(b, y, 1) / len(y), O.topk_correct(b, y, 5) / len(y)]
+    assert got == G["sth_metrics"].tolist()
+    sig = torch.from_numpy(G["ag_logits"]).sigmoid().numpy().astype(np.float64)
+    m, w, aps = O.charades_map(sig, G["ag_truths"])
+    assert np.isnan(m) and np.isnan(G["ag_map"])
+    np.testing.assert_allclose(aps, G["ag_aps"], rtol=0, atol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(w, G["ag_wap"], rtol=0, atol=1e-15, equal_nan=True)
+    keep = [j for j in range(157) if j != 11]
+    m2, _, a2 = O.charades_map(sig[:, keep], G["ag_truths"][:, keep])
+    assert abs(m2 - float(G["ag_map_finite"])) < 1e-15
+
+
+def _check(device):
+    ev = _run_something(device)
+    m = ev.evaluate()
+    assert [m["stlt_top1_accuracy"], m["stlt_top5_accuracy"], m["caf_top1_accuracy"], m["caf_top5_accuracy"]] == G["sth_metrics"].tolist()
+    assert ev.corrects["stlt_top1"] == round(G["sth_metrics"][0] * 90)
+    assert ev.is_best() and not ev.is_best()
+    ev.reset()
+    assert ev.evaluate()["stlt_top1_accuracy"] == 0.0
+    ag = _run_ag(device)
+    assert np.isnan(ag.evaluate()["map"]) and not ag.is_best()  # class 11 has no positive: the reference's mean is NaN too
+    _, w, aps = E.charades_map(ag.predictions, ag.ground_truths)
+    np.testing.assert_allclose(aps.cpu().numpy(), G["ag_aps"], rtol=0, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(w.cpu().numpy(), G["ag_wap"], rtol=0, atol=1e-12, equal_nan=True)
+    keep = [j for j in range(157) if j != 11]
+    ag2 = _run_ag(device, keep)
+    assert abs(ag2.evaluate()["map"] - float(G["ag_map_finite"])) < 1e-12
+    assert ag2.is_best() and not ag2.is_best()
+
+
+def test_evaluators_cpu_tensors():
+    _check("cpu")
+
+
+@pytest.mark.gpu
+def test_evaluators_device_tensors():
+    _check("cuda")
+    ev = _run_something("cuda")
+    assert ev._counts.is_cuda  # state stays on the device between batches
+
+
+def test_partial_fill_matches_reference_zero_rows():
+    # fewer processed clips than total_instances: the unfilled rows are all-zero clips, which sort last (evaluation.py:72-74,129-131)
+    lg, gt = G["ag_logits"][:40, :20], G["ag_truths"][:40, :20].copy()
+    gt[0, :] = 1  # every class has a positive
+    ev = E.EvaluatorActionGenome(64, 20, ("stlt",))
+    ev.process({"stlt": torch.from_numpy(lg)}, torch.from_numpy(gt))
+    sig = np.zeros((64, 20)); sig[:40] = torch.from_numpy(lg).sigmoid().numpy()
+    full = np.zeros((64, 20)); full[:40] = gt
+    assert abs(ev.evaluate()["map"] - O.charades_map(sig, full)[0]) < 1e-12
