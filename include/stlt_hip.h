@@ -65,6 +65,14 @@ int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
 int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb,
               const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride,
               int64_t M, int64_t N, int64_t K, int n_split, stlt_stream_t stream);
+/* Optional scratch for the calling thread's stlt_linear_fwd / stlt_gemm launches (torch's nn.Linear has no
+ * counterpart: this is launch policy).  With scratch lent, a launch whose 256x128 output tiles would leave compute
+ * units idle (fewer tiles than CUs, or a ragged last round) is cut into equal contiguous k-step ranges instead
+ * ("stream-K"); tiles computed by more than one workgroup are summed in workgroup order by a second kernel, so results
+ * stay deterministic.  The buffer must hold stlt_gemm_scratch_bytes() and may only be reused by work ordered after
+ * the launch on its stream.  Pass NULL to withdraw.  The whole-path entry points lend a slice of their workspace. */
+size_t stlt_gemm_scratch_bytes(void);
+int stlt_gemm_set_scratch(void* scratch, size_t bytes);
 /* dst[i] = (accumulate ? dst[i] : 0) + sum_s slabs[s*stride + i], i < n */
 int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate,
                       stlt_stream_t stream);

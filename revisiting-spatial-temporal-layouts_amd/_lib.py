@@ -75,6 +75,8 @@ SIGNATURES = {
                                   C.c_int, _vp]),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
+    "stlt_gemm_scratch_bytes": (C.c_size_t, []),
+    "stlt_gemm_set_scratch": (C.c_int, [_vp, C.c_size_t]),
     "stlt_reduce_slabs": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int, _vp]),
     "stlt_attn_core_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_attn_cross_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64,

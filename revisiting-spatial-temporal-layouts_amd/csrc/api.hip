@@ -107,6 +107,15 @@ int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* 
                      STLT_ACT_NONE, (hipStream_t)stream);
 }
 
+size_t stlt_gemm_scratch_bytes(void) { return STLT_GEMM_SCRATCH_BYTES; }
+
+int stlt_gemm_set_scratch(void* scratch, size_t bytes) {
+  if (scratch && bytes < STLT_GEMM_SCRATCH_BYTES)
+    return stlt_set_error(STLT_EWORKSPACE, "gemm scratch %zu B < required %zu B", bytes, (size_t)STLT_GEMM_SCRATCH_BYTES);
+  stlt_gemm_set_scratch_impl(scratch, bytes);
+  return 0;
+}
+
 int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate,
                       stlt_stream_t stream) {
   return launch_reduce_slabs(slabs, stride, n_slabs, dst, n, accumulate, (hipStream_t)stream);
@@ -147,7 +156,7 @@ int stlt_gather_last_fwd(const float* x, const int64_t* lengths, int64_t B, int6
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t x, x1, qkv, ctx, tmp, hh, head, total;
+  size_t x, x1, qkv, ctx, tmp, hh, head, sk, total;
 };
 
 static WsLayout ws_layout(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes) {
@@ -163,6 +172,7 @@ static WsLayout ws_layout(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_
   w.tmp = take(tok * d * f);
   w.hh = take(tok * 4 * d * f);
   w.head = take((size_t)B * (3 * d + n_classes) * f);
+  w.sk = take(STLT_GEMM_SCRATCH_BYTES);  // stream-K partial tiles of under-filled GEMM launches
   w.total = off;
   return w;
 }
@@ -216,6 +226,7 @@ static int backbone_impl(const stlt_params* p, const stlt_inputs* in, void* work
   if (!workspace || workspace_bytes < w.total)
     return stlt_set_error(STLT_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
   char* base = (char*)workspace;
+  StltGemmScratch gemm_scratch(base + w.sk, STLT_GEMM_SCRATCH_BYTES);
   float* x = (float*)(base + w.x);
   float* x1 = (float*)(base + w.x1);
   float* qkv = (float*)(base + w.qkv);
@@ -312,6 +323,7 @@ int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, s
   if (!workspace || workspace_bytes < w.total)
     return stlt_set_error(STLT_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
   char* base = (char*)workspace;
+  StltGemmScratch gemm_scratch(base + w.sk, STLT_GEMM_SCRATCH_BYTES);
   float* bb_out = out_btd ? out_btd : (float*)(base + w.x1);  // x1 doubles as the in-place temporal buffer
   float* h0 = (float*)(base + w.head);
   float* h1 = h0 + (size_t)B * d;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void mean3_kernel(const float* a, const float*
 }
 
 struct CafWs {
-  size_t bb, lh, ah, la, aa, q, kv, ctx, tmp, hh, ft, proj, zero, fused, h1, h2, hl, total;
+  size_t bb, lh, ah, la, aa, q, kv, ctx, tmp, hh, ft, proj, zero, fused, h1, h2, hl, sk, total;
 };
 
 CafWs caf_ws(int64_t B, int64_t T, int64_t N, int64_t d, int64_t C, int64_t S, int64_t K) {
@@ -84,6 +84,7 @@ CafWs caf_ws(int64_t B, int64_t T, int64_t N, int64_t d, int64_t C, int64_t S, i
   w.h1 = take((size_t)B * d * f);
   w.h2 = take((size_t)B * d * f);
   w.hl = take((size_t)B * d * f);
+  w.sk = take(STLT_GEMM_SCRATCH_BYTES);
   w.total = off;
   return w;
 }
@@ -141,6 +142,7 @@ extern "C" int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in,
   const CafWs w = caf_ws(B, T, N, d, C, S, K);
   if (workspace_bytes < w.total) return stlt_set_error(STLT_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
   char* base = (char*)workspace;
+  StltGemmScratch gemm_scratch(base + w.sk, STLT_GEMM_SCRATCH_BYTES);
   auto F = [&](size_t o) { return (float*)(base + o); };
   float *Lh = F(w.lh), *Ah = F(w.ah), *la = F(w.la), *aa = F(w.aa);
   Bufs b{F(w.q), F(w.kv), F(w.ctx), F(w.tmp), F(w.hh), (const uint8_t*)(base + w.zero)};

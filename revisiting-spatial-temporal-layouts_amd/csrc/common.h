@@ -70,6 +70,22 @@ int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
                 int64_t K, int n_split, int act, hipStream_t s);
+// Scratch for stream-K partial tiles (2 images of 256x128 floats per workgroup).  While a StltGemmScratch is alive
+// on the calling thread, launch_gemm may cut under-filled launches into equal k-step ranges; the buffer is only
+// touched by kernels enqueued on the launch stream.  Whole-path entry points lend a slice of their workspace.
+constexpr int STLT_GEMM_SK_MAX_WG = 256;
+constexpr size_t STLT_GEMM_SCRATCH_BYTES = (size_t)2 * STLT_GEMM_SK_MAX_WG * 256 * 128 * sizeof(float);  // 64 MiB
+class StltGemmScratch {
+ public:
+  StltGemmScratch(void* p, size_t bytes);
+  ~StltGemmScratch();
+  StltGemmScratch(const StltGemmScratch&) = delete;
+  StltGemmScratch& operator=(const StltGemmScratch&) = delete;
+ private:
+  float* prev_;
+  size_t prev_bytes_;
+};
+void stlt_gemm_set_scratch_impl(void* p, size_t bytes);
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);

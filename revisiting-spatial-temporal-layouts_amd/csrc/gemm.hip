@@ -47,7 +47,7 @@ constexpr int STAGE_FLOATS = (BM + BN) * BK;  // 12288 floats = 48 KB per stage
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-template <int ACT, bool STAMP, bool TA, bool TB, bool ADD>
+template <int ACT, bool STAMP, bool TA, bool TB, bool ADD, bool SK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ W, int64_t ldw,
                                                                   const float* __restrict__ bias,
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
                                                                   float* __restrict__ Y, int64_t ldy,
                                                                   int64_t slab_stride, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, int n_split,
+                                                                  float* __restrict__ partials,
                                                                   unsigned long long* __restrict__ dbg) {
   constexpr int prio = STLT_GEMM_PRIO_MODE;
   __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + 2 * BN];  // operand stages + 2 bias strips
@@ -73,17 +74,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   const int G = gridDim.x;
   int v = blockIdx.x;
   if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int my_tiles = (n_tiles - v + G - 1) / G;  // tiles v, v+G, v+2G, ...
-  if (my_tiles <= 0) return;
+  // Work assignment.  Default: whole work items v, v+G, v+2G, ...  Stream-K (SK): the launch's k-steps
+  // (tile-major) are cut into G equal contiguous ranges, so a launch with fewer tiles than CUs, or a ragged last
+  // round, still keeps every CU busy; a range may begin and/or end inside a tile, and those segments go to the
+  // partial-tile slots 2v (range begins inside / at this tile) and 2v+1 (range ends inside it), which
+  // gemm_fixup_kernel sums in workgroup order (deterministic).
+  int my_tiles, sk_first = 0, sk_kt0 = 0, sk_tail = 0;
+  if (SK) {
+    const int total = n_tiles * nk;
+    const int S = (total + G - 1) / G;
+    const int s0 = v * S;
+    if (s0 >= total) return;
+    const int s1 = s0 + S < total ? s0 + S : total;
+    sk_first = s0 / nk;
+    sk_kt0 = s0 - sk_first * nk;
+    const int last = (s1 - 1) / nk;
+    my_tiles = last - sk_first + 1;
+    sk_tail = s1 - last * nk;  // == nk when the range ends on a tile boundary
+  } else {
+    my_tiles = (n_tiles - v + G - 1) / G;  // tiles v, v+G, v+2G, ...
+    if (my_tiles <= 0) return;
+  }
   if (dbg && tid == 0) {  // diagnostics only (tools/gemm_block_times.py): per-workgroup start/end on the 100 MHz clock
     dbg[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
     dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
     dbg[4 * blockIdx.x + 3] = my_tiles;
   }
-  const int total_steps = my_tiles * nk;
+  const int total_steps = SK ? (my_tiles - 1) * nk + sk_tail - sk_kt0 : my_tiles * nk;
+  // does this workgroup compute every k-step of its it-th tile?  (otherwise the segment is a partial: no bias, raw store)
+  auto seg_complete = [&](int it) {
+    if (!SK) return true;
+    return (it > 0 || sk_kt0 == 0) && (it < my_tiles - 1 || sk_tail == nk);
+  };
 
   auto tile_origin = [&](int it, int& m0, int& n0, int& split) {
-    const int item = v + it * G;
+    const int item = SK ? sk_first + it : v + it * G;
     const int tile = item / n_split;
     split = item - tile * n_split;
     const int tm = tile / tiles_n;
@@ -230,8 +255,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   };
 
   // ---- prologue: two steps in flight ------------------------------------------------------------------
-  int d_it = 0, d_kt = 0;  // DMA stream position (runs two steps ahead of the MFMAs)
+  int d_it = 0, d_kt = SK ? sk_kt0 : 0;  // DMA stream position (runs two steps ahead of the MFMAs)
   int d_stage = 0;
+  if (SK && sk_kt0 != 0) dma_set_tile(0);  // a range that begins inside a tile
   auto dma_part = [&](int part) {  // part 0 also moves to the next tile's row pointers when needed
     if (part == 0 && d_kt == 0) dma_set_tile(d_it);
     issue_dma_part(part, d_kt, d_stage);
@@ -249,13 +275,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   }
   __builtin_amdgcn_s_barrier();
   read_bias(0, bn0, bn1);
+  if (SK && !seg_complete(0)) { bn0 = 0.f; bn1 = 0.f; }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[a][0][r] = bn0; acc[a][1][r] = bn1; }
   Frags fa = read_frags(0, 0), fb;  // ping-pong fragment registers: 4 chunk reads per step, so fa is "current" at every step start
 
-  int c_it = 0, c_kt = 0;  // MFMA stream position
+  int c_it = 0, c_kt = SK ? sk_kt0 : 0;  // MFMA stream position
   int stage = 0;
   unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
 #define GSTAMP(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); t_acc[k] += t_now - t_prev; t_prev = t_now; __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -288,7 +315,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     GSTAMP(1);  // wait for own DMA + LDS reads
     __builtin_amdgcn_s_barrier();
     GSTAMP(2);  // barrier
-    if (bias_step) read_bias(c_it + 1, bn0, bn1);
+    if (bias_step) {
+      read_bias(c_it + 1, bn0, bn1);
+      if (SK && !seg_complete(c_it + 1)) { bn0 = 0.f; bn1 = 0.f; }
+    }
     GSTAMP(3);
     if (step + 1 < total_steps) fa = read_frags(next_stage, 0);
     mfma_chunk(fb);
@@ -296,17 +326,34 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     GSTAMP(4);  // chunk 3: 16 MFMAs + next step's first fragment read
     stage = next_stage;
 
-    if (++c_kt == nk) {
+    if (++c_kt == nk || (SK && step == total_steps - 1)) {
       // ---- epilogue of tile c_it (the next tile's first fragments are already in registers, its next two
       // k-steps are in flight).  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
       int m0, n0, split;
       tile_origin(c_it, m0, n0, split);
       const bool interior = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
       float* Yt = Y + (int64_t)split * slab_stride;
+      const bool partial = SK && !seg_complete(c_it);
+      if (partial) {  // raw accumulators into this workgroup's head / tail slot (a whole BMxBN image, no guards)
+        float* P = partials + (size_t)(2 * v + (c_it == 0 ? 0 : 1)) * (BM * BN);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            float* pp = P + (wm * 64 + a * 32 + 4 * lh) * BN + wn * 64 + b * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2)) * BN] = acc[a][b][r];
+          }
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+          if (partial) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = b == 0 ? bn0 : bn1;
+            continue;
+          }
           const int n = n0 + wn * 64 + b * 32 + lr;
           const int mb = m0 + wm * 64 + a * 32 + 4 * lh;
           float* yp = Yt + (int64_t)mb * ldy + n;
@@ -348,6 +395,51 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
 }
 
 int g_n_cu = 0;
+
+constexpr int FIXUP_CHUNKS = 16;
+// Second half of a stream-K launch: FIXUP_CHUNKS workgroups per output tile.  A tile whose k-steps were all computed by one
+// workgroup was stored by it; otherwise the segments' raw partial images are summed in workgroup order, then
+// bias / add-source / activation are applied exactly as the main kernel's epilogue does.
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict__ partials, int S, int nk,
+                                                         const float* __restrict__ bias, const float* __restrict__ R,
+                                                         int64_t ldr, float* __restrict__ Y, int64_t ldy, int M, int N,
+                                                         int tiles_n) {
+  const int t = blockIdx.x / FIXUP_CHUNKS, chunk = blockIdx.x - t * FIXUP_CHUNKS;  // a workgroup sums BM/FIXUP_CHUNKS rows of a tile
+  const int lo = t * nk, hi = lo + nk;
+  const int v_first = lo / S, v_last = (hi - 1) / S;
+  if (v_first == v_last) return;
+  const int tm = t / tiles_n;
+  const int m0 = tm * BM, n0 = (t - tm * tiles_n) * BN;
+  const int c4 = (threadIdx.x & 31) * 4;
+  float bv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bv[e] = (bias && n0 + c4 + e < N) ? bias[n0 + c4 + e] : 0.f;
+  const int r_end = (chunk + 1) * (BM / FIXUP_CHUNKS);
+  for (int rr = chunk * (BM / FIXUP_CHUNKS) + (threadIdx.x >> 5); rr < r_end; rr += 8) {
+    const int m = m0 + rr;
+    if (m >= M) break;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int v = v_first; v <= v_last; ++v) {
+      const size_t slot = (size_t)(2 * v + (v * S >= lo ? 0 : 1));
+      acc += *reinterpret_cast<const f32x4*>(partials + slot * (BM * BN) + rr * BN + c4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + c4 + e;
+      if (n < N) {
+        float val = acc[e] + bv[e];
+        if (R) val += R[(int64_t)m * ldr + n];
+        if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+        if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
+        Y[(int64_t)m * ldy + n] = val;
+      }
+    }
+  }
+}
+
+thread_local float* t_gemm_scratch = nullptr;
+thread_local size_t t_gemm_scratch_bytes = 0;
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s slabs[s*stride + i] : the deterministic second half of a split-K product
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int n_slabs,
@@ -412,6 +504,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU) return stlt_set_error(STLT_EINVAL, "gemm: unknown activation %d", act);
   if (n_split < 1 || (K / BK) % n_split != 0) return stlt_set_error(STLT_EINVAL, "gemm: n_split=%d must divide K/32=%lld", n_split, (long long)(K / BK));
   if (transA && !transB) return stlt_set_error(STLT_EINVAL, "gemm: the (transA, !transB) layout is not built");
+  if (n_split > 1 && (bias || act != STLT_ACT_NONE || r)) return stlt_set_error(STLT_EINVAL, "gemm: a split product takes no bias / activation / add-source");
   if ((transA || transB) && (act != STLT_ACT_NONE || bias)) return stlt_set_error(STLT_EINVAL, "gemm: bias/activation only with the forward (NT) layout");
   if (M == 0) return 0;
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -420,8 +513,39 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   int64_t n_wg = tiles_m * tiles_n * n_split;
   if (n_wg > n_cu()) n_wg = n_cu();
   StltProfScope ps(STLT_K_GEMM, s);
-  dim3 grid((unsigned)n_wg), block(GEMM_THREADS);
-#define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, g_stlt_debug_buf)
+  dim3 block(GEMM_THREADS);
+  // Stream-K when whole tiles would leave CUs idle (fewer tiles than CUs, or a ragged last round) and the caller
+  // lent scratch for the partial tiles (StltGemmScratch / stlt_gemm_set_scratch).
+  const int64_t n_tiles = tiles_m * tiles_n, nk = K / BK;
+  const int64_t rounds = (n_tiles + n_cu() - 1) / n_cu();
+  const double fill = (double)n_tiles / (double)(rounds * n_cu());
+  if (n_split == 1 && t_gemm_scratch && fill < 0.9 && n_tiles * nk < 0x7fffffffLL && !g_stlt_debug_buf) {
+    int64_t G = n_cu() < STLT_GEMM_SK_MAX_WG ? n_cu() : STLT_GEMM_SK_MAX_WG;
+    if (n_tiles * nk < 4 * G) G = (n_tiles * nk + 3) / 4;  // at least ~4 k-steps per workgroup
+    if (t_gemm_scratch_bytes >= (size_t)(2 * G) * BM * BN * sizeof(float)) {
+      const int S = (int)((n_tiles * nk + G - 1) / G);
+      dim3 grid((unsigned)G);
+      float* P = t_gemm_scratch;
+#define LAUNCH_SK(ACTV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr)
+      if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
+      else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
+      else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
+      else if (act == STLT_ACT_GELU) LAUNCH_SK(STLT_ACT_GELU, false, false, false);
+      else if (act == STLT_ACT_RELU) LAUNCH_SK(STLT_ACT_RELU, false, false, false);
+      else LAUNCH_SK(STLT_ACT_NONE, false, false, false);
+#undef LAUNCH_SK
+      if (int e = stlt_check_launch("gemm_nt_kernel(stream-k)")) return e;
+      dim3 fgrid((unsigned)(n_tiles * FIXUP_CHUNKS)), fblock(256);
+#define FIX(ACTV) hipLaunchKernelGGL((gemm_fixup_kernel<ACTV>), fgrid, fblock, 0, s, P, S, (int)nk, bias, r, ldr, c, ldc, (int)M, (int)N, (int)tiles_n)
+      if (act == STLT_ACT_GELU) FIX(STLT_ACT_GELU);
+      else if (act == STLT_ACT_RELU) FIX(STLT_ACT_RELU);
+      else FIX(STLT_ACT_NONE);
+#undef FIX
+      return stlt_check_launch("gemm_fixup_kernel");
+    }
+  }
+  dim3 grid((unsigned)n_wg);
+#define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
   else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
@@ -431,6 +555,19 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   else LAUNCH(STLT_ACT_NONE, false, false, false, false);
 #undef LAUNCH
   return stlt_check_launch("gemm_nt_kernel");
+}
+
+StltGemmScratch::StltGemmScratch(void* p, size_t bytes) : prev_(t_gemm_scratch), prev_bytes_(t_gemm_scratch_bytes) {
+  t_gemm_scratch = static_cast<float*>(p);
+  t_gemm_scratch_bytes = p ? bytes : 0;
+}
+StltGemmScratch::~StltGemmScratch() {
+  t_gemm_scratch = prev_;
+  t_gemm_scratch_bytes = prev_bytes_;
+}
+void stlt_gemm_set_scratch_impl(void* p, size_t bytes) {
+  t_gemm_scratch = static_cast<float*>(p);
+  t_gemm_scratch_bytes = p ? bytes : 0;
 }
 
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s) {

@@ -27,6 +27,7 @@ struct Tape {
   LayerTape tp[64];
   float* tp_out;
   float *h0, *u0, *z1, *z2;
+  float* sk;  // stream-K partial tiles (not part of the record: scratch of the forward's GEMM launches)
   size_t bytes;
 };
 
@@ -47,6 +48,7 @@ static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, 
   for (int64_t l = 0; l < n_tp; ++l) take_layer(t.tp[l], t.btp);
   t.tp_out = take(t.btp, d);
   t.h0 = take(t.bp, d); t.u0 = take(t.bp, d); t.z1 = take(t.bp, d); t.z2 = take(t.bp, d);
+  t.sk = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)), 1);
   t.bytes = off;
   return t;
 }
@@ -59,6 +61,7 @@ struct Scratch {
   float *hA, *hB;                   // head: (bp,d) x2
   float* slabs;
   float* red;
+  float* sk;
   size_t slab_floats, bytes;
 };
 
@@ -79,6 +82,7 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   const int64_t eb = embed_bwd_scratch_floats(B * T * N, C, d);
   if (eb > red) red = eb;
   s.red = take(red);
+  s.sk = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
   s.bytes = off;
   return s;
 }
@@ -197,6 +201,7 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
   const Tape t = tape_layout((char*)tape_mem, B, T, N, d, p->n_spatial, p->n_temporal);
   if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
   const int64_t tok = B * T * N, BT = B * T;
+  StltGemmScratch gemm_scratch(t.sk, STLT_GEMM_SCRATCH_BYTES);
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
   const StltDrop dr = stlt_drop_make(dropout_p, dropout_seed);
   float* x0 = p->n_spatial > 0 ? t.sp[0].x : t.sp_out;
@@ -234,6 +239,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   const Scratch sc = scratch_layout((char*)scratch_mem, B, T, N, d, p->n_categories);
   if (scratch_bytes < sc.bytes) return stlt_set_error(STLT_EWORKSPACE, "scratch %zu B < required %zu B", scratch_bytes, sc.bytes);
   const int64_t tok = B * T * N, BT = B * T;
+  StltGemmScratch gemm_scratch(sc.sk, STLT_GEMM_SCRATCH_BYTES);
   const StltDrop dr = stlt_drop_make(dropout_p, dropout_seed);
   auto W = [](const float* q) { return const_cast<float*>(q); };
 

@@ -79,6 +79,28 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: 
     return out
 
 
+class gemm_scratch:
+    """Context manager: lend the calling thread's `linear` / `gemm` launches a scratch buffer so that under-filled
+    launches run as stream-K (include/stlt_hip.h: stlt_gemm_set_scratch).  The whole-path calls do this themselves."""
+
+    def __init__(self, device="cuda"):
+        self.device = device
+        self.buf = None
+
+    def __enter__(self):
+        lib = L.load()
+        n = lib.stlt_gemm_scratch_bytes()
+        self.buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        L.check(lib.stlt_gemm_set_scratch(self.buf.data_ptr(), n), "stlt_gemm_set_scratch")
+        return self
+
+    def __exit__(self, *exc):
+        L.check(L.load().stlt_gemm_set_scratch(None, 0), "stlt_gemm_set_scratch")
+        torch.cuda.synchronize()  # the buffer may still be read by enqueued fix-up kernels
+        self.buf = None
+        return False
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
          add: Optional[torch.Tensor] = None, n_split: int = 1, k: Optional[int] = None):
     """c = opA(a) @ opB(b) (+ add) on the f32-MFMA kernel (backward layouts of nn.Linear).  a: (M,K) or (K,M) if trans_a;

@@ -191,3 +191,55 @@ def test_linear_relu(pkg):
     y = pkg.ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=2).cpu()
     ref = torch.relu(x.double() @ w.double().t() + b.double())
     assert (y.double() - ref).abs().max().item() <= 2e-5
+
+
+# Stream-K: with scratch lent, under-filled launches are cut into equal k-step ranges and partial tiles are summed by
+# the fix-up kernel.  Shapes: fewer tiles than CUs, a ragged last round (1.3 rounds), ranges shorter than a tile
+# (many partials per tile), ragged M/N edges, and a launch small enough that the grid shrinks below the CU count.
+SK_SHAPES = [(2048, 768, 768), (2048, 768, 3072), (2048, 2304, 768), (14336, 768, 768), (64, 768, 768), (1000, 174, 256),
+             (300, 130, 96), (5000, 3072, 64), (1, 64, 32)]
+
+
+@pytest.mark.parametrize("M,N,K", SK_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_stream_k(pkg, M, N, K, act):
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3, scale=0.1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    plain = pkg.ops.linear(xd, wd, bd, act=act)
+    with pkg.ops.gemm_scratch():
+        y = pkg.ops.linear(xd, wd, bd, act=act)
+        again = pkg.ops.linear(xd, wd, bd, act=act)
+        nobias = pkg.ops.linear(xd, wd, None, act=act)
+    ref = x.double() @ w.double().t()
+    f = {0: lambda t: t, 1: O.gelu, 2: torch.relu}[act]
+    assert (y.cpu().double() - f(ref + b.double())).abs().max().item() <= 2e-5
+    assert (nobias.cpu().double() - f(ref)).abs().max().item() <= 2e-5
+    assert torch.equal(y, again)  # fixed summation order
+    assert (y - plain).abs().max().item() <= 1e-5  # same products, different association across the k-range cuts
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 3072), (2048, 3072, 768), (300, 200, 96), (57, 3072, 768)])
+def test_gemm_nn_stream_k_with_add_source(pkg, M, N, K):
+    a, b, r = _rand(M, K, seed=1), _rand(K, N, seed=2, scale=1 / math.sqrt(K)), _rand(M, N, seed=3)
+    ref = a.double() @ b.double()
+    with pkg.ops.gemm_scratch():
+        got = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_b=True).cpu()
+        got_r = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_b=True, add=r.to(DEV)).cpu()
+    assert (got.double() - ref).abs().max().item() <= 3e-5
+    assert (got_r.double() - (ref + r.double())).abs().max().item() <= 3e-5
+
+
+def test_gemm_tn_stream_k(pkg):
+    M, N, K = 768, 768, 2048  # 18 tiles: far fewer than CUs
+    a, b = _rand(K, M, seed=4), _rand(K, N, seed=5)
+    ref = a.double().t() @ b.double()
+    with pkg.ops.gemm_scratch():
+        got = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_a=True, trans_b=True).cpu()
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * math.sqrt(K)
+
+
+def test_gemm_scratch_too_small_is_rejected(pkg):
+    lib = pkg._lib.load()
+    buf = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    assert lib.stlt_gemm_set_scratch(buf.data_ptr(), 1024) != 0
+    assert lib.stlt_gemm_set_scratch(None, 0) == 0
