@@ -19,16 +19,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ b2, int64_t ldb,
                                                      const float* __restrict__ w, float eps, int64_t M, int d,
                                                      float* __restrict__ ds, int64_t ldds,
-                                                     float* __restrict__ partials /* [n_waves][2][d] */, StltDrop dr,
+                                                     float* __restrict__ partials /* [blocks][3][d] */, StltDrop dr,
                                                      uint32_t site_b2, float* __restrict__ ds_drop, uint32_t site_dy) {
+  __shared__ float red[3 * NV * 256];  // block-level sums of dw | db | column sums of the branch gradient
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * RW_WAVES;
-  f32x4 dw_acc[NV], db_acc[NV], wv[NV];
+  f32x4 dw_acc[NV], db_acc[NV], cs_acc[NV], wv[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     dw_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     db_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cs_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int e = (i * 64 + lane) * 4;
     wv[i] = e < d ? *reinterpret_cast<const f32x4*>(w + e) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -85,19 +87,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       if (e < d) {
         const f32x4 o = (g[i] - mg - x[i] * mgx) * rstd;
         *reinterpret_cast<f32x4*>(ds + row * ldds + e) = o;
-        if (ds_drop) *reinterpret_cast<f32x4*>(ds_drop + row * ldds + e) = stlt_drop4(dr, site_b2, (uint64_t)row * d + e, o);  // gradient wrt the un-dropped b2
+        if (ds_drop) {
+          const f32x4 od = stlt_drop4(dr, site_b2, (uint64_t)row * d + e, o);  // gradient wrt the un-dropped b2
+          *reinterpret_cast<f32x4*>(ds_drop + row * ldds + e) = od;
+          cs_acc[i] += od;
+        } else {
+          cs_acc[i] += o;
+        }
       }
     }
   }
-  if (partials && gw < n_waves) {
+  if (partials) {  // the block's waves add their register partials in wave order (deterministic), one partial row set per block
+    const int wave = threadIdx.x >> 6;
+    for (int w = 0; w < RW_WAVES; ++w) {
+      if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int e = (i * 64 + lane) * 4;
-      if (e < d) {
-        *reinterpret_cast<f32x4*>(partials + (gw * 2 + 0) * d + e) = dw_acc[i];
-        *reinterpret_cast<f32x4*>(partials + (gw * 2 + 1) * d + e) = db_acc[i];
+        for (int i = 0; i < NV; ++i) {
+          const int e = (i * 64 + lane) * 4;
+          if (e < d) {
+            f32x4* r0 = reinterpret_cast<f32x4*>(red + e);
+            f32x4* r1 = reinterpret_cast<f32x4*>(red + d + e);
+            f32x4* r2 = reinterpret_cast<f32x4*>(red + 2 * d + e);
+            if (w == 0) { *r0 = dw_acc[i]; *r1 = db_acc[i]; *r2 = cs_acc[i]; }
+            else { *r0 += dw_acc[i]; *r1 += db_acc[i]; *r2 += cs_acc[i]; }
+          }
+        }
       }
+      __syncthreads();
     }
+    for (int e = threadIdx.x * 4; e < 3 * d; e += 256 * 4)
+      *reinterpret_cast<f32x4*>(partials + (int64_t)blockIdx.x * 3 * d + e) = *reinterpret_cast<const f32x4*>(red + e);
   }
 }
 
@@ -141,26 +160,60 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   }
 }
 
+// du = dh * gelu'(u) on an (M, N) matrix with the column sums of du (the bias gradient of the producing Linear)
+// accumulated on the way: a block owns 1024 columns x a row range, thread = 4 columns.
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const float* __restrict__ dh, const float* __restrict__ u,
+                                                              float* __restrict__ du, int64_t M, int N, int64_t rows_per_block,
+                                                              float* __restrict__ partials, StltDrop dr, uint32_t site) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= N) return;
+  const int64_t m0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int64_t m = m0; m < m1; ++m) {
+    const int64_t i = m * N + c;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dh + i);
+    if (dr.thr) g = stlt_drop4(dr, site, (uint64_t)i, g);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(u + i);
+    const f32x4 o = {g.x * gelu_grad(v.x), g.y * gelu_grad(v.y), g.z * gelu_grad(v.z), g.w * gelu_grad(v.w)};
+    *reinterpret_cast<f32x4*>(du + i) = o;
+    acc += o;
+  }
+  *reinterpret_cast<f32x4*>(partials + (int64_t)blockIdx.y * N + c) = acc;
+}
+
 // ------------------------------------------------------------------ attention core backward
-// One 256-thread block per (token group, head); a group = whole sequences totalling GL <= 64 tokens (floor(64/L)
-// sequences when L <= 32, one sequence when 32 < L <= 64).  Everything lives in LDS as fp32; P is recomputed.
+// One 256-thread block per (token group, head); a group = whole sequences totalling GL tokens (floor(32/L) sequences
+// when L <= 32, one sequence when 32 < L <= 64).  Attention never crosses sequences, so scores / dS are stored per
+// row as L columns (the row's own sequence) and every inner loop runs over L keys.  Operands live in dynamic LDS as
+// fp32 (29-41 KB at L = 7 / 32: several blocks per CU); P is recomputed.
 //   dV = P^T dO ; dP = dO V^T ; dS = P * (dP - rowsum(P*dP)) ; dQ = scale dS K ; dK = scale dS^T Q
-constexpr int AB_MAXL = 64, AB_DH = 64, AB_LD = AB_DH + 1, AB_PLD = AB_MAXL + 1;
+constexpr int AB_MAXL = 64, AB_DH = 64, AB_LD = AB_DH + 1;
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                        const uint8_t* __restrict__ kpm, int causal, int64_t n_tokens,
                                                        int L, int H, int GL, float scale, float* __restrict__ dqkv,
-                                                       StltDrop dr, uint32_t site) {
-  __shared__ float Qs[AB_MAXL * AB_LD], Ks[AB_MAXL * AB_LD], Vs[AB_MAXL * AB_LD], Gs[AB_MAXL * AB_LD];
-  __shared__ float Ps[AB_MAXL * AB_PLD], Ds[AB_MAXL * AB_PLD];
-  __shared__ int meta[AB_MAXL];
+                                                       StltDrop dr, uint32_t site, int64_t n_groups,
+                                                       float* __restrict__ cs_partials /* nullable: [chunks][3*H*64] */) {
+  extern __shared__ float ab_smem[];
+  const int PLD = L + 1;
+  float* Qs = ab_smem;
+  float* Ks = Qs + GL * AB_LD;
+  float* Vs = Ks + GL * AB_LD;
+  float* Gs = Vs + GL * AB_LD;
+  float* Ps = Gs + GL * AB_LD;
+  float* Ds = Ps + GL * PLD;
+  int* keep = reinterpret_cast<int*>(Ds + GL * PLD);  // 1 = key token is real
   const int tid = threadIdx.x;
   const int head = blockIdx.x % H;
-  const int64_t g = blockIdx.x / H;
-  const int64_t tok0 = g * GL;
-  const int gv = (int)((n_tokens - tok0) < GL ? (n_tokens - tok0) : GL);
   const int d = H * AB_DH;
   const int64_t ld = 3 * (int64_t)d;
+  const int64_t chunk = blockIdx.x / H, n_chunks = gridDim.x / H;
+  float cq = 0.f, ck = 0.f, cv = 0.f;  // column sums of dq/dk/dv over this thread's rows (channel tid&63): in-proj bias gradient
+  for (int64_t g = chunk; g < n_groups; g += n_chunks) {
+  const int64_t tok0 = g * GL;
+  const int gv = (int)((n_tokens - tok0) < GL ? (n_tokens - tok0) : GL);
   // load Q, K, V, dO (rows >= gv are zero)
   for (int idx = tid; idx < GL * AB_DH; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
@@ -172,18 +225,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     Qs[r * AB_LD + c] = q; Ks[r * AB_LD + c] = k; Vs[r * AB_LD + c] = v; Gs[r * AB_LD + c] = go;
   }
-  if (tid < GL) {
-    int m = -1;
-    if (tid < gv && kpm[tok0 + tid] == 0) { const int s = tid / L; m = (s << 16) | (tid - s * L); }
-    meta[tid] = m;
-  }
+  if (tid < GL) keep[tid] = (tid < gv && kpm[tok0 + tid] == 0) ? 1 : 0;
   __syncthreads();
-  // scores and dP for every (i, j) pair of the group
-  for (int p = tid; p < GL * GL; p += 256) {
-    const int i = p / GL, j = p - i * GL;
-    const int mk = meta[j];
-    const int qs = i / L, qp = i - qs * L;
-    const bool ok = mk >= 0 && (mk >> 16) == qs && (!causal || (mk & 0xffff) <= qp);
+  // scores and dP for every (query i, key position jj of i's sequence)
+  for (int p = tid; p < GL * L; p += 256) {
+    const int i = p / L, jj = p - i * L;
+    const int s0 = (i / L) * L, qp = i - s0;
+    const int j = s0 + jj;
+    const bool ok = keep[j] && (!causal || jj <= qp);
     float s = 0.f, dp = 0.f;
 #pragma unroll 8
     for (int c = 0; c < AB_DH; ++c) {
@@ -191,54 +240,69 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       dp += Gs[i * AB_LD + c] * Vs[j * AB_LD + c];
     }
     if (dr.thr) {  // dPd -> dP: the forward multiplied P by the dropout mask before the P·V product
-      const uint64_t idx = ((((uint64_t)(tok0 + i)) * H + head) << 8) | (uint64_t)((j - (j / L) * L) & 0xff);
+      const uint64_t idx = ((((uint64_t)(tok0 + i)) * H + head) << 8) | (uint64_t)(jj & 0xff);
       dp = stlt_keep(dr, site, idx) ? dp * dr.scale : 0.f;
     }
-    Ps[i * AB_PLD + j] = ok ? s * scale : -1e30f;
-    Ds[i * AB_PLD + j] = dp;
+    Ps[i * PLD + jj] = ok ? s * scale : -1e30f;
+    Ds[i * PLD + jj] = dp;
   }
   __syncthreads();
   // row softmax, D_i, dS (in place: Ps <- P, Ds <- dS)
   if (tid < GL) {
     const int i = tid;
     float m = -1e30f;
-    for (int j = 0; j < GL; ++j) m = fmaxf(m, Ps[i * AB_PLD + j]);
+    for (int j = 0; j < L; ++j) m = fmaxf(m, Ps[i * PLD + j]);
     float l = 0.f;
-    for (int j = 0; j < GL; ++j) {
-      const float s = Ps[i * AB_PLD + j];
+    for (int j = 0; j < L; ++j) {
+      const float s = Ps[i * PLD + j];
       const float e = s > -1e29f ? expf(s - m) : 0.f;
-      Ps[i * AB_PLD + j] = e;
+      Ps[i * PLD + j] = e;
       l += e;
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     float dsum = 0.f;
-    for (int j = 0; j < GL; ++j) {
-      const float pj = Ps[i * AB_PLD + j] * inv;
-      Ps[i * AB_PLD + j] = pj;
-      dsum += pj * Ds[i * AB_PLD + j];
+    for (int j = 0; j < L; ++j) {
+      const float pj = Ps[i * PLD + j] * inv;
+      Ps[i * PLD + j] = pj;
+      dsum += pj * Ds[i * PLD + j];
     }
-    for (int j = 0; j < GL; ++j) Ds[i * AB_PLD + j] = Ps[i * AB_PLD + j] * (Ds[i * AB_PLD + j] - dsum);
+    for (int j = 0; j < L; ++j) Ds[i * PLD + j] = Ps[i * PLD + j] * (Ds[i * PLD + j] - dsum);
   }
   __syncthreads();
   // dQ, dK, dV: thread owns (row r, channel c); consecutive threads -> consecutive channels (coalesced stores)
   for (int idx = tid; idx < GL * AB_DH; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     if (r >= gv) continue;
+    const int s0 = (r / L) * L, rp = r - s0;
     float dq = 0.f, dk = 0.f, dv = 0.f;
-    for (int j = 0; j < GL; ++j) {
-      dq += Ds[r * AB_PLD + j] * Ks[j * AB_LD + c];   // sum_j dS[r][j] K[j][c]
-      dk += Ds[j * AB_PLD + r] * Qs[j * AB_LD + c];   // sum_i dS[i][r] Q[i][c]
-      float pd = Ps[j * AB_PLD + r];                  // P[i=j][key r] (dropped like in the forward for dV)
+    for (int jj = 0; jj < L; ++jj) {
+      const int j = s0 + jj;
+      dq += Ds[r * PLD + jj] * Ks[j * AB_LD + c];   // sum_j dS[r][j] K[j][c]
+      dk += Ds[j * PLD + rp] * Qs[j * AB_LD + c];   // sum_i dS[i][r] Q[i][c]
+      float pd = Ps[j * PLD + rp];                  // P[query j][key r] (dropped like in the forward for dV)
       if (dr.thr) {
-        const uint64_t idx = ((((uint64_t)(tok0 + j)) * H + head) << 8) | (uint64_t)((r - (r / L) * L) & 0xff);
+        const uint64_t idx = ((((uint64_t)(tok0 + j)) * H + head) << 8) | (uint64_t)(rp & 0xff);
         pd = stlt_keep(dr, site, idx) ? pd * dr.scale : 0.f;
       }
-      dv += pd * Gs[j * AB_LD + c];                   // sum_i Pd[i][r] dO[i][c]
+      dv += pd * Gs[j * AB_LD + c];                 // sum_i Pd[i][r] dO[i][c]
     }
     float* out = dqkv + (tok0 + r) * ld + head * AB_DH + c;
     out[0] = dq * scale;
     out[d] = dk * scale;
     out[2 * d] = dv;
+    cq += dq * scale; ck += dk * scale; cv += dv;
+  }
+  __syncthreads();  // LDS is reloaded by the next group
+  }
+  if (cs_partials) {  // the 4 row classes (tid>>6) of a channel are added in order through LDS
+    float* red = ab_smem;
+    red[tid] = cq; red[256 + tid] = ck; red[512 + tid] = cv;
+    __syncthreads();
+    if (tid < 192) {
+      const int which = tid >> 6, c = tid & 63;
+      const float* r = red + which * 256 + c;
+      cs_partials[chunk * 3 * d + which * d + head * AB_DH + c] = ((r[0] + r[64]) + r[128]) + r[192];
+    }
   }
 }
 
@@ -369,26 +433,25 @@ inline int nv_for(int64_t d) { return (int)((d + 255) / 256); }
 
 // ds = dLN(dy; s = a (+ b2)); parameter gradients ACCUMULATE into g_w / g_b (either may be null).
 // scratch: >= ln_bwd_scratch_floats(d) floats.
-int64_t ln_bwd_scratch_floats(int64_t d) { return 1024 * 2 * d; }
+int64_t ln_bwd_scratch_floats(int64_t d) { return 512 * 3 * d; }
 
 int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
                   float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
-                  hipStream_t s, StltDrop dr, uint32_t site_b2, float* ds_drop, uint32_t site_dy) {
+                  hipStream_t s, StltDrop dr, uint32_t site_b2, float* ds_drop, uint32_t site_dy, float* g_colsum) {
   if (!dy || !a || !w || !ds || !scratch) return stlt_set_error(STLT_EINVAL, "ln_bwd: null pointer");
   if (d <= 0 || d % 4 || d > 2048) return stlt_set_error(STLT_EINVAL, "ln_bwd: bad d=%lld", (long long)d);
   if (M == 0) return 0;
-  int64_t blocks = (M + 64 * RW_WAVES - 1) / (64 * RW_WAVES);  // ~64 rows per persistent wave
-  if (blocks < 16) blocks = M >= 16 * RW_WAVES ? 16 : (M + RW_WAVES - 1) / RW_WAVES;
-  if (blocks > 256) blocks = 256;  // at most 1024 persistent waves (scratch is sized for that)
-  const int64_t n_waves = blocks * RW_WAVES;
+  int64_t blocks = (M + 16 * RW_WAVES - 1) / (16 * RW_WAVES);  // ~16 rows per persistent wave
+  if (blocks > 512) blocks = 512;  // one partial row set per block (scratch is sized for that)
   StltProfScope ps(STLT_K_ADDLN, s);
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
                                             ldb, w, eps, M, (int)d, ds, ldds, scratch, dr, site_b2,
                                             (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy));
   if (int e = stlt_check_launch("ln_bwd_kernel")) return e;
-  // partial rows are interleaved [wave][dw|db][d]: two strided reductions
-  if (g_w) { if (int e = launch_reduce_slabs(scratch, 2 * d, (int)n_waves, g_w, d, 1, s)) return e; }
-  if (g_b) { if (int e = launch_reduce_slabs(scratch + d, 2 * d, (int)n_waves, g_b, d, 1, s)) return e; }
+  // partial rows are interleaved [block][dw|db|colsum][d]: strided reductions
+  if (g_w) { if (int e = launch_reduce_slabs(scratch, 3 * d, (int)blocks, g_w, d, 1, s)) return e; }
+  if (g_b) { if (int e = launch_reduce_slabs(scratch + d, 3 * d, (int)blocks, g_b, d, 1, s)) return e; }
+  if (g_colsum) { if (int e = launch_reduce_slabs(scratch + 2 * d, 3 * d, (int)blocks, g_colsum, d, 1, s)) return e; }
   return 0;
 }
 
@@ -414,6 +477,20 @@ int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop
   return stlt_check_launch("gelu_fwd_kernel");
 }
 
+int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
+                           hipStream_t s, StltDrop dr, uint32_t site) {
+  if (!dh || !u || !du || !g_colsum || !scratch) return stlt_set_error(STLT_EINVAL, "gelu_bwd: null pointer");
+  if (N % 4 || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gelu: column count must be a multiple of 4");
+  if (M == 0 || N == 0) return 0;
+  int64_t rows = 32;
+  if ((M + rows - 1) / rows > 512) rows = (M + 511) / 512;  // at most 512 partial rows (scratch >= 512*N floats)
+  const int64_t parts = (M + rows - 1) / rows;
+  hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)((N + 1023) / 1024), (unsigned)parts), dim3(256), 0, s, dh, u, du, M, (int)N,
+                     rows, scratch, dr, site);
+  if (int e = stlt_check_launch("gelu_bwd_colsum_kernel")) return e;
+  return launch_reduce_slabs(scratch, N, (int)parts, g_colsum, N, 1, s);
+}
+
 int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr, uint32_t site) {
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
@@ -424,19 +501,29 @@ int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipSt
 }
 
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
-                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr, uint32_t site) {
+                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr, uint32_t site, float* g_colsum, float* scratch) {
   if (!qkv || !dctx || !kpm || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
   if (dh != AB_DH) return stlt_set_error(STLT_EINVAL, "attn_bwd: head dim must be 64");
   if (L <= 0 || L > AB_MAXL)
     return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld); training with longer layouts is not built yet", AB_MAXL, (long long)L);
   if (S == 0) return 0;
-  const int P = (int)(AB_MAXL / L);
+  const int P = L <= 32 ? (int)(32 / L) : 1;
   const int GL = P * (int)L;
   const int64_t groups = (S + P - 1) / P;
-  if (groups * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "attn_bwd: too many groups");
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(groups * H)), dim3(256), 0, s, qkv, dctx, kpm, causal, S * L, (int)L, (int)H,
-                     GL, 1.0f / sqrtf((float)dh), dqkv, dr, site);
-  return stlt_check_launch("attn_bwd_kernel");
+  if (g_colsum && !scratch) return stlt_set_error(STLT_EINVAL, "attn_bwd: column sums need scratch");
+  int64_t chunks = groups < 256 ? groups : 256;  // persistent blocks per head (scratch >= 256 * 3 * H * dh floats)
+  const size_t lds = ((size_t)4 * GL * AB_LD + (size_t)2 * GL * (L + 1) + GL) * sizeof(float);
+  static bool lds_opt_in = false;  // > 64 KB of dynamic LDS (one 64-token sequence: 100 KB) needs the attribute
+  if (!lds_opt_in) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
+      return stlt_set_error((int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    lds_opt_in = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(chunks * H)), dim3(256), lds, s, qkv, dctx, kpm, causal, S * L, (int)L, (int)H,
+                     GL, 1.0f / sqrtf((float)dh), dqkv, dr, site, groups, g_colsum ? scratch : (float*)nullptr);
+  if (int e = stlt_check_launch("attn_bwd_kernel")) return e;
+  if (g_colsum) return launch_reduce_slabs(scratch, 3 * H * dh, (int)chunks, g_colsum, 3 * H * dh, 1, s);
+  return 0;
 }
 
 int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d) {

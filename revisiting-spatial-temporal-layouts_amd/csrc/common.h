@@ -106,13 +106,16 @@ int64_t ln_bwd_scratch_floats(int64_t d);
 int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
                   float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
                   hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site_b2 = 0, float* ds_drop = nullptr,
-                  uint32_t site_dy = 0);
+                  uint32_t site_dy = 0, float* g_colsum = nullptr);  // g_colsum += column sums of the branch gradient (ds_drop, else ds)
 int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g, float* scratch, hipStream_t s);
 int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
                     uint32_t site = 0);
+int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
+                           hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);  // scratch >= 512*N floats
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
-                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
+                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0,
+                    float* g_colsum = nullptr, float* scratch = nullptr);  // g_colsum (3*H*dh) += column sums of dqkv; scratch >= 256*3*H*dh floats
 int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d);
 int launch_embed_bwd(const float* dx, const int64_t* categories, const float* boxes, const float* scores, int64_t C,
                      int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,

@@ -78,7 +78,7 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   s.slab_floats = (size_t)MAX_SPLIT * 4 * d * d;
   s.slabs = take((int64_t)s.slab_floats);
   int64_t red = ln_bwd_scratch_floats(d);
-  if (64 * 4 * d > red) red = 64 * 4 * d;
+  if (512 * 4 * d > red) red = 512 * 4 * d;  // gelu_bwd column-sum partials (512 x 4d); attn_bwd needs 256 x 3d
   const int64_t eb = embed_bwd_scratch_floats(B * T * N, C, d);
   if (eb > red) red = eb;
   s.red = take(red);
@@ -127,29 +127,28 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
   float* br = dr.thr ? bufD : bufB;  // branch gradient (after the dropout mask)
   // y = LN2(x1 + drop(f))
   TRY(launch_ln_bwd(bufA, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm2_w),
-                    G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD));              // bufB = ds2, br = df
+                    G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0,
+                    G(&stlt_layer_params::lin2_b)));                                               // bufB = ds2, br = df; lin2_b += colsum(df)
   // f = h·W2ᵀ + b2
   TRY(weight_grad(br, d, t.h, 4 * d, Mp, G(&stlt_layer_params::lin2_w), sc, s));
-  if (float* gb = G(&stlt_layer_params::lin2_b)) TRY(launch_colsum_acc(br, d, M, d, gb, sc.red, s));
   TRY(launch_gemm(0, 1, br, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, M, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
   // h = drop(gelu(u))
-  TRY(launch_gelu_bwd(bufH, t.u, bufH, M * 4 * d, s, dr, site0 + 2));                             // bufH = du
+  if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_gelu_bwd_colsum(bufH, t.u, bufH, M, 4 * d, gb, sc.red, s, dr, site0 + 2));  // bufH = du; lin1_b += colsum(du)
+  else TRY(launch_gelu_bwd(bufH, t.u, bufH, M * 4 * d, s, dr, site0 + 2));
   // u = x1·W1ᵀ + b1
   TRY(weight_grad(bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w), sc, s));
-  if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_colsum_acc(bufH, 4 * d, M, 4 * d, gb, sc.red, s));
   TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, M, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x + drop(a))
   TRY(launch_ln_bwd(bufC, d, t.x, d, t.a, d, lp.norm1_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm1_w),
-                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufD));              // bufB = ds1, br = da
+                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufD, 0,
+                    G(&stlt_layer_params::out_proj_b)));                                           // bufB = ds1, br = da; out_proj_b += colsum(da)
   // a = ctx·Woᵀ + bo
   TRY(weight_grad(br, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w), sc, s));
-  if (float* gb = G(&stlt_layer_params::out_proj_b)) TRY(launch_colsum_acc(br, d, M, d, gb, sc.red, s));
   TRY(launch_gemm(0, 1, br, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
   // ctx = attention(qkv) with dropout on the probabilities
-  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0));             // bufQ = dqkv
+  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red));  // bufQ = dqkv; in_proj_b += colsum(dqkv)
   // qkv = x·Winᵀ + bin
   TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
-  if (float* gb = G(&stlt_layer_params::in_proj_b)) TRY(launch_colsum_acc(bufQ, 3 * d, M, 3 * d, gb, sc.red, s));
   TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, bufB, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
   return 0;
 }
