@@ -185,24 +185,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   const int sw = (lr >> 1) & 7;
   const int a_row = (wm * 64 + lr) * BK;         // k-contiguous image; + 32*BK for the second M tile
   const int b_row = (BM + wn * 64 + lr) * BK;    // + 32*BK for the second N tile
-  const int a_col = wm * 64 + lr;                // contraction-major image [32][BM]
-  const int b_col = BM * BK + wn * 64 + lr;      // contraction-major image [32][BN] behind the A image
+  const int a_col2 = wm * 64 + 2 * lr;           // contraction-major image [32][BM]: this lane's pair of rows
+  const int b_col2 = BM * BK + wn * 64 + 2 * lr; // contraction-major image [32][BN] behind the A image
   struct Frags { f32x4 a0, a1, b0, b1; };
   auto read_frags = [&](int stage, int c) {
     const float* s = smem + stage * STAGE_FLOATS;
     const int off = ((2 * c + lh) ^ sw) * 4;
     const int kk = 8 * c + 4 * lh;               // first of this lane's 4 contraction indices in the chunk
     Frags f;
-    if (TA) {
+    if (TA) {  // one ds_read_b64 = two adjacent m of one k: M-tile a holds rows wm*64 + 2*i + a (row-interleaved tiles)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { f.a0[e] = s[(kk + e) * BM + a_col]; f.a1[e] = s[(kk + e) * BM + a_col + 32]; }
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(s + (kk + e) * BM + a_col2);
+        f.a0[e] = t.x; f.a1[e] = t.y;
+      }
     } else {
       f.a0 = *reinterpret_cast<const f32x4*>(s + a_row + off);
       f.a1 = *reinterpret_cast<const f32x4*>(s + a_row + 32 * BK + off);
     }
-    if (TB) {
+    if (TB) {  // N-tile b holds columns wn*64 + 2*j + b
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { f.b0[e] = s[(kk + e) * BN + b_col]; f.b1[e] = s[(kk + e) * BN + b_col + 32]; }
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(s + (kk + e) * BN + b_col2);
+        f.b0[e] = t.x; f.b1[e] = t.y;
+      }
     } else {
       f.b0 = *reinterpret_cast<const f32x4*>(s + b_row + off);
       f.b1 = *reinterpret_cast<const f32x4*>(s + b_row + 32 * BK + off);
@@ -334,15 +340,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
       const bool interior = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
       float* Yt = Y + (int64_t)split * slab_stride;
       const bool partial = SK && !seg_complete(c_it);
+      // tile-local coordinates of accumulator (a, b, r): contraction-major operands interleave the two MFMA tiles
+      auto t_row = [&](int a, int r) { const int i = (r & 3) + 8 * (r >> 2) + 4 * lh; return TA ? wm * 64 + 2 * i + a : wm * 64 + a * 32 + i; };
+      auto t_col = [&](int b) { return TB ? wn * 64 + 2 * lr + b : wn * 64 + b * 32 + lr; };
       if (partial) {  // raw accumulators into this workgroup's head / tail slot (a whole BMxBN image, no guards)
         float* P = partials + (size_t)(2 * v + (c_it == 0 ? 0 : 1)) * (BM * BN);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            float* pp = P + (wm * 64 + a * 32 + 4 * lh) * BN + wn * 64 + b * 32 + lr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2)) * BN] = acc[a][b][r];
+            for (int r = 0; r < 16; ++r) P[t_row(a, r) * BN + t_col(b)] = acc[a][b][r];
           }
       }
 #pragma unroll
@@ -354,23 +362,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
             for (int r = 0; r < 16; ++r) acc[a][b][r] = b == 0 ? bn0 : bn1;
             continue;
           }
-          const int n = n0 + wn * 64 + b * 32 + lr;
-          const int mb = m0 + wm * 64 + a * 32 + 4 * lh;
+          const int n = n0 + t_col(b);
+          const int mb = m0 + t_row(a, 0);               // row of r = 0; rows advance by rstep * ((r&3) + 8*(r>>2))
+          constexpr int rstep = TA ? 2 : 1;
           float* yp = Yt + (int64_t)mb * ldy + n;
           const float* rp = ADD ? R + (int64_t)mb * ldr + n : nullptr;  // add-source (residual gradient)
           if (interior) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               float val = acc[a][b][r];
-              if (ADD) val += rp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldr];
+              if (ADD) val += rp[(int64_t)(rstep * ((r & 3) + 8 * (r >> 2))) * ldr];
               if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
               if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
-              yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = val;
+              yp[(int64_t)(rstep * ((r & 3) + 8 * (r >> 2))) * ldy] = val;
             }
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int row = (r & 3) + 8 * (r >> 2);
+              const int row = rstep * ((r & 3) + 8 * (r >> 2));
               float val = acc[a][b][r];
               if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
               if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);

@@ -100,10 +100,13 @@ static int n_cu_cached() {
   return n;
 }
 
-// g_w (n_out, k_in) += dYᵀ·X with dY (Mp, n_out), X (Mp, k_in): split the token contraction so the persistent grid is full
+// g_w (n_out, k_in) += dYᵀ·X with dY (Mp, n_out), X (Mp, k_in).  A weight matrix is only 18-72 output tiles, so the
+// launch runs as stream-K over the token contraction (every CU gets an equal share of k-steps; the fix-up adds the
+// partial tiles to g_w in a fixed order).  Without lent scratch it falls back to explicit split-K slabs.
 static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k_in, int64_t Mp, float* g_w, const Scratch& sc,
                        hipStream_t s) {
   if (!g_w) return 0;
+  if (sc.sk) return launch_gemm(1, 1, dy, n_out, x, k_in, nullptr, g_w, k_in, g_w, k_in, 0, n_out, k_in, Mp, 1, STLT_ACT_NONE, s);
   const int64_t tiles = ((n_out + 255) / 256) * ((k_in + 127) / 128);
   const int64_t steps = Mp / 32;
   int64_t want = (2 * n_cu_cached() + tiles - 1) / tiles;
