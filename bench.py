@@ -168,6 +168,25 @@ def main():
                                       "traffic": None, "launches_per_step": as_n, "us_per_launch": round(as_ms / max(as_n, 1) * 1e3, 2)},
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
         }
+        if world == 1:
+            # Same workload with STLT_FLAG_SKIP_PADDING (opt-in: only the real tokens / frames of the padded batch are
+            # computed; logits agree to ~3e-6).  Reported beside `value`, never as `value`: the reference computes the
+            # padded rows too, and `value` is priced on that schedule.
+            real_tok = int(((~cpu_batch["src_key_padding_mask_boxes"]) & (~cpu_batch["src_key_padding_mask_frames"])[:, :, None]).sum())
+            model.backbone.skip_padding = True
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sk_logits = step()
+            torch.cuda.synchronize(dev)
+            sk_s = (time.perf_counter() - t1) / args.steps
+            model.backbone.skip_padding = False
+            out["skip_padding"] = {"value": round(B / sk_s, 2), "unit": "clips/s", "ms_per_step": round(sk_s * 1e3, 4),
+                                   "real_token_frac": round(real_tok / (B * T * N), 4),
+                                   "real_frame_frac": round(float((~cpu_batch["src_key_padding_mask_frames"]).float().mean()), 4),
+                                   "logit_max_abs_diff_vs_padded": float((sk_logits - logits).abs().max())}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import stlt_oracle as O
             nb = min(8, B)

@@ -152,6 +152,9 @@ typedef struct {
 } stlt_inputs;
 
 #define STLT_FLAG_CLS_ONLY_LAST_SPATIAL 1 /* last spatial layer: Q/out-proj/FFN on the CLS rows only (the only rows read, models.py:79) */
+#define STLT_FLAG_SKIP_PADDING 4 /* stlt_forward with out_btd == NULL: compute the real (unmasked) tokens and frames only.  Same logits: a padded row is
+                                   masked as a key everywhere and never read as a query result.  Implies both flags above.  Needs collater-shaped
+                                   masks (slot 0 of a real frame unmasked, frame lengths-1 real); synchronises the stream once per call. */
 #define STLT_FLAG_LAST_ROW_ONLY_TEMPORAL 2 /* stlt_forward with out_btd == NULL: last temporal layer's out-proj/FFN on the rows at lengths-1 only (models.py:189-192) */
 
 /* bytes of scratch the whole-path calls need for this shape */

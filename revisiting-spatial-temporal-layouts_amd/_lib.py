@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("STLT_HIP_LIB") or os.path.join(HERE, "libstlt_hip.so"
 K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "frames_embed", "gather_last")
 FLAG_CLS_ONLY_LAST_SPATIAL = 1
 FLAG_LAST_ROW_ONLY_TEMPORAL = 2
+FLAG_SKIP_PADDING = 4
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _f = C.POINTER(C.c_float)

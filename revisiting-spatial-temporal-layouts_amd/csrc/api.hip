@@ -156,7 +156,7 @@ int stlt_gather_last_fwd(const float* x, const int64_t* lengths, int64_t B, int6
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t x, x1, qkv, ctx, tmp, hh, head, sk, total;
+  size_t x, x1, qkv, ctx, tmp, hh, head, sk, ridx, total;
 };
 
 static WsLayout ws_layout(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes) {
@@ -173,6 +173,7 @@ static WsLayout ws_layout(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_
   w.hh = take(tok * 4 * d * f);
   w.head = take((size_t)B * (3 * d + n_classes) * f);
   w.sk = take(STLT_GEMM_SCRATCH_BYTES);  // stream-K partial tiles of under-filled GEMM launches
+  w.ridx = take(ragged_index_bytes(B, T, N));  // STLT_FLAG_SKIP_PADDING: index of the real tokens / frames
   w.total = off;
   return w;
 }
@@ -294,6 +295,91 @@ static int backbone_impl(const stlt_params* p, const stlt_inputs* in, void* work
   return 0;
 }
 
+// One encoder layer over M compacted rows cut into variable-length segments (ragged.hip): same arithmetic as
+// encoder_layer, attention restricted to the row's own segment (no padded keys exist).
+static int encoder_layer_ragged(const stlt_layer_params& lp, int64_t d, int64_t H, const float* x, int64_t M, const int* seg_start,
+                                const int* seg_end, int causal, int kid, float* qkv, float* ctx, float* tmp, float* x1,
+                                float* hh, float* out, hipStream_t s) {
+  TRY(launch_linear(x, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
+  TRY(launch_attn_ragged(qkv, seg_start, seg_end, causal, M, H, d / H, ctx, kid, s));
+  TRY(launch_linear(ctx, d, lp.out_proj_w, lp.out_proj_b, tmp, d, M, d, d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(tmp, d, x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, x1, d, s));
+  TRY(launch_linear(x1, d, lp.lin1_w, lp.lin1_b, hh, 4 * d, M, 4 * d, d, STLT_ACT_GELU, s));
+  TRY(launch_linear(hh, 4 * d, lp.lin2_w, lp.lin2_b, tmp, d, M, d, 4 * d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(tmp, d, x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, M, d, out, d, s));
+  return 0;
+}
+
+// The tail of an encoder layer (out-proj, norm1, FFN, norm2) on n rows picked out of the layer's attention output
+// and input: what the layer computes for rows whose output is the only thing read afterwards.
+static int encoder_tail_rows(const stlt_layer_params& lp, int64_t d, const float* ctx, const float* x, const int* rows, int64_t n,
+                             float* g_ctx, float* g_res, float* g_x1, float* tmp, float* hh, float* out, hipStream_t s) {
+  TRY(launch_gather_rows(ctx, d, rows, n, d, g_ctx, s));
+  TRY(launch_gather_rows(x, d, rows, n, d, g_res, s));
+  TRY(launch_linear(g_ctx, d, lp.out_proj_w, lp.out_proj_b, tmp, d, n, d, d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(tmp, d, g_res, d, lp.norm1_w, lp.norm1_b, 1e-5f, n, d, g_x1, d, s));
+  TRY(launch_linear(g_x1, d, lp.lin1_w, lp.lin1_b, hh, 4 * d, n, 4 * d, d, STLT_ACT_GELU, s));
+  TRY(launch_linear(hh, 4 * d, lp.lin2_w, lp.lin2_b, tmp, d, n, d, 4 * d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(tmp, d, g_x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, n, d, out, d, s));
+  return 0;
+}
+
+// Stlt.forward up to the rows the head reads, computed on the real tokens / frames only (STLT_FLAG_SKIP_PADDING).
+// Synchronises the stream once, to read the two row counts the launches are sized by.
+static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* workspace, const WsLayout& w, float* h0, hipStream_t s) {
+  const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
+  char* base = (char*)workspace;
+  float* x = (float*)(base + w.x);
+  float* x1 = (float*)(base + w.x1);
+  float* qkv = (float*)(base + w.qkv);
+  float* ctx = (float*)(base + w.ctx);
+  float* tmp = (float*)(base + w.tmp);
+  float* hh = (float*)(base + w.hh);
+  const RaggedIndex ix = ragged_index_carve(base + w.ridx, B, T, N);
+  TRY(launch_ragged_index(in->kpm_boxes, in->kpm_frames, in->lengths, B, T, N, ix, s));
+  int counts[4] = {0, 0, 0, 0};
+  if (hipError_t e = hipMemcpyAsync(counts, ix.counts, sizeof(counts), hipMemcpyDeviceToHost, s); e != hipSuccess)
+    return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
+  if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess)
+    return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
+  if (counts[2] != 0)
+    return stlt_set_error(STLT_EINVAL, "skip-padding needs collater-shaped masks: slot 0 of every real frame unmasked and frame lengths-1 real (datasets.py:247-288)");
+  const int64_t Ms = counts[0], Mf = counts[1];
+  TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
+                   p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, Ms, d, x, s, nullptr, StltDrop{0u, 1.0f, 0ull}, ix.t_orig));
+  // spatial transformer: segments = frames; after it only each frame's CLS row is read (models.py:79)
+  for (int64_t l = 0; l + 1 < p->n_spatial; ++l)
+    TRY(encoder_layer_ragged(p->spatial[l], d, H, x, Ms, ix.t_seg_start, ix.t_seg_end, 0, STLT_K_ATTN_SPATIAL, qkv, ctx, tmp, x1, hh, x, s));
+  float* cls = ctx;  // (Mf, d)
+  if (p->n_spatial > 0) {
+    const stlt_layer_params& lp = p->spatial[p->n_spatial - 1];
+    TRY(launch_linear(x, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, Ms, 3 * d, d, STLT_ACT_NONE, s));
+    TRY(launch_attn_ragged(qkv, ix.t_seg_start, ix.t_seg_end, 0, Ms, H, d / H, ctx, STLT_K_ATTN_SPATIAL, s));
+    // qkv is dead once ctx exists: it holds the gathered rows; the layer output lands in ctx's first Mf rows
+    // (ctx rows are read by the gather before anything is written back)
+    TRY(encoder_tail_rows(lp, d, ctx, x, ix.f_cls_row, Mf, qkv, qkv + (size_t)Mf * d, x1, tmp, hh, qkv + (size_t)2 * Mf * d, s));
+    cls = qkv + (size_t)2 * Mf * d;
+  } else {
+    TRY(launch_gather_rows(x, d, ix.f_cls_row, Mf, d, ctx, s));
+  }
+  // frames embedding on the real frames (position / frame type looked up through the frame's place in the padded batch)
+  float* tbuf = x1;
+  TRY(launch_frames_embed(cls, d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b, p->ln_eps, B, T,
+                          d, tbuf, s, nullptr, StltDrop{0u, 1.0f, 0ull}, ix.f_orig, Mf));
+  // temporal transformer: segments = clips, causal
+  for (int64_t l = 0; l + 1 < p->n_temporal; ++l)
+    TRY(encoder_layer_ragged(p->temporal[l], d, H, tbuf, Mf, ix.f_seg_start, ix.f_seg_end, 1, STLT_K_ATTN_TEMPORAL, qkv, ctx, tmp, x, hh, tbuf, s));
+  if (p->n_temporal > 0) {
+    const stlt_layer_params& lp = p->temporal[p->n_temporal - 1];
+    TRY(launch_linear(tbuf, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, Mf, 3 * d, d, STLT_ACT_NONE, s));
+    TRY(launch_attn_ragged(qkv, ix.f_seg_start, ix.f_seg_end, 1, Mf, H, d / H, ctx, STLT_K_ATTN_TEMPORAL, s));
+    TRY(encoder_tail_rows(lp, d, ctx, tbuf, ix.last_row, B, x, qkv, qkv + (size_t)B * d, tmp, hh, h0, s));  // qkv is dead once ctx exists
+  } else {
+    TRY(launch_gather_rows(tbuf, d, ix.last_row, B, d, h0, s));
+  }
+  return 0;
+}
+
 // exported to caf.hip (same library, C++ linkage)
 int backbone_impl_public(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes, int flags,
                          float* out_btd, hipStream_t s) {
@@ -329,7 +415,9 @@ int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, s
   float* h1 = h0 + (size_t)B * d;
   float* h2 = h1 + (size_t)B * d;
   const bool last_only = (flags & STLT_FLAG_LAST_ROW_ONLY_TEMPORAL) && !out_btd && p->n_temporal > 0 && in->T > 1;
-  if (last_only) {  // the caller does not want the (B,T,d) backbone output: produce only the rows the head reads
+  if ((flags & STLT_FLAG_SKIP_PADDING) && !out_btd) {  // padded rows are never computed, so there is no (B,T,d) output to hand back
+    TRY(forward_ragged(p, in, workspace, w, h0, s));
+  } else if (last_only) {  // the caller does not want the (B,T,d) backbone output: produce only the rows the head reads
     TRY(backbone_impl(p, in, workspace, workspace_bytes, flags, bb_out, h0, s));
   } else {
     TRY(backbone_impl(p, in, workspace, workspace_bytes, flags, bb_out, nullptr, s));

@@ -76,12 +76,32 @@ struct AttnGeo {
   int64_t ldq, ldkv;             // row strides in floats
   int64_t nq_tokens, nk_tokens;  // S*Lq, S*Lk
   int Lq, Lk, GLq, GLk, ntq, ntk, H, causal;
+  // Ragged mode (VARLEN kernels): self-attention over nq_tokens compacted rows cut into variable-length segments;
+  // seg_start[row] / seg_end[row] = first row / one past the last row of the row's segment.  A query tile is 32
+  // consecutive rows whatever the segment boundaries; its keys are the rows from its first query's segment start to
+  // its last query's segment end, walked in 32-row tiles; the mask is "same segment" (+ key row <= query row).
+  const int* seg_start; const int* seg_end;
 };
 
+template <bool VARLEN>
 __device__ __forceinline__ StepGeo step_geo(int64_t item, int kt, const AttnGeo& a) {
   StepGeo s;
   s.head = (int)(item % a.H);
   const int64_t tile_id = item / a.H;
+  if (VARLEN) {
+    s.qb = 0;
+    s.q_tok0 = 0;
+    s.k_tok0 = 0;
+    s.q_first = (int)tile_id * TILE;
+    const int left = (int)a.nq_tokens - s.q_first;
+    s.q_rows = left < TILE ? left : TILE;
+    const int klo = a.seg_start[s.q_first];
+    const int khi = a.causal ? s.q_first + s.q_rows : a.seg_end[s.q_first + s.q_rows - 1];
+    s.k_first = klo + kt * TILE;
+    s.k_rows = khi - s.k_first < TILE ? khi - s.k_first : TILE;
+    s.kt_end = (khi - klo + TILE - 1) / TILE;
+    return s;
+  }
   const int64_t g = tile_id / a.ntq;
   s.qb = (int)(tile_id % a.ntq);
   s.q_tok0 = g * a.GLq;
@@ -96,7 +116,7 @@ __device__ __forceinline__ StepGeo step_geo(int64_t item, int kt, const AttnGeo&
   return s;
 }
 
-template <bool STAMP>
+template <bool STAMP, bool VARLEN>
 __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo geo,
                                                                   const uint8_t* __restrict__ kpm,
                                                                   int64_t n_items, float scale,
@@ -126,29 +146,39 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo 
 
   f32x4 qf[8], kf[8];
   int kt = 0, buf = 0;
-  uint8_t pad;
+  int pad;    // fixed-L: the key's padding byte; ragged: the key row's segment start
+  int qseg = 0;  // ragged: this lane's query row's segment start
   {  // prologue: first step's loads
-    const StepGeo s0 = step_geo(item, 0, geo);
+    const StepGeo s0 = step_geo<VARLEN>(item, 0, geo);
     frag_load(qf, gq + (s0.q_tok0 + s0.q_first) * ldq + s0.head * DH, ldq, s0.q_rows, li, lh);
     frag_load(kf, gk + (s0.k_tok0 + s0.k_first) * ldkv + s0.head * DH, ldkv, s0.k_rows, li, lh);
     tile_dma(smem, gv + (s0.k_tok0 + s0.k_first) * ldkv + s0.head * DH, ldkv, s0.k_rows, lane);
-    pad = kpm[s0.k_tok0 + s0.k_first + (li < s0.k_rows ? li : 0)];
+    if (VARLEN) {
+      pad = geo.seg_start[s0.k_first + (li < s0.k_rows ? li : 0)];
+      qseg = geo.seg_start[s0.q_first + (li < s0.q_rows ? li : 0)];
+    } else {
+      pad = kpm[s0.k_tok0 + s0.k_first + (li < s0.k_rows ? li : 0)];
+    }
   }
 
   f32x16 o0, o1;
   float m_run = -1e30f, l_run = 0.f;
 
   for (;;) {
-    const StepGeo s = step_geo(item, kt, geo);
+    const StepGeo s = step_geo<VARLEN>(item, kt, geo);
     float* Vs = smem + buf * TILE_FLOATS;
     STAMP_AT(1);
     wave_mem_sync();  // this step's fragments + V tile have landed (and the previous item's stores retired)
     STAMP_AT(2);
     {
       // key metadata for the mask: -1 = masked/absent, else (sequence id << 16) | position in sequence
-      const int kj = s.k_first + li;
-      const int ks = kj / geo.Lk;
-      if (lane < TILE) kmeta[lane] = (li < s.k_rows && pad == 0) ? ((ks << 16) | (kj - ks * geo.Lk)) : -1;
+      if (VARLEN) {
+        if (lane < TILE) kmeta[lane] = li < s.k_rows ? pad : -1;  // segment start of the key row
+      } else {
+        const int kj = s.k_first + li;
+        const int ks = kj / geo.Lk;
+        if (lane < TILE) kmeta[lane] = (li < s.k_rows && pad == 0) ? ((ks << 16) | (kj - ks * geo.Lk)) : -1;
+      }
     }
     if (kt == 0) {
 #pragma unroll
@@ -173,13 +203,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo 
     int n_kt = kt + 1;
     if (n_kt >= s.kt_end) { n_item = item + stride; n_kt = 0; }
     const bool have_next = n_item < n_items;
-    uint8_t n_pad = 0;
+    int n_pad = 0, n_qseg = qseg;
     if (have_next) {
-      const StepGeo sn = step_geo(n_item, n_kt, geo);
+      const StepGeo sn = step_geo<VARLEN>(n_item, n_kt, geo);
       if (n_kt == 0) frag_load(qf, gq + (sn.q_tok0 + sn.q_first) * ldq + sn.head * DH, ldq, sn.q_rows, li, lh);
       frag_load(kf, gk + (sn.k_tok0 + sn.k_first) * ldkv + sn.head * DH, ldkv, sn.k_rows, li, lh);
       tile_dma(smem + (buf ^ 1) * TILE_FLOATS, gv + (sn.k_tok0 + sn.k_first) * ldkv + sn.head * DH, ldkv, sn.k_rows, lane);
-      n_pad = kpm[sn.k_tok0 + sn.k_first + (li < sn.k_rows ? li : 0)];
+      if (VARLEN) {
+        n_pad = geo.seg_start[sn.k_first + (li < sn.k_rows ? li : 0)];
+        if (n_kt == 0) n_qseg = geo.seg_start[sn.q_first + (li < sn.q_rows ? li : 0)];
+      } else {
+        n_pad = kpm[sn.k_tok0 + sn.k_first + (li < sn.k_rows ? li : 0)];
+      }
     }
     if (STAMP) asm volatile("" :: "v"(st[0]), "v"(st[15]));
     STAMP_AT(3);
@@ -198,7 +233,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       // valid key: meta >= 0, same sequence, position <= limit
-      const bool ok = (meta[r] >= 0) & ((meta[r] & ~0xffff) == q_hi) & ((meta[r] & 0xffff) <= pos_lim);
+      const bool ok = VARLEN ? ((meta[r] == qseg) & (s.k_first + (r & 3) + 8 * (r >> 2) + 4 * lh <= (causal ? qi : 0x7fffffff)))
+                             : ((meta[r] >= 0) & ((meta[r] & ~0xffff) == q_hi) & ((meta[r] & 0xffff) <= pos_lim));
       p[r] = ok ? st[r] * scale : -1e30f;
       m_tile = fmaxf(m_tile, p[r]);
     }
@@ -271,6 +307,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo 
     item = n_item;
     kt = n_kt;
     pad = n_pad;
+    qseg = n_qseg;
     buf ^= 1;
   }
 #undef STAMP_AT
@@ -298,6 +335,7 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
   g.Lq = (int)Lq; g.Lk = (int)Lk; g.GLq = P * (int)Lq; g.GLk = P * (int)Lk;
   g.ntq = (g.GLq + TILE - 1) / TILE; g.ntk = (g.GLk + TILE - 1) / TILE;
   g.H = (int)H; g.causal = causal;
+  g.seg_start = nullptr; g.seg_end = nullptr;
   const int64_t groups = (S + P - 1) / P;
   if (groups * g.ntq * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles");
   StltProfScope ps(kid, s);
@@ -310,7 +348,7 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false, false>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
       wg_per_cu = 1;
     if (getenv("STLT_DEBUG")) fprintf(stderr, "[stlt] attn: %d CUs, %d workgroups/CU of %d waves\n", n_cu, wg_per_cu, WAVES);
   }
@@ -319,9 +357,9 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
   dim3 grid((unsigned)n_wg);
   const float scale = 1.0f / sqrtf((float)dh);
   if (g_stlt_debug_buf && !getenv("STLT_GEMM_STAMP"))  // diagnostic build path only (tools/attn_stamps.py); never set by the product
-    hipLaunchKernelGGL(attn_core_kernel<true>, grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, g_stlt_debug_buf, dr, site);
+    hipLaunchKernelGGL((attn_core_kernel<true, false>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, g_stlt_debug_buf, dr, site);
   else
-    hipLaunchKernelGGL(attn_core_kernel<false>, grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, (unsigned long long*)nullptr, dr, site);
+    hipLaunchKernelGGL((attn_core_kernel<false, false>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, (unsigned long long*)nullptr, dr, site);
   return stlt_check_launch("attn_core_kernel");
 }
 
@@ -330,4 +368,38 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
   if (!qkv) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: null pointer");
   const int64_t d = H * dh;
   return launch_attn_general(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, kpm, causal, S, L, L, H, dh, ctx, kid, s, dr, site);
+}
+
+// Ragged self-attention over M compacted rows of a packed (M, 3*H*dh) buffer (see AttnGeo): every row is a real
+// token, so there is no key-padding mask.
+int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_end, int causal, int64_t M, int64_t H, int64_t dh,
+                       float* ctx, int kid, hipStream_t s) {
+  if (!qkv || !seg_start || !seg_end || !ctx) return stlt_set_error(STLT_EINVAL, "attn_ragged: null pointer");
+  if (dh != DH) return stlt_set_error(STLT_EINVAL, "attn_ragged: head dim %lld unsupported (kernel is built for dh=64)", (long long)dh);
+  if (H <= 0 || H > 65535 || M < 0 || M > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "attn_ragged: bad M/H");
+  if (M == 0) return 0;
+  const int64_t d = H * dh;
+  AttnGeo g;
+  g.q = qkv; g.k = qkv + d; g.v = qkv + 2 * d; g.ldq = 3 * d; g.ldkv = 3 * d;
+  g.nq_tokens = M; g.nk_tokens = M;
+  g.Lq = g.Lk = g.GLq = g.GLk = TILE; g.ntq = g.ntk = 1;
+  g.H = (int)H; g.causal = causal;
+  g.seg_start = seg_start; g.seg_end = seg_end;
+  const int64_t n_items = ((M + TILE - 1) / TILE) * H;
+  if (n_items > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "attn_ragged: too many tiles");
+  StltProfScope ps(kid, s);
+  static int n_cu = 0, wg_per_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false, true>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
+      wg_per_cu = 1;
+  }
+  int64_t n_wg = (n_items + WAVES - 1) / WAVES;
+  if (n_wg > (int64_t)wg_per_cu * n_cu) n_wg = (int64_t)wg_per_cu * n_cu;
+  hipLaunchKernelGGL((attn_core_kernel<false, true>), dim3((unsigned)n_wg), dim3(64 * WAVES), 0, s, g, (const uint8_t*)nullptr, n_items,
+                     1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, StltDrop{0u, 1.0f, 0ull}, 0u);
+  return stlt_check_launch("attn_core_kernel(ragged)");
 }

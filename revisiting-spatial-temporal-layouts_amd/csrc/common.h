@@ -65,7 +65,8 @@ inline StltDrop stlt_drop_make(float p, uint64_t seed) {
 int launch_embed(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
                  int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
                  const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
-                 float* out, hipStream_t s, float* pre_out = nullptr, StltDrop dr = StltDrop{0u, 1.0f, 0ull});
+                 float* out, hipStream_t s, float* pre_out = nullptr, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
+                 const int* src_index = nullptr);
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, int act, hipStream_t s);
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -98,9 +99,26 @@ int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
                          uint32_t site = 0);
 int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
                         const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
-                        int64_t d, float* out, hipStream_t s, float* pre_out = nullptr, StltDrop dr = StltDrop{0u, 1.0f, 0ull});
+                        int64_t d, float* out, hipStream_t s, float* pre_out = nullptr, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
+                        const int* src_index = nullptr, int64_t n_rows = 0);
 int launch_gather_last(const float* x, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* out,
                        hipStream_t s);
+
+// ragged layout (ragged.hip): index of the real tokens / frames of a padded batch, see RaggedIndex
+struct RaggedIndex {
+  int *t_seg_start, *t_seg_end, *t_orig;              // per compacted token row: its frame's first row, one past its last row; token index in the padded batch
+  int *f_seg_start, *f_seg_end, *f_orig, *f_cls_row;  // per compacted frame row: its clip's first / past-last frame row; frame index b*T+t; token row of its CLS object
+  int *last_row;                                      // per clip: compacted frame row of frame lengths[b]-1
+  int *clip_tok, *clip_frm, *clip_tok_off, *clip_frm_off;  // per clip: real tokens / frames and their exclusive prefix sums
+  int *counts;                                        // [0] real tokens, [1] real frames, [2] != 0: input breaks the collater contract
+};
+size_t ragged_index_bytes(int64_t B, int64_t T, int64_t N);
+RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N);
+int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, const int64_t* lengths, int64_t B, int64_t T,
+                        int64_t N, const RaggedIndex& idx, hipStream_t s);
+int launch_gather_rows(const float* src, int64_t ld, const int* rows, int64_t n, int64_t d, float* out, hipStream_t s);
+int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_end, int causal, int64_t M, int64_t H, int64_t dh,
+                       float* ctx, int kid, hipStream_t s);
 
 // backward kernels (backward.hip)
 int64_t ln_bwd_scratch_floats(int64_t d);

@@ -55,14 +55,16 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
                                                     const float* __restrict__ score_w,
                                                     const float* __restrict__ score_b, const float* __restrict__ ln_w,
                                                     const float* __restrict__ ln_b, float eps, int64_t n_tokens, int d,
-                                                    float* __restrict__ out, float* __restrict__ pre_out, StltDrop dr) {
+                                                    float* __restrict__ out, float* __restrict__ pre_out, StltDrop dr,
+                                                    const int* __restrict__ src_index) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= n_tokens) return;
-  int64_t cat = categories[row];
+  const int64_t src = src_index ? src_index[row] : row;  // ragged mode: output row -> token of the padded batch
+  int64_t cat = categories[src];
   cat = cat < 0 ? 0 : (cat >= n_categories ? n_categories - 1 : cat);  // never read outside the table
-  const f32x4 box = *reinterpret_cast<const f32x4*>(boxes + row * 4);
-  const float sc = scores ? scores[row] : 0.f;
+  const f32x4 box = *reinterpret_cast<const f32x4*>(boxes + src * 4);
+  const float sc = scores ? scores[src] : 0.f;
   const float* __restrict__ erow = cat_table + cat * d;
   f32x4 v[NV];
 #pragma unroll
@@ -125,12 +127,14 @@ __global__ __launch_bounds__(256) void frames_embed_kernel(const float* __restri
                                                            const float* __restrict__ type_table,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            float eps, int64_t BT, int T, int d,
-                                                           float* __restrict__ out, float* __restrict__ pre_out, StltDrop dr) {
+                                                           float* __restrict__ out, float* __restrict__ pre_out, StltDrop dr,
+                                                           const int* __restrict__ src_index) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= BT) return;
-  const int t = (int)(row % T);
-  int64_t ft = frame_types[row];
+  const int64_t src = src_index ? src_index[row] : row;  // ragged mode: output row -> frame b*T+t of the padded batch
+  const int t = (int)(src % T);
+  int64_t ft = frame_types[src];
   ft = ft < 0 ? 0 : (ft > 4 ? 4 : ft);  // frame_type_embedding has 5 rows (models.py:91)
   f32x4 v[NV];
 #pragma unroll
@@ -183,7 +187,7 @@ inline int check_d(int64_t d) {
 int launch_embed(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table,
                  int64_t n_categories, const float* box_w, const float* box_b, const float* score_w,
                  const float* score_b, const float* ln_w, const float* ln_b, float eps, int64_t n_tokens, int64_t d,
-                 float* out, hipStream_t s, float* pre_out, StltDrop dr) {
+                 float* out, hipStream_t s, float* pre_out, StltDrop dr, const int* src_index) {
   if (int e = check_d(d)) return e;
   if (!categories || !boxes || !cat_table || !box_w || !box_b || !ln_w || !ln_b || !out || n_categories <= 0)
     return stlt_set_error(STLT_EINVAL, "stlt_embed_fwd: null pointer / empty table");
@@ -193,7 +197,7 @@ int launch_embed(const int64_t* categories, const float* boxes, const float* sco
   dim3 grid((unsigned)((n_tokens + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((embed_kernel<NV>), grid, dim3(256), 0, s, categories, boxes, scores,
                                             cat_table, (int)n_categories, box_w, box_b, score_w, score_b, ln_w, ln_b,
-                                            eps, n_tokens, (int)d, out, pre_out, dr));
+                                            eps, n_tokens, (int)d, out, pre_out, dr, src_index));
   return stlt_check_launch("embed_kernel");
 }
 
@@ -212,17 +216,18 @@ int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
 
 int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
                         const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
-                        int64_t d, float* out, hipStream_t s, float* pre_out, StltDrop dr) {
+                        int64_t d, float* out, hipStream_t s, float* pre_out, StltDrop dr, const int* src_index, int64_t n_rows) {
   if (int e = check_d(d)) return e;
   if (!spatial || !frame_types || !pos_table || !type_table || !ln_w || !ln_b || !out)
     return stlt_set_error(STLT_EINVAL, "stlt_frames_embed_fwd: null pointer");
   if (row_stride % 4) return stlt_set_error(STLT_EINVAL, "stlt_frames_embed_fwd: row_stride must be a multiple of 4");
-  if (B * T == 0) return 0;
+  const int64_t rows = src_index ? n_rows : B * T;  // ragged mode: n_rows compacted frames
+  if (rows == 0) return 0;
   StltProfScope ps(STLT_K_FRAMES, s);
-  dim3 grid((unsigned)((B * T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((frames_embed_kernel<NV>), grid, dim3(256), 0, s, spatial, row_stride,
-                                            frame_types, pos_table, type_table, ln_w, ln_b, eps, B * T, (int)T, (int)d,
-                                            out, pre_out, dr));
+                                            frame_types, pos_table, type_table, ln_w, ln_b, eps, rows, (int)T, (int)d,
+                                            out, pre_out, dr, src_index));
   return stlt_check_launch("frames_embed_kernel");
 }
 

@@ -182,6 +182,10 @@ class StltBackbone(nn.Module):
         self.transformer = _EncoderStack(_EncoderLayerParams(config.hidden_size), config.num_temporal_layers)
         self.cls_only_last_spatial = True  # exact: only token 0 of the last spatial layer is read (models.py:79)
         self.last_row_only_temporal = True  # exact, Stlt.forward only: the head reads one row per clip (models.py:189-192)
+        # Stlt.forward (inference) only, off by default: compute the real tokens / frames of the padded batch only.
+        # Same logits (a padded row is masked as a key and never read); needs collater-shaped masks and costs one
+        # stream synchronisation per call (include/stlt_hip.h: STLT_FLAG_SKIP_PADDING).
+        self.skip_padding = False
         self._cache = None
         self._ws = _Workspace()
 
@@ -264,7 +268,8 @@ class StltBackbone(nn.Module):
 
     def _flags(self) -> int:
         return ((L.FLAG_CLS_ONLY_LAST_SPATIAL if self.cls_only_last_spatial else 0)
-                | (L.FLAG_LAST_ROW_ONLY_TEMPORAL if self.last_row_only_temporal else 0))
+                | (L.FLAG_LAST_ROW_ONLY_TEMPORAL if self.last_row_only_temporal else 0)
+                | (L.FLAG_SKIP_PADDING if self.skip_padding else 0))
 
     def _check_mode(self, grad_path: bool = False):
         if self.training and self.config.hidden_dropout_prob > 0 and not grad_path:

@@ -195,3 +195,87 @@ def test_inference_loop_counters_match_oracle(pkg):
     exp5 = sum(1 for j in range(8) if j % 3 != 2) + sum(1 for j in range(5) if j % 3 != 2)
     assert res["num_clips"] == n
     assert res["top1_accuracy"] == round(100.0 * exp1 / n, 2) and res["top5_accuracy"] == round(100.0 * exp5 / n, 2)
+
+
+# ---- STLT_FLAG_SKIP_PADDING: only the real tokens / frames are computed; logits must not move
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg2p", "cfg4"])
+def test_skip_padding_matches_reference_golden(pkg, name):
+    sd, batch, z, meta = golden_case(name)
+    m = _model(pkg, name, sd)
+    with torch.no_grad():
+        padded = m(_to(batch))["stlt"]
+        m.backbone.skip_padding = True
+        got = m(_to(batch))["stlt"]
+    err = np.abs(got.cpu().numpy() - z["logits"]).max()
+    print(f"{name} skip_padding: max|gpu-ref32|={err:.2e} max|skip-padded|={(got - padded).abs().max().item():.2e}")
+    assert err <= TOL
+    assert (got - padded).abs().max().item() <= 2e-5
+
+
+def test_skip_padding_edge_layouts(pkg):
+    """Clips of minimum length (2 frames), frames with no object besides CLS, fully dense clips, B=1, and a batch whose
+    real-token count is not a multiple of the 32-row attention tile."""
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5, gain=2.0)
+    m.load_state_dict(sd)
+    m = m.train(False).to(DEV)
+    cases = [pkg.synth.make_batch(5, c["T"], c["N"], seed=21, min_len=2),
+             pkg.synth.make_batch(3, c["T"], c["N"], seed=22, dense=True),
+             pkg.synth.make_batch(1, c["T"], c["N"], seed=23),
+             pkg.synth.make_batch(7, c["T"], c["N"], seed=24, min_len=2)]
+    empty = pkg.synth.make_batch(4, c["T"], c["N"], seed=25)
+    empty["categories"][:, :, 1:] = 0  # every frame holds the CLS object only
+    empty["boxes"][:, :, 1:] = 0
+    empty["src_key_padding_mask_boxes"] = empty["categories"] == 0
+    cases.append(empty)
+    for batch in cases:
+        with torch.no_grad():
+            m.backbone.skip_padding = False
+            padded = m(_to(batch))["stlt"]
+            m.backbone.skip_padding = True
+            got = m(_to(batch))["stlt"]
+        ref = O.stlt_forward(sd, batch, c["num_attention_heads"])["stlt"]
+        assert (got.cpu() - ref).abs().max().item() <= TOL
+        assert (got - padded).abs().max().item() <= 2e-5
+
+
+def test_skip_padding_rejects_masks_that_break_the_collater_contract(pkg):
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5))
+    m = m.train(False).to(DEV)
+    m.backbone.skip_padding = True
+    batch = pkg.synth.make_batch(3, c["T"], c["N"], seed=1)
+    bad = dict(batch)
+    bad["src_key_padding_mask_boxes"] = batch["src_key_padding_mask_boxes"].clone()
+    bad["src_key_padding_mask_boxes"][1, 0, 0] = True  # CLS slot of a real frame masked
+    with pytest.raises(pkg.StltHipError):
+        with torch.no_grad():
+            m(_to(bad))
+    bad = dict(batch)
+    bad["lengths"] = batch["lengths"].clone()
+    bad["src_key_padding_mask_frames"] = batch["src_key_padding_mask_frames"].clone()
+    bad["src_key_padding_mask_frames"][2, int(batch["lengths"][2]) - 1] = True  # the frame the head reads is padded
+    with pytest.raises(pkg.StltHipError):
+        with torch.no_grad():
+            m(_to(bad))
+    with torch.no_grad():
+        assert torch.isfinite(m(_to(batch))["stlt"]).all()  # the library is still usable after the rejections
+
+
+def test_skip_padding_full_size_cfg2(pkg):
+    name = "cfg2"
+    c = pkg.synth.CONFIGS[name]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234))
+    m = m.train(False).to(DEV)
+    batch = _to(pkg.synth.make_batch(256, c["T"], c["N"], seed=3))
+    with torch.no_grad():
+        padded = m(batch)["stlt"]
+        m.backbone.skip_padding = True
+        got = m(batch)["stlt"]
+        assert torch.equal(got, m(batch)["stlt"])  # deterministic
+    assert (got - padded).abs().max().item() <= 2e-5
