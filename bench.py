@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--batch", type=int, default=1024, help="clips per GPU per step (1024 makes every cfg2 GEMM a whole number of 256-tile rounds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-skip-padding", action="store_true", help="do not time the opt-in skip-padding variant after the main measurement (profiling runs)")
     ap.add_argument("--no-cls-only", action="store_true", help="dense schedule: run the last spatial / last temporal layer on every token")
     args = ap.parse_args()
 
@@ -168,7 +169,7 @@ def main():
                                       "traffic": None, "launches_per_step": as_n, "us_per_launch": round(as_ms / max(as_n, 1) * 1e3, 2)},
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
         }
-        if world == 1:
+        if world == 1 and not args.no_skip_padding:
             # Same workload with STLT_FLAG_SKIP_PADDING (opt-in: only the real tokens / frames of the padded batch are
             # computed; logits agree to ~3e-6).  Reported beside `value`, never as `value`: the reference computes the
             # padded rows too, and `value` is priced on that schedule.
