@@ -221,11 +221,15 @@ int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const floa
  * Attention backward supports sequences <= 64 tokens. */
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);
 size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories);
+/* flags: 0, or STLT_FLAG_SKIP_PADDING (the same value in both calls of a step): forward and reverse sweep run over the
+ * real tokens / frames only — same loss and gradients when dropout is off; with dropout the masks are drawn per
+ * compacted row, i.e. a different (equally valid) random stream than the padded schedule's.  Each call then
+ * synchronises the stream once. */
 int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape, size_t tape_bytes, float* logits,
-                       float dropout_p, uint64_t dropout_seed, stlt_stream_t stream);
+                       float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream);
 int stlt_train_backward(const stlt_params* p, const stlt_params* grads, const stlt_inputs* in, const void* tape,
                         size_t tape_bytes, void* scratch, size_t scratch_bytes, const float* dlogits,
-                        float dropout_p, uint64_t dropout_seed, stlt_stream_t stream);
+                        float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream);
 
 /* ---- per-kernel timing (bench.py roofline leg): hipEvents around every launch of the whole-path calls ---- */
 #define STLT_K_EMBED 0

@@ -96,9 +96,9 @@ SIGNATURES = {
     "stlt_caf_forward": (C.c_int, [C.c_void_p, C.POINTER(Inputs), _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp]),
     "stlt_train_tape_bytes": (C.c_size_t, [C.c_int64] * 6),
     "stlt_train_scratch_bytes": (C.c_size_t, [C.c_int64] * 5),
-    "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, _vp]),
+    "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
     "stlt_train_backward": (C.c_int, [C.POINTER(Params), C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp,
-                                      C.c_size_t, _vp, C.c_float, C.c_uint64, _vp]),
+                                      C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
     "stlt_prof_enable": (C.c_int, [C.c_int]),
     "stlt_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "stlt_debug_set_buffer": (C.c_int, [_vp]),

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo 
       const float v1 = vrow[swz(j, 8 + (li >> 2)) * 4];
       float pr = p[r];
       if (dr.thr) {  // train-mode dropout of the attention probabilities: the denominator keeps the undropped sum
-        const uint64_t idx = ((((uint64_t)(s.q_tok0 + qi)) * H + s.head) << 8) | (uint64_t)(meta[r] & 0xff);
+        // key position inside its sequence: fixed-L metadata carries it; ragged metadata is the segment's first row
+        const uint64_t kpos = VARLEN ? (uint64_t)((s.k_first + j - meta[r]) & 0xff) : (uint64_t)(meta[r] & 0xff);
+        const uint64_t idx = ((((uint64_t)(s.q_tok0 + qi)) * H + s.head) << 8) | kpos;
         pr = stlt_keep(dr, site, idx) ? pr * dr.scale : 0.f;
       }
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, pr, o0, 0, 0, 0);
@@ -373,7 +375,7 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
 // Ragged self-attention over M compacted rows of a packed (M, 3*H*dh) buffer (see AttnGeo): every row is a real
 // token, so there is no key-padding mask.
 int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_end, int causal, int64_t M, int64_t H, int64_t dh,
-                       float* ctx, int kid, hipStream_t s) {
+                       float* ctx, int kid, hipStream_t s, StltDrop dr, uint32_t site) {
   if (!qkv || !seg_start || !seg_end || !ctx) return stlt_set_error(STLT_EINVAL, "attn_ragged: null pointer");
   if (dh != DH) return stlt_set_error(STLT_EINVAL, "attn_ragged: head dim %lld unsupported (kernel is built for dh=64)", (long long)dh);
   if (H <= 0 || H > 65535 || M < 0 || M > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "attn_ragged: bad M/H");
@@ -400,6 +402,6 @@ int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_en
   int64_t n_wg = (n_items + WAVES - 1) / WAVES;
   if (n_wg > (int64_t)wg_per_cu * n_cu) n_wg = (int64_t)wg_per_cu * n_cu;
   hipLaunchKernelGGL((attn_core_kernel<false, true>), dim3((unsigned)n_wg), dim3(64 * WAVES), 0, s, g, (const uint8_t*)nullptr, n_items,
-                     1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, StltDrop{0u, 1.0f, 0ull}, 0u);
+                     1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, dr, site);
   return stlt_check_launch("attn_core_kernel(ragged)");
 }

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const uint8_t* __restrict__ kpm, int causal, int64_t n_tokens,
                                                        int L, int H, int GL, float scale, float* __restrict__ dqkv,
                                                        StltDrop dr, uint32_t site, int64_t n_groups,
-                                                       float* __restrict__ cs_partials /* nullable: [chunks][3*H*64] */) {
+                                                       float* __restrict__ cs_partials /* nullable: [chunks][3*H*64] */,
+                                                       const int* __restrict__ grp_ptr, const int* __restrict__ seg_start,
+                                                       const int* __restrict__ seg_end) {
+  // Ragged mode (grp_ptr != null): group g = rows [grp_ptr[g], grp_ptr[g+1]) of a compacted buffer (whole segments,
+  // at most GL rows); a row's sequence is [seg_start[row], seg_end[row]); L is the longest possible sequence.
   extern __shared__ float ab_smem[];
   const int PLD = L + 1;
   float* Qs = ab_smem;
@@ -205,6 +209,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   float* Ps = Gs + GL * AB_LD;
   float* Ds = Ps + GL * PLD;
   int* keep = reinterpret_cast<int*>(Ds + GL * PLD);  // 1 = key token is real
+  int* rs0 = keep + GL;                                // row -> first row of its sequence (group-local)
+  int* rlen = rs0 + GL;                                // row -> length of its sequence (0 for rows past the group)
   const int tid = threadIdx.x;
   const int head = blockIdx.x % H;
   const int d = H * AB_DH;
@@ -212,8 +218,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const int64_t chunk = blockIdx.x / H, n_chunks = gridDim.x / H;
   float cq = 0.f, ck = 0.f, cv = 0.f;  // column sums of dq/dk/dv over this thread's rows (channel tid&63): in-proj bias gradient
   for (int64_t g = chunk; g < n_groups; g += n_chunks) {
-  const int64_t tok0 = g * GL;
-  const int gv = (int)((n_tokens - tok0) < GL ? (n_tokens - tok0) : GL);
+  const int64_t tok0 = grp_ptr ? (int64_t)grp_ptr[g] : g * GL;
+  const int gv = grp_ptr ? grp_ptr[g + 1] - grp_ptr[g] : (int)((n_tokens - tok0) < GL ? (n_tokens - tok0) : GL);
   // load Q, K, V, dO (rows >= gv are zero)
   for (int idx = tid; idx < GL * AB_DH; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
@@ -225,14 +231,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     Qs[r * AB_LD + c] = q; Ks[r * AB_LD + c] = k; Vs[r * AB_LD + c] = v; Gs[r * AB_LD + c] = go;
   }
-  if (tid < GL) keep[tid] = (tid < gv && kpm[tok0 + tid] == 0) ? 1 : 0;
+  if (tid < GL) {
+    if (grp_ptr) {
+      keep[tid] = tid < gv ? 1 : 0;
+      rs0[tid] = tid < gv ? seg_start[tok0 + tid] - (int)tok0 : 0;
+      rlen[tid] = tid < gv ? seg_end[tok0 + tid] - seg_start[tok0 + tid] : 0;
+    } else {
+      keep[tid] = (tid < gv && kpm[tok0 + tid] == 0) ? 1 : 0;
+      rs0[tid] = (tid / L) * L;
+      rlen[tid] = L;
+    }
+  }
   __syncthreads();
   // scores and dP for every (query i, key position jj of i's sequence)
   for (int p = tid; p < GL * L; p += 256) {
     const int i = p / L, jj = p - i * L;
-    const int s0 = (i / L) * L, qp = i - s0;
-    const int j = s0 + jj;
-    const bool ok = keep[j] && (!causal || jj <= qp);
+    const int s0 = rs0[i], qp = i - s0;
+    const bool in_seq = jj < rlen[i];
+    const int j = in_seq ? s0 + jj : s0;
+    const bool ok = in_seq && keep[j] && (!causal || jj <= qp);
     float s = 0.f, dp = 0.f;
 #pragma unroll 8
     for (int c = 0; c < AB_DH; ++c) {
@@ -250,10 +267,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   // row softmax, D_i, dS (in place: Ps <- P, Ds <- dS)
   if (tid < GL) {
     const int i = tid;
+    const int Li = rlen[i];
     float m = -1e30f;
-    for (int j = 0; j < L; ++j) m = fmaxf(m, Ps[i * PLD + j]);
+    for (int j = 0; j < Li; ++j) m = fmaxf(m, Ps[i * PLD + j]);
     float l = 0.f;
-    for (int j = 0; j < L; ++j) {
+    for (int j = 0; j < Li; ++j) {
       const float s = Ps[i * PLD + j];
       const float e = s > -1e29f ? expf(s - m) : 0.f;
       Ps[i * PLD + j] = e;
@@ -261,21 +279,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     float dsum = 0.f;
-    for (int j = 0; j < L; ++j) {
+    for (int j = 0; j < Li; ++j) {
       const float pj = Ps[i * PLD + j] * inv;
       Ps[i * PLD + j] = pj;
       dsum += pj * Ds[i * PLD + j];
     }
-    for (int j = 0; j < L; ++j) Ds[i * PLD + j] = Ps[i * PLD + j] * (Ds[i * PLD + j] - dsum);
+    for (int j = 0; j < Li; ++j) Ds[i * PLD + j] = Ps[i * PLD + j] * (Ds[i * PLD + j] - dsum);
   }
   __syncthreads();
   // dQ, dK, dV: thread owns (row r, channel c); consecutive threads -> consecutive channels (coalesced stores)
   for (int idx = tid; idx < GL * AB_DH; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     if (r >= gv) continue;
-    const int s0 = (r / L) * L, rp = r - s0;
+    const int s0 = rs0[r], rp = r - s0, Lr = rlen[r];
     float dq = 0.f, dk = 0.f, dv = 0.f;
-    for (int jj = 0; jj < L; ++jj) {
+    for (int jj = 0; jj < Lr; ++jj) {
       const int j = s0 + jj;
       dq += Ds[r * PLD + jj] * Ks[j * AB_LD + c];   // sum_j dS[r][j] K[j][c]
       dk += Ds[j * PLD + rp] * Qs[j * AB_LD + c];   // sum_i dS[i][r] Q[i][c]
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ categories,
                                                         const float* __restrict__ boxes, const float* __restrict__ scores,
                                                         int C, int64_t n_tokens, int d, int64_t tok_per_block,
-                                                        float* __restrict__ partials) {
+                                                        float* __restrict__ partials, const int* __restrict__ src_index) {
   const int64_t t0 = (int64_t)blockIdx.x * tok_per_block;
   const int64_t t1 = t0 + tok_per_block < n_tokens ? t0 + tok_per_block : n_tokens;
   float* out = partials + (int64_t)blockIdx.x * (C + 7) * d;
@@ -321,11 +339,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     for (int k = 0; k < C; ++k) out[(int64_t)k * d + c] = 0.f;
     for (int64_t t = t0; t < t1; ++t) {
       const float g = dx[t * d + c];
-      const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + t * 4);
+      const int64_t src = src_index ? src_index[t] : t;  // ragged: gradient row -> token of the padded batch
+      const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + src * 4);
       bw0 += g * bx.x; bw1 += g * bx.y; bw2 += g * bx.z; bw3 += g * bx.w;
       bb += g;
-      if (scores) sw += g * scores[t];
-      int64_t cat = categories[t];
+      if (scores) sw += g * scores[src];
+      int64_t cat = categories[src];
       cat = cat < 0 ? 0 : (cat >= C ? C - 1 : cat);
       out[cat * d + c] += g;  // same thread owns this (row, channel): plain read-modify-write
     }
@@ -371,14 +390,18 @@ __global__ __launch_bounds__(256) void frames_bwd_scatter_kernel(const float* __
 
 __global__ __launch_bounds__(256) void frames_bwd_params_kernel(const float* __restrict__ ds,
                                                                 const int64_t* __restrict__ frame_types, int64_t B, int T,
-                                                                int d, float* __restrict__ g_pos, float* __restrict__ g_type) {
+                                                                int d, float* __restrict__ g_pos, float* __restrict__ g_type,
+                                                                const int* __restrict__ row_of /* ragged: frame b*T+t -> row of ds, -1 = padded */) {
   // grid.y = T position rows followed by 5 type rows; fixed summation order over clips
   const int row = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d) return;
   float acc = 0.f;
   if (row < T) {
-    for (int64_t b = 0; b < B; ++b) acc += ds[(b * T + row) * d + c];
+    for (int64_t b = 0; b < B; ++b) {
+      const int64_t r = row_of ? row_of[b * T + row] : b * T + row;
+      if (r >= 0) acc += ds[r * d + c];
+    }
     if (g_pos) g_pos[(int64_t)row * d + c] += acc;
   } else {
     const int ft = row - T;
@@ -386,7 +409,8 @@ __global__ __launch_bounds__(256) void frames_bwd_params_kernel(const float* __r
     for (int64_t i = 0; i < B * T; ++i) {
       int64_t v = frame_types[i];
       v = v < 0 ? 0 : (v > 4 ? 4 : v);
-      if (v == ft) acc += ds[i * d + c];
+      const int64_t r = row_of ? row_of[i] : i;
+      if (v == ft && r >= 0) acc += ds[r * d + c];
     }
     g_type[(int64_t)ft * d + c] += acc;
   }
@@ -501,26 +525,31 @@ int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipSt
 }
 
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
-                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr, uint32_t site, float* g_colsum, float* scratch) {
-  if (!qkv || !dctx || !kpm || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
+                    int64_t dh, float* dqkv, hipStream_t s, StltDrop dr, uint32_t site, float* g_colsum, float* scratch,
+                    const AttnBwdRagged* rg) {
+  if (!qkv || !dctx || (!kpm && !rg) || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
   if (dh != AB_DH) return stlt_set_error(STLT_EINVAL, "attn_bwd: head dim must be 64");
   if (L <= 0 || L > AB_MAXL)
     return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld); training with longer layouts is not built yet", AB_MAXL, (long long)L);
   if (S == 0) return 0;
   const int P = L <= 32 ? (int)(32 / L) : 1;
-  const int GL = P * (int)L;
-  const int64_t groups = (S + P - 1) / P;
+  const int GL = rg ? rg->max_rows : P * (int)L;
+  const int64_t groups = rg ? rg->n_groups : (S + P - 1) / P;
+  if (GL < 1 || GL > AB_MAXL) return stlt_set_error(STLT_EINVAL, "attn_bwd: group of %d rows unsupported", GL);
+  if (groups == 0) return 0;
   if (g_colsum && !scratch) return stlt_set_error(STLT_EINVAL, "attn_bwd: column sums need scratch");
   int64_t chunks = groups < 256 ? groups : 256;  // persistent blocks per head (scratch >= 256 * 3 * H * dh floats)
-  const size_t lds = ((size_t)4 * GL * AB_LD + (size_t)2 * GL * (L + 1) + GL) * sizeof(float);
+  const size_t lds = ((size_t)4 * GL * AB_LD + (size_t)2 * GL * (L + 1) + 3 * GL) * sizeof(float);
   static bool lds_opt_in = false;  // > 64 KB of dynamic LDS (one 64-token sequence: 100 KB) needs the attribute
   if (!lds_opt_in) {
     if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
       return stlt_set_error((int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     lds_opt_in = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(chunks * H)), dim3(256), lds, s, qkv, dctx, kpm, causal, S * L, (int)L, (int)H,
-                     GL, 1.0f / sqrtf((float)dh), dqkv, dr, site, groups, g_colsum ? scratch : (float*)nullptr);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(chunks * H)), dim3(256), lds, s, qkv, dctx, kpm, causal, rg ? rg->n_rows : S * L, (int)L,
+                     (int)H, GL, 1.0f / sqrtf((float)dh), dqkv, dr, site, groups, g_colsum ? scratch : (float*)nullptr,
+                     rg ? rg->grp_ptr : (const int*)nullptr, rg ? rg->seg_start : (const int*)nullptr,
+                     rg ? rg->seg_end : (const int*)nullptr);
   if (int e = stlt_check_launch("attn_bwd_kernel")) return e;
   if (g_colsum) return launch_reduce_slabs(scratch, 3 * H * dh, (int)chunks, g_colsum, 3 * H * dh, 1, s);
   return 0;
@@ -533,14 +562,14 @@ int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d) {
 
 int launch_embed_bwd(const float* dx, const int64_t* categories, const float* boxes, const float* scores, int64_t C,
                      int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,
-                     float* g_score_b, float* scratch, hipStream_t s) {
+                     float* g_score_b, float* scratch, hipStream_t s, const int* src_index) {
   if (!dx || !categories || !boxes || !scratch) return stlt_set_error(STLT_EINVAL, "embed_bwd: null pointer");
   if (n_tokens == 0) return 0;
   int64_t blocks = (n_tokens + 127) / 128;
   if (blocks > 512) blocks = 512;
   const int64_t tpb = (n_tokens + blocks - 1) / blocks;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dx, categories, boxes, scores, (int)C, n_tokens,
-                     (int)d, tpb, scratch);
+                     (int)d, tpb, scratch, src_index);
   if (int e = stlt_check_launch("embed_bwd_kernel")) return e;
   hipLaunchKernelGGL(embed_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)(C + 7)), dim3(256), 0, s, scratch,
                      (int)blocks, (int)C, (int)d, scores ? 1 : 0, g_cat, g_box_w, g_box_b, g_score_w, g_score_b);
@@ -548,13 +577,15 @@ int launch_embed_bwd(const float* dx, const int64_t* categories, const float* bo
 }
 
 int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
-                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s) {
-  if (!ds || !frame_types || !dx_spatial) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
+                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s, const int* row_of) {
+  if (!ds || !frame_types || (!dx_spatial && !row_of)) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
   if (B * T == 0) return 0;
-  hipLaunchKernelGGL(frames_bwd_scatter_kernel, dim3((unsigned)(B * T)), dim3(256), 0, s, ds, B * T, (int)N, (int)d, dx_spatial);
-  if (int e = stlt_check_launch("frames_bwd_scatter_kernel")) return e;
+  if (!row_of) {  // (ragged callers scatter the CLS rows themselves: launch_scatter_rows)
+    hipLaunchKernelGGL(frames_bwd_scatter_kernel, dim3((unsigned)(B * T)), dim3(256), 0, s, ds, B * T, (int)N, (int)d, dx_spatial);
+    if (int e = stlt_check_launch("frames_bwd_scatter_kernel")) return e;
+  }
   hipLaunchKernelGGL(frames_bwd_params_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)(T + 5)), dim3(256), 0, s, ds,
-                     frame_types, B, (int)T, (int)d, g_pos, g_type);
+                     frame_types, B, (int)T, (int)d, g_pos, g_type, row_of);
   return stlt_check_launch("frames_bwd_params_kernel");
 }
 

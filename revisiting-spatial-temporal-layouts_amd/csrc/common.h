@@ -109,16 +109,21 @@ struct RaggedIndex {
   int *t_seg_start, *t_seg_end, *t_orig;              // per compacted token row: its frame's first row, one past its last row; token index in the padded batch
   int *f_seg_start, *f_seg_end, *f_orig, *f_cls_row;  // per compacted frame row: its clip's first / past-last frame row; frame index b*T+t; token row of its CLS object
   int *last_row;                                      // per clip: compacted frame row of frame lengths[b]-1
-  int *clip_tok, *clip_frm, *clip_tok_off, *clip_frm_off;  // per clip: real tokens / frames and their exclusive prefix sums
+  int *clip_tok, *clip_frm, *clip_tok_off, *clip_frm_off;  // per clip: real tokens / frames and their exclusive prefix sums (clip_frm_off has B+1 entries)
+  int *f_row_of;                                      // per padded frame b*T+t: its compacted frame row, -1 if padded
+  int *sp_grp_ptr;                                    // training: token-row offsets of groups of `frames_per_group` whole frames (see launch_ragged_groups)
   int *counts;                                        // [0] real tokens, [1] real frames, [2] != 0: input breaks the collater contract
 };
+// sp_grp_ptr[g] = first token row of compacted frame g*frames_per_group (g = 0..n_groups), the last entry = n_tokens
+int launch_ragged_groups(const RaggedIndex& idx, int64_t n_tokens, int64_t n_frames, int frames_per_group, hipStream_t s);
+int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s);  // dst = 0; dst[rows[i]] = src[i]
 size_t ragged_index_bytes(int64_t B, int64_t T, int64_t N);
 RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N);
 int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, const int64_t* lengths, int64_t B, int64_t T,
                         int64_t N, const RaggedIndex& idx, hipStream_t s);
 int launch_gather_rows(const float* src, int64_t ld, const int* rows, int64_t n, int64_t d, float* out, hipStream_t s);
 int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_end, int causal, int64_t M, int64_t H, int64_t dh,
-                       float* ctx, int kid, hipStream_t s);
+                       float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 
 // backward kernels (backward.hip)
 int64_t ln_bwd_scratch_floats(int64_t d);
@@ -132,15 +137,17 @@ int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipSt
                     uint32_t site = 0);
 int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
                            hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);  // scratch >= 512*N floats
+// ragged attention backward: groups of whole segments (rows [grp_ptr[g], grp_ptr[g+1]), at most max_rows <= 64 each)
+struct AttnBwdRagged { const int* grp_ptr; const int* seg_start; const int* seg_end; int64_t n_groups; int64_t n_rows; int max_rows; };
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
                     int64_t dh, float* dqkv, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0,
-                    float* g_colsum = nullptr, float* scratch = nullptr);  // g_colsum (3*H*dh) += column sums of dqkv; scratch >= 256*3*H*dh floats
+                    float* g_colsum = nullptr, float* scratch = nullptr, const AttnBwdRagged* ragged = nullptr);  // ragged: L = longest possible segment  // g_colsum (3*H*dh) += column sums of dqkv; scratch >= 256*3*H*dh floats
 int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d);
 int launch_embed_bwd(const float* dx, const int64_t* categories, const float* boxes, const float* scores, int64_t C,
                      int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,
-                     float* g_score_b, float* scratch, hipStream_t s);
+                     float* g_score_b, float* scratch, hipStream_t s, const int* src_index = nullptr);
 int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
-                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s);
+                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s, const int* row_of = nullptr);
 int launch_scatter_last(const float* dh, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* dout, hipStream_t s);
 int launch_small_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk, int64_t sbn, float* c,
                       int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t s);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(1024) void ragged_scan_kernel(const int* __restrict
     if (t == 1023) { carry_a += s_a[1023]; carry_b += s_b[1023]; }
     __syncthreads();
   }
-  if (t == 0) { counts[0] = carry_a; counts[1] = carry_b; }
+  if (t == 0) { counts[0] = carry_a; counts[1] = carry_b; frm_off[B] = carry_b; }
 }
 
 // per clip: place its real frames / tokens.  thread t = frame t.
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void ragged_fill_kernel(const uint8_t* __restr
   const int frm0 = ix.clip_frm_off[b], n_frm = ix.clip_frm[b];
   const int row0 = ix.clip_tok_off[b] + s_tok[t] - cnt;  // first token row of this frame
   const int fr = frm0 + s_frm[t] - real;                  // this frame's row
+  if (t < T) ix.f_row_of[b * T + t] = real ? fr : -1;
   if (real) {
     ix.f_orig[fr] = (int)(b * T + t);
     ix.f_cls_row[fr] = row0;
@@ -116,6 +117,23 @@ __global__ __launch_bounds__(256) void ragged_fill_kernel(const uint8_t* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void ragged_groups_kernel(const int* __restrict__ f_cls_row, int n_tokens, int n_frames, int fpg,
+                                                            int n_groups, int* __restrict__ grp_ptr) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g > n_groups) return;
+  const int64_t f = (int64_t)g * fpg;
+  grp_ptr[g] = f < n_frames ? f_cls_row[f] : n_tokens;
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, int64_t n, int d,
+                                                           float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float* o = dst + (int64_t)rows[i] * d;
+  for (int e = lane * 4; e < d; e += 256) *reinterpret_cast<f32x4*>(o + e) = *reinterpret_cast<const f32x4*>(src + i * d + e);
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t ld, const int* __restrict__ rows,
                                                           int64_t n, int d, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -131,7 +149,7 @@ inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 size_t ragged_index_bytes(int64_t B, int64_t T, int64_t N) {
   const size_t tok = (size_t)B * T * N, bt = (size_t)B * T;
-  return 3 * al(tok * 4) + 4 * al(bt * 4) + 5 * al((size_t)B * 4) + 256;
+  return 3 * al(tok * 4) + 4 * al(bt * 4) + 4 * al((size_t)B * 4) + al((size_t)(B + 1) * 4) + al(bt * 4) + al((bt + 1) * 4) + 256;
 }
 
 RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N) {
@@ -141,7 +159,8 @@ RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N) {
   RaggedIndex ix;
   ix.t_seg_start = take(tok); ix.t_seg_end = take(tok); ix.t_orig = take(tok);
   ix.f_seg_start = take(bt); ix.f_seg_end = take(bt); ix.f_orig = take(bt); ix.f_cls_row = take(bt);
-  ix.last_row = take(B); ix.clip_tok = take(B); ix.clip_frm = take(B); ix.clip_tok_off = take(B); ix.clip_frm_off = take(B);
+  ix.last_row = take(B); ix.clip_tok = take(B); ix.clip_frm = take(B); ix.clip_tok_off = take(B); ix.clip_frm_off = take(B + 1);
+  ix.f_row_of = take(bt); ix.sp_grp_ptr = take(bt + 1);
   ix.counts = take(4);
   return ix;
 }
@@ -168,4 +187,22 @@ int launch_gather_rows(const float* src, int64_t ld, const int* rows, int64_t n,
   StltProfScope ps(STLT_K_GATHER, s);
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, src, ld, rows, n, (int)d, out);
   return stlt_check_launch("gather_rows_kernel");
+}
+
+int launch_ragged_groups(const RaggedIndex& ix, int64_t n_tokens, int64_t n_frames, int fpg, hipStream_t s) {
+  if (fpg < 1) return stlt_set_error(STLT_EINVAL, "ragged_groups: frames per group must be positive");
+  const int64_t n_groups = (n_frames + fpg - 1) / fpg;
+  hipLaunchKernelGGL(ragged_groups_kernel, dim3((unsigned)((n_groups + 256) / 256)), dim3(256), 0, s, ix.f_cls_row, (int)n_tokens,
+                     (int)n_frames, fpg, (int)n_groups, ix.sp_grp_ptr);
+  return stlt_check_launch("ragged_groups_kernel");
+}
+
+int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s) {
+  if (!src || !rows || !dst) return stlt_set_error(STLT_EINVAL, "scatter_rows: null pointer");
+  if (d % 4) return stlt_set_error(STLT_EINVAL, "scatter_rows: d must be a multiple of 4");
+  if (hipError_t e = hipMemsetAsync(dst, 0, (size_t)dst_rows * d * sizeof(float), s); e != hipSuccess)
+    return stlt_set_error((int)e, "scatter_rows: memset: %s", hipGetErrorString(e));
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, src, rows, n, (int)d, dst);
+  return stlt_check_launch("scatter_rows_kernel");
 }

@@ -28,6 +28,7 @@ struct Tape {
   float* tp_out;
   float *h0, *u0, *z1, *z2;
   float* sk;  // stream-K partial tiles (not part of the record: scratch of the forward's GEMM launches)
+  char* ridx;  // STLT_FLAG_SKIP_PADDING: the ragged index built by the forward, read again by the backward
   size_t bytes;
 };
 
@@ -49,6 +50,7 @@ static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, 
   t.tp_out = take(t.btp, d);
   t.h0 = take(t.bp, d); t.u0 = take(t.bp, d); t.z1 = take(t.bp, d); t.z2 = take(t.bp, d);
   t.sk = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)), 1);
+  t.ridx = (char*)take((int64_t)((ragged_index_bytes(B, T, N) + 3) / 4), 1);
   t.bytes = off;
   return t;
 }
@@ -66,6 +68,7 @@ struct Scratch {
 };
 
 constexpr int MAX_SPLIT = 32;
+constexpr int AB_MAX_ROWS = 64;  // attention backward: longest sequence / largest group (backward.hip)
 
 static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, int64_t C) {
   Scratch s;
@@ -125,7 +128,7 @@ static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k
 static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
                           int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, float* bufA, float* bufB,
                           float* bufC, float* bufD, float* bufQ, float* bufH, const Scratch& sc, StltDrop dr, uint32_t site0,
-                          hipStream_t s) {
+                          hipStream_t s, const AttnBwdRagged* rg = nullptr) {
   auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
   float* br = dr.thr ? bufD : bufB;  // branch gradient (after the dropout mask)
   // y = LN2(x1 + drop(f))
@@ -149,7 +152,7 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
   TRY(weight_grad(br, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w), sc, s));
   TRY(launch_gemm(0, 1, br, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
   // ctx = attention(qkv) with dropout on the probabilities
-  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red));  // bufQ = dqkv; in_proj_b += colsum(dqkv)
+  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv; in_proj_b += colsum(dqkv)
   // qkv = x·Winᵀ + bin
   TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
   TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, bufB, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
@@ -157,9 +160,11 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
 }
 
 static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
-                         const uint8_t* kpm, int causal, int kid, float* y, StltDrop dr, uint32_t site0, hipStream_t s) {
+                         const uint8_t* kpm, int causal, int kid, float* y, StltDrop dr, uint32_t site0, hipStream_t s,
+                         const int* seg_start = nullptr, const int* seg_end = nullptr) {
   TRY(launch_linear(t.x, d, lp.in_proj_w, lp.in_proj_b, t.qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
-  TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s, dr, site0));
+  if (seg_start) TRY(launch_attn_ragged(t.qkv, seg_start, seg_end, causal, M, H, d / H, t.ctx, kid, s, dr, site0));
+  else TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s, dr, site0));
   TRY(launch_linear(t.ctx, d, lp.out_proj_w, lp.out_proj_b, t.a, d, M, d, d, STLT_ACT_NONE, s));
   TRY(launch_add_layernorm(t.a, d, t.x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, t.x1, d, s, dr, site0 + 1));
   TRY(launch_linear(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, 4 * d, M, 4 * d, d, STLT_ACT_NONE, s));
@@ -194,34 +199,65 @@ size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int6
   return scratch_layout(nullptr, B, T, N, d, n_categories).bytes;
 }
 
+// Row counts of the ragged index: one device->host copy + stream synchronisation.
+static int read_ragged_counts(const RaggedIndex& ix, int64_t& Ms, int64_t& Mf, hipStream_t s) {
+  int counts[4] = {0, 0, 0, 0};
+  if (hipError_t e = hipMemcpyAsync(counts, ix.counts, sizeof(counts), hipMemcpyDeviceToHost, s); e != hipSuccess)
+    return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
+  if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess)
+    return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
+  if (counts[2] != 0)
+    return stlt_set_error(STLT_EINVAL, "skip-padding needs collater-shaped masks: slot 0 of every real frame unmasked and frame lengths-1 real (datasets.py:247-288)");
+  Ms = counts[0];
+  Mf = counts[1];
+  return 0;
+}
+
 int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_mem, size_t tape_bytes, float* logits,
-                       float dropout_p, uint64_t dropout_seed, stlt_stream_t stream) {
+                       float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream) {
   TRY(check_train(p, in));
   if (!logits || !tape_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_forward: null logits/tape");
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
   const Tape t = tape_layout((char*)tape_mem, B, T, N, d, p->n_spatial, p->n_temporal);
   if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
-  const int64_t tok = B * T * N, BT = B * T;
   StltGemmScratch gemm_scratch(t.sk, STLT_GEMM_SCRATCH_BYTES);
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
   const StltDrop dr = stlt_drop_make(dropout_p, dropout_seed);
+  // Padded schedule: every (clip, frame, slot) row, masks applied inside the attention.  Skip-padding: the same
+  // launches over the real rows only (ragged.hip); dropout masks are then drawn per compacted row.
+  const bool ragged = (flags & STLT_FLAG_SKIP_PADDING) != 0;
+  int64_t tok = B * T * N, BT = B * T;
+  RaggedIndex ix{};
+  if (ragged) {
+    ix = ragged_index_carve(t.ridx, B, T, N);
+    TRY(launch_ragged_index(in->kpm_boxes, in->kpm_frames, in->lengths, B, T, N, ix, s));
+    TRY(read_ragged_counts(ix, tok, BT, s));
+  }
   float* x0 = p->n_spatial > 0 ? t.sp[0].x : t.sp_out;
   TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
-                   p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x0, s, t.s_embed, dr));
+                   p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x0, s, t.s_embed, dr, ragged ? ix.t_orig : nullptr));
   for (int64_t l = 0; l < p->n_spatial; ++l) {
     float* y = l + 1 < p->n_spatial ? t.sp[l + 1].x : t.sp_out;
-    TRY(layer_forward(p->spatial[l], d, H, t.sp[l], tok, BT, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, y, dr, (uint32_t)(8 * (l + 1)), s));
+    TRY(layer_forward(p->spatial[l], d, H, t.sp[l], tok, B * T, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, y, dr, (uint32_t)(8 * (l + 1)), s,
+                      ragged ? ix.t_seg_start : nullptr, ragged ? ix.t_seg_end : nullptr));
   }
   float* g0 = p->n_temporal > 0 ? t.tp[0].x : t.tp_out;
-  TRY(launch_frames_embed(t.sp_out, N * d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b,
-                          p->ln_eps, B, T, d, g0, s, t.s_frames, dr));
+  if (ragged) {  // CLS rows are not evenly strided any more: gather them (tp_out is free until the last temporal layer writes it)
+    TRY(launch_gather_rows(t.sp_out, d, ix.f_cls_row, BT, d, t.tp_out, s));
+    TRY(launch_frames_embed(t.tp_out, d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b, p->ln_eps, B, T,
+                            d, g0, s, t.s_frames, dr, ix.f_orig, BT));
+  } else {
+    TRY(launch_frames_embed(t.sp_out, N * d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b,
+                            p->ln_eps, B, T, d, g0, s, t.s_frames, dr));
+  }
   for (int64_t l = 0; l < p->n_temporal; ++l) {
     float* y = l + 1 < p->n_temporal ? t.tp[l + 1].x : t.tp_out;
     TRY(layer_forward(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, y, dr,
-                      (uint32_t)(8 * (p->n_spatial + l + 1)), s));
+                      (uint32_t)(8 * (p->n_spatial + l + 1)), s, ragged ? ix.f_seg_start : nullptr, ragged ? ix.f_seg_end : nullptr));
   }
-  TRY(launch_gather_last(t.tp_out, in->lengths, B, T, d, t.h0, s));
+  if (ragged) TRY(launch_gather_rows(t.tp_out, d, ix.last_row, B, d, t.h0, s));
+  else TRY(launch_gather_last(t.tp_out, in->lengths, B, T, d, t.h0, s));
   TRY(launch_linear(t.h0, d, p->fc1_w, p->fc1_b, t.u0, d, B, d, d, STLT_ACT_NONE, s));
   TRY(launch_gelu_fwd(t.u0, t.z1, B * d, s));
   TRY(launch_add_layernorm(t.z1, d, nullptr, 0, p->head_ln_w, p->head_ln_b, p->ln_eps, B, d, t.z2, d, s));
@@ -231,7 +267,7 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
 
 int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_inputs* in, const void* tape_mem,
                         size_t tape_bytes, void* scratch_mem, size_t scratch_bytes, const float* dlogits,
-                        float dropout_p, uint64_t dropout_seed, stlt_stream_t stream) {
+                        float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream) {
   TRY(check_train(p, in));
   if (!g || !dlogits || !tape_mem || !scratch_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: null argument");
   hipStream_t s = (hipStream_t)stream;
@@ -240,10 +276,40 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
   const Scratch sc = scratch_layout((char*)scratch_mem, B, T, N, d, p->n_categories);
   if (scratch_bytes < sc.bytes) return stlt_set_error(STLT_EWORKSPACE, "scratch %zu B < required %zu B", scratch_bytes, sc.bytes);
-  const int64_t tok = B * T * N, BT = B * T;
+  int64_t tok = B * T * N, BT = B * T;
+  int64_t tokp = t.tokp, btp = t.btp;
   StltGemmScratch gemm_scratch(sc.sk, STLT_GEMM_SCRATCH_BYTES);
   const StltDrop dr = stlt_drop_make(dropout_p, dropout_seed);
   auto W = [](const float* q) { return const_cast<float*>(q); };
+  // Skip-padding: the tape holds the real rows only (same buffers, fewer rows).  The weight-gradient products
+  // contract over the row count rounded up to 32, so the gradient-side operands' rows between the count and its
+  // round-up are zeroed here (the padded schedule never dirties them; a ragged row count changes every step).
+  const bool ragged = (flags & STLT_FLAG_SKIP_PADDING) != 0;
+  RaggedIndex ix{};
+  AttnBwdRagged rg_sp{}, rg_tp{};
+  if (ragged) {
+    ix = ragged_index_carve(t.ridx, B, T, N);
+    TRY(read_ragged_counts(ix, tok, BT, s));
+    tokp = up32(tok);
+    btp = up32(BT);
+    if (N > AB_MAX_ROWS || T > AB_MAX_ROWS) return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens", AB_MAX_ROWS);
+    const int fpg = N <= 32 ? (int)(32 / N) : 1;  // whole frames per attention-backward group
+    TRY(launch_ragged_groups(ix, tok, BT, fpg, s));
+    rg_sp = AttnBwdRagged{ix.sp_grp_ptr, ix.t_seg_start, ix.t_seg_end, (BT + fpg - 1) / fpg, tok, (int)(fpg * N)};
+    rg_tp = AttnBwdRagged{ix.clip_frm_off, ix.f_seg_start, ix.f_seg_end, B, BT, (int)T};
+    auto zero_pad = [&](float* buf, int64_t width, int64_t rows, int64_t rows_p) -> int {
+      if (rows_p == rows) return 0;
+      if (hipError_t e = hipMemsetAsync(buf + rows * width, 0, (size_t)(rows_p - rows) * width * sizeof(float), s); e != hipSuccess)
+        return stlt_set_error((int)e, "train_backward: memset: %s", hipGetErrorString(e));
+      return 0;
+    };
+    for (float* b : {sc.sB, sc.sD}) TRY(zero_pad(b, d, tok, tokp));
+    TRY(zero_pad(sc.sQKV, 3 * d, tok, tokp));
+    TRY(zero_pad(sc.sH, 4 * d, tok, tokp));
+    for (float* b : {sc.tB, sc.tD}) TRY(zero_pad(b, d, BT, btp));
+    TRY(zero_pad(sc.tQKV, 3 * d, BT, btp));
+    TRY(zero_pad(sc.tH, 4 * d, BT, btp));
+  }
 
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
@@ -255,25 +321,32 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   if (g->fc1_w) TRY(launch_small_gemm(sc.hB, 1, d, t.h0, d, 1, W(g->fc1_w), d, d, d, B, 1, s));     // (d,d) += du0ᵀ·h0
   if (g->fc1_b) TRY(launch_colsum_acc(sc.hB, d, B, d, W(g->fc1_b), sc.red, s));
   TRY(launch_small_gemm(sc.hB, d, 1, p->fc1_w, d, 1, sc.hA, d, B, d, d, 0, s));                     // hA = dh0
-  TRY(launch_scatter_last(sc.hA, in->lengths, B, T, d, sc.tA, s));                                  // tA = d(backbone out)
+  if (ragged) TRY(launch_scatter_rows(sc.hA, ix.last_row, B, d, sc.tA, btp, s));                    // tA = d(backbone out)
+  else TRY(launch_scatter_last(sc.hA, in->lengths, B, T, d, sc.tA, s));
 
   // ---- temporal transformer
   for (int64_t l = p->n_temporal - 1; l >= 0; --l)
-    TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, t.btp, B, T, in->kpm_frames, 1,
-                       sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s));
+    TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
+                       sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s,
+                       ragged ? &rg_tp : nullptr));
   // ---- frames embeddings (models.py:98-111)
   TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, sc.tB, d, W(g->frames_ln_w),
                     W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));
-  TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, sc.sA, W(g->pos_emb), W(g->type_emb), s));   // sA = d(spatial out), CLS rows only
+  if (ragged) {
+    TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, nullptr, W(g->pos_emb), W(g->type_emb), s, ix.f_row_of));
+    TRY(launch_scatter_rows(sc.tB, ix.f_cls_row, BT, d, sc.sA, tokp, s));                           // sA = d(spatial out), CLS rows only
+  } else {
+    TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, sc.sA, W(g->pos_emb), W(g->type_emb), s));  // sA = d(spatial out), CLS rows only
+  }
   // ---- spatial transformer
   for (int64_t l = p->n_spatial - 1; l >= 0; --l)
-    TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, t.tokp, BT, N, in->kpm_boxes, 0,
-                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s));
+    TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
+                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr));
   // ---- category / box / score embeddings (models.py:29-39)
   TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sB, d, W(g->emb_ln_w), W(g->emb_ln_b),
                     sc.red, s, dr, 0, nullptr, STLT_SITE_EMBED));
   TRY(launch_embed_bwd(sc.sB, in->categories, in->boxes, in->scores, p->n_categories, tok, d, W(g->cat_emb), W(g->box_w),
-                       W(g->box_b), W(g->score_w), W(g->score_b), sc.red, s));
+                       W(g->box_b), W(g->score_w), W(g->score_b), sc.red, s, ragged ? ix.t_orig : nullptr));
   return 0;
 }
 

@@ -182,7 +182,7 @@ class StltBackbone(nn.Module):
         self.transformer = _EncoderStack(_EncoderLayerParams(config.hidden_size), config.num_temporal_layers)
         self.cls_only_last_spatial = True  # exact: only token 0 of the last spatial layer is read (models.py:79)
         self.last_row_only_temporal = True  # exact, Stlt.forward only: the head reads one row per clip (models.py:189-192)
-        # Stlt.forward (inference) only, off by default: compute the real tokens / frames of the padded batch only.
+        # Stlt.forward (inference and training), off by default: compute the real tokens / frames of the padded batch only.
         # Same logits (a padded row is masked as a key and never read); needs collater-shaped masks and costs one
         # stream synchronisation per call (include/stlt_hip.h: STLT_FLAG_SKIP_PADDING).
         self.skip_padding = False
@@ -373,10 +373,11 @@ class _StltTrainFn(torch.autograd.Function):
         drop_p = float(cfg.hidden_dropout_prob) if bb.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0
         seed = getattr(model, "_dropout_seed_override", None) or seed
+        flags = L.FLAG_SKIP_PADDING if bb.skip_padding else 0  # the other two flags are inference-only elisions
         with torch.cuda.device(device):
             L.check(lib.stlt_train_forward(C.byref(p), C.byref(inp), tape.data_ptr(), tape.numel(), logits.data_ptr(),
-                                           drop_p, seed, torch.cuda.current_stream().cuda_stream), "stlt_train_forward")
-        ctx.model, ctx.batch, ctx.shape, ctx.params, ctx.drop = model, batch, (B, T, N, d), params, (drop_p, seed)
+                                           drop_p, seed, flags, torch.cuda.current_stream().cuda_stream), "stlt_train_forward")
+        ctx.model, ctx.batch, ctx.shape, ctx.params, ctx.drop = model, batch, (B, T, N, d), params, (drop_p, seed, flags)
         return logits
 
     @staticmethod
@@ -402,7 +403,7 @@ class _StltTrainFn(torch.autograd.Function):
         with torch.cuda.device(device):
             L.check(lib.stlt_train_backward(C.byref(p), C.byref(g), C.byref(inp), tape.data_ptr(), tape.numel(),
                                             scratch.data_ptr(), scratch.numel(), dl.data_ptr(), ctx.drop[0], ctx.drop[1],
-                                            torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
+                                            ctx.drop[2], torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
         model._last_flat_grad = flat  # one contiguous buffer: what a data-parallel wrapper all-reduces
         return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)
 

@@ -20,8 +20,9 @@ def _oracle_grads(sd, batch, H, labels, dtype=torch.float64):
     return loss.item(), logits.detach(), {k: v.grad for k, v in leaves.items() if v.is_floating_point()}
 
 
-@pytest.mark.parametrize("name,B,with_scores", [("cfg1", 3, False), ("cfg1", 5, True), ("cfg2", 2, False)])
-def test_gradients_match_oracle_autograd(pkg, name, B, with_scores):
+@pytest.mark.parametrize("skip_padding", [False, True])
+@pytest.mark.parametrize("name,B,with_scores", [("cfg1", 3, False), ("cfg1", 5, True), ("cfg2", 2, False), ("cfg4", 2, True)])
+def test_gradients_match_oracle_autograd(pkg, name, B, with_scores, skip_padding):
     c = pkg.synth.CONFIGS[name]
     H = c["num_attention_heads"]
     m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
@@ -29,6 +30,7 @@ def test_gradients_match_oracle_autograd(pkg, name, B, with_scores):
     m.load_state_dict(sd)
     m.train(True)  # hidden_dropout_prob = 0 in model_kwargs
     m.to(DEV)
+    m.backbone.skip_padding = skip_padding  # forward + reverse sweep on the real tokens / frames only
     batch = pkg.synth.make_batch(B, c["T"], c["N"], dataset=c["dataset"], seed=77, with_scores=with_scores)
     labels = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(5))
     ref_loss, ref_logits, ref_g = _oracle_grads(sd, batch, H, labels)
@@ -56,7 +58,7 @@ def test_gradients_match_oracle_autograd(pkg, name, B, with_scores):
         if err > worst[1]:
             worst = (k, err)
         assert err <= 2e-4, f"{k}: relative grad error {err:.2e} (|g|max={scale:.2e})"
-    print(f"{name} B={B}: {n_checked} gradients checked, worst {worst[0]} rel err {worst[1]:.2e}")
+    print(f"{name} B={B} skip_padding={skip_padding}: {n_checked} gradients checked, worst {worst[0]} rel err {worst[1]:.2e}")
     # padding_idx rows get no gradient (models.py:22,91)
     assert m.backbone.frames_embeddings.frame_type_embedding.weight.grad[0].abs().max().item() == 0.0
     assert m.backbone.frames_embeddings.layout_embedding.category_box_embeddings.category_embeddings.weight.grad[0].abs().max().item() == 0.0
@@ -166,3 +168,74 @@ def test_dropout_forward_and_gradients_match_masked_oracle(pkg, name, B, p):
     assert (other - out).abs().max().item() > 1e-3
     keep = O.dropout_keep(p, seed, 17, np.arange(200000, dtype=np.uint64))
     assert abs(1.0 - keep.mean() - p) < 0.01
+
+
+def test_skip_padding_training_edge_layouts_and_alternation(pkg):
+    """Ragged row counts change from step to step and the padded schedule can follow a ragged step on the same tape /
+    scratch buffers: gradients must match the padded schedule's every time (stale rows past the row count must not leak)."""
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=8, gain=1.5))
+    m.train(True).to(DEV)
+    B = 6
+    batches = [pkg.synth.make_batch(B, c["T"], c["N"], seed=41, dense=True),          # nothing to skip
+               pkg.synth.make_batch(B, c["T"], c["N"], seed=42, min_len=2),            # short clips
+               pkg.synth.make_batch(B, c["T"], c["N"], seed=43),
+               pkg.synth.make_batch(B, c["T"], c["N"], seed=44, min_len=2)]
+    empty = pkg.synth.make_batch(B, c["T"], c["N"], seed=45)
+    empty["categories"][:, :, 1:] = 0
+    empty["boxes"][:, :, 1:] = 0
+    empty["src_key_padding_mask_boxes"] = empty["categories"] == 0                       # CLS-only frames
+    batches.append(empty)
+    labels = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def grads(batch, skip):
+        m.backbone.skip_padding = skip
+        m.zero_grad(set_to_none=True)
+        out = m({k: v.to(DEV) for k, v in batch.items()})["stlt"]
+        F.cross_entropy(out, labels).backward()
+        return out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    for batch in batches:
+        ref_out, ref = grads(batch, False)
+        out, got = grads(batch, True)
+        assert (out - ref_out).abs().max().item() <= 2e-5
+        assert set(got) == set(ref)
+        for k in ref:
+            scale = max(ref[k].abs().max().item(), 1e-6)
+            assert (got[k] - ref[k]).abs().max().item() / scale <= 2e-4, k
+        again_out, again = grads(batch, True)
+        assert torch.equal(out, again_out) and all(torch.equal(got[k], again[k]) for k in got)  # reproducible
+
+
+def test_skip_padding_training_with_dropout_is_seeded_and_finite(pkg):
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    kw = pkg.synth.model_kwargs(name)
+    kw["hidden_dropout_prob"] = 0.1
+    m = pkg.Stlt(pkg.StltModelConfig(**kw))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=8))
+    m.train(True).to(DEV)
+    m.backbone.skip_padding = True
+    batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(4, c["T"], c["N"], seed=3).items()}
+    labels = torch.randint(0, c["num_classes"], (4,), generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def run(seed):
+        torch.manual_seed(seed)
+        m.zero_grad(set_to_none=True)
+        out = m(batch)["stlt"]
+        F.cross_entropy(out, labels).backward()
+        g = m.backbone.transformer.layers[0].linear1.weight.grad.detach().clone()
+        return out.detach().clone(), g
+
+    a, ga = run(1)
+    b, gb = run(1)
+    c2, gc = run(2)
+    assert torch.isfinite(a).all() and torch.isfinite(ga).all()
+    assert torch.equal(a, b) and torch.equal(ga, gb)          # same seed -> same masks in forward and backward
+    assert not torch.equal(a, c2)                             # another seed -> another mask
+    m.train(False)
+    with torch.no_grad():
+        e = m(batch)["stlt"]
+    assert (e - a).abs().max().item() > 1e-4                  # dropout really was applied in training mode
