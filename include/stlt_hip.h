@@ -231,6 +231,23 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* grads, const st
                         size_t tape_bytes, void* scratch, size_t scratch_bytes, const float* dlogits,
                         float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream);
 
+/* ---- optimiser step of the training loop (reference train.py:128-131 with utils/train_inference_utils.py:37-54) ----
+ * The reverse sweep writes all parameter gradients into ONE flat fp32 buffer (what a data-parallel run all-reduces).
+ * stlt_grad_norm: out[0] = ||g||_2 over the n floats, out[1] = min(1, max_norm / (out[0] + 1e-6)) — the factor
+ * torch.nn.utils.clip_grad_norm_ scales the gradients by (max_norm <= 0: out[1] = 1).  scratch: >= 1024 floats.
+ * stlt_adamw_step: torch.optim.AdamW.step (decoupled weight decay, bias correction, fp32) over a device table of
+ * chunks; element i of a chunk is parameter param[i], its gradient flat_grad[flat_offset + i] (scaled by
+ * norm_and_clip[1] when given) and its moments exp_avg / exp_avg_sq at the same flat offset.  step counts from 1. */
+typedef struct {
+  float* param;
+  int64_t flat_offset;
+  int32_t n;
+  float weight_decay;
+} stlt_opt_chunk;
+int stlt_grad_norm(const float* flat_grad, int64_t n, float max_norm, float* scratch, float* out, stlt_stream_t stream);
+int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const float* flat_grad, float* exp_avg, float* exp_avg_sq,
+                    const float* norm_and_clip, float lr, float beta1, float beta2, float eps, int64_t step, stlt_stream_t stream);
+
 /* ---- per-kernel timing (bench.py roofline leg): hipEvents around every launch of the whole-path calls ---- */
 #define STLT_K_EMBED 0
 #define STLT_K_GEMM 1

@@ -20,6 +20,10 @@ _u8 = C.POINTER(C.c_uint8)
 _vp = C.c_void_p
 
 
+class OptChunk(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("flat_offset", C.c_int64), ("n", C.c_int32), ("weight_decay", C.c_float)]
+
+
 class LayerParams(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
@@ -99,6 +103,8 @@ SIGNATURES = {
     "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
     "stlt_train_backward": (C.c_int, [C.POINTER(Params), C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp,
                                       C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
+    "stlt_grad_norm": (C.c_int, [_vp, C.c_int64, C.c_float, _vp, _vp, _vp]),
+    "stlt_adamw_step": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
     "stlt_prof_enable": (C.c_int, [C.c_int]),
     "stlt_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "stlt_debug_set_buffer": (C.c_int, [_vp]),

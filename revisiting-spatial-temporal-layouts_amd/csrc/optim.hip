@@ -1,0 +1,119 @@
+// Gradient clipping + AdamW of the training step (reference train.py:128-131: clip_grad_norm_(5.0), AdamW.step) as
+// two passes over ONE flat gradient buffer: the reverse sweep already writes every parameter gradient into one
+// contiguous allocation (the buffer a data-parallel run all-reduces), so the norm is one reduction and the update is
+// one kernel over a table of (parameter pointer, flat offset, length, weight decay) chunks, instead of torch's
+// ~10 multi-tensor launches.  Arithmetic follows torch.optim.AdamW's foreach path operation by operation (fp32).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n4, int64_t n, float* __restrict__ partials) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 * 4; i < n; ++i) acc += g[i] * g[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// out[0] = ||g||_2, out[1] = min(1, max_norm / (||g|| + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restrict__ partials, int n_partials, float max_norm,
+                                                          float* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += 256) acc += (double)partials[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]);
+    out[0] = norm;
+    out[1] = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const stlt_opt_chunk* __restrict__ chunks, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ clip,
+                                                    float lr, float w_lerp, float beta2, float w_sq, float eps, float neg_step,
+                                                    float bc2_sqrt) {
+  const stlt_opt_chunk c = chunks[blockIdx.x];
+  const float coef = clip ? clip[1] : 1.0f;
+  const float decay = 1.0f - lr * c.weight_decay;  // param.mul_(1 - lr * weight_decay)
+  float* __restrict__ p = c.param;
+  auto update = [&](float gi, float& mi, float& vi, float& pi) {
+    gi *= coef;
+    pi = pi * decay;
+    mi = mi + w_lerp * (gi - mi);              // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * beta2;                           // exp_avg_sq.mul_(beta2)
+    vi = vi + (w_sq * gi) * gi;                //            .addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi + neg_step * (mi / denom);         // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+  };
+  const bool vec = (((uintptr_t)p | (uintptr_t)(g + c.flat_offset) | (uintptr_t)(m + c.flat_offset) | (uintptr_t)(v + c.flat_offset)) & 15) == 0;
+  const int n4 = vec ? c.n / 4 : 0;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const int64_t k = c.flat_offset + 4 * (int64_t)i;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + k);
+    f32x4 m4 = *reinterpret_cast<const f32x4*>(m + k), v4 = *reinterpret_cast<const f32x4*>(v + k);
+    f32x4 p4 = *reinterpret_cast<const f32x4*>(p + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float mi = m4[e], vi = v4[e], pi = p4[e];
+      update(g4[e], mi, vi, pi);
+      m4[e] = mi; v4[e] = vi; p4[e] = pi;
+    }
+    *reinterpret_cast<f32x4*>(m + k) = m4;
+    *reinterpret_cast<f32x4*>(v + k) = v4;
+    *reinterpret_cast<f32x4*>(p + 4 * i) = p4;
+  }
+  for (int i = n4 * 4 + threadIdx.x; i < c.n; i += 256) {
+    const int64_t k = c.flat_offset + i;
+    float mi = m[k], vi = v[k], pi = p[i];
+    update(g[k], mi, vi, pi);
+    m[k] = mi; v[k] = vi; p[i] = pi;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int stlt_grad_norm(const float* flat_grad, int64_t n, float max_norm, float* scratch, float* out, stlt_stream_t stream) {
+  if (!flat_grad || !scratch || !out) return stlt_set_error(STLT_EINVAL, "stlt_grad_norm: null pointer");
+  if (n < 0 || ((uintptr_t)flat_grad & 15)) return stlt_set_error(STLT_EINVAL, "stlt_grad_norm: buffer must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat_grad, n / 4, n, scratch);
+  if (int e = stlt_check_launch("sumsq_kernel")) return e;
+  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, scratch, (int)blocks, max_norm, out);
+  return stlt_check_launch("norm_finish_kernel");
+}
+
+int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const float* flat_grad, float* exp_avg, float* exp_avg_sq,
+                    const float* norm_and_clip, float lr, float beta1, float beta2, float eps, int64_t step, stlt_stream_t stream) {
+  if (!chunks_dev || !flat_grad || !exp_avg || !exp_avg_sq) return stlt_set_error(STLT_EINVAL, "stlt_adamw_step: null pointer");
+  if (step < 1 || n_chunks < 0 || n_chunks > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_adamw_step: bad step / chunk count");
+  if (n_chunks == 0) return 0;
+  // scalars as torch computes them: python floats (double), rounded to fp32 where they meet the tensors
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float neg_step = (float)(-(double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const float w_lerp = (float)(1.0 - (double)beta1), w_sq = (float)(1.0 - (double)beta2);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, chunks_dev, flat_grad, exp_avg, exp_avg_sq,
+                     norm_and_clip, lr, w_lerp, beta2, w_sq, eps, neg_step, bc2_sqrt);
+  return stlt_check_launch("adamw_kernel");
+}
+
+}  // extern "C"

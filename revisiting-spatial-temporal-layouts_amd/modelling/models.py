@@ -391,11 +391,14 @@ class _StltTrainFn(torch.autograd.Function):
         p, _, _ = bb.c_params(model.prediction_head)
         used = model._grad_params("scores" in batch)
         want = [prm for prm in ctx.params if prm.requires_grad and id(prm) in used]
-        flat = torch.zeros(sum(q.numel() for q in want), device=device, dtype=torch.float32)
-        views, off = {}, 0
+        # every gradient lives in one flat buffer (offsets rounded up to 4 floats so each tensor stays 16-byte aligned;
+        # the gaps stay zero): what a data-parallel run all-reduces and what train.FusedAdamW consumes
+        layout, off = [], 0
         for q in want:
-            views[id(q)] = flat[off: off + q.numel()].view_as(q)
-            off += q.numel()
+            layout.append((q, off, q.numel()))
+            off += (q.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, device=device, dtype=torch.float32)
+        views = {id(q): flat[o: o + n].view_as(q) for q, o, n in layout}
         g, gsp, gtp = bb._build_struct(model.prediction_head, lambda t: views[id(t)].data_ptr() if id(t) in views else None)
         tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, p.n_spatial, p.n_temporal)), device)
         scratch = bb._train_buf("scratch", int(lib.stlt_train_scratch_bytes(B, T, N, d, p.n_categories)), device)
@@ -405,6 +408,9 @@ class _StltTrainFn(torch.autograd.Function):
                                             scratch.data_ptr(), scratch.numel(), dl.data_ptr(), ctx.drop[0], ctx.drop[1],
                                             ctx.drop[2], torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
         model._last_flat_grad = flat  # one contiguous buffer: what a data-parallel wrapper all-reduces
+        model._flat_layout = layout
+        if getattr(model, "_flat_grads_only", False):  # train.FusedAdamW reads the flat buffer: skip the per-parameter .grad copies
+            return (None, None) + tuple(None for _ in ctx.params)
         return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)
 
 

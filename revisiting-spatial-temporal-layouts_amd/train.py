@@ -57,24 +57,115 @@ def allreduce_gradients(model: torch.nn.Module, world: int) -> None:
         g.copy_(f)
 
 
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (and its state layout: `step`, `exp_avg`, `exp_avg_sq` per parameter, so state dicts
+    are interchangeable) fed from the flat gradient buffer the native reverse sweep fills: gradient norm + clipping
+    factor in one reduction, then one update kernel over a chunk table (include/stlt_hip.h: stlt_grad_norm,
+    stlt_adamw_step).  Parameters absent from the flat buffer (no gradient this step) are left alone, like torch's
+    `if p.grad is None: continue`."""
+
+    CHUNK = 16384
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._layout_key = None
+
+    def _bind(self, layout, device):
+        from . import _lib as L
+        import ctypes as C
+        import numpy as np
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        total = max((off + (n + 3) // 4 * 4 for _, off, n in layout), default=0)
+        self._m = torch.zeros(total, device=device, dtype=torch.float32)
+        self._v = torch.zeros(total, device=device, dtype=torch.float32)
+        self._tables = []  # one chunk table per parameter group (lr / betas / eps are per group)
+        for g in self.param_groups:
+            rows = []
+            for p, off, n in layout:
+                if group_of.get(id(p)) is not g:
+                    continue
+                old = self.state.get(p, {})
+                st = self.state[p] = {"step": old.get("step", torch.tensor(0.0)),
+                                      "exp_avg": self._m[off: off + n].view_as(p), "exp_avg_sq": self._v[off: off + n].view_as(p)}
+                if "exp_avg" in old:  # state loaded from a checkpoint: move it into the flat buffers
+                    st["exp_avg"].copy_(old["exp_avg"]); st["exp_avg_sq"].copy_(old["exp_avg_sq"])
+                for c0 in range(0, n, self.CHUNK):
+                    rows.append((p.data_ptr() + 4 * c0, off + c0, min(self.CHUNK, n - c0), float(g["weight_decay"])))
+            arr = np.zeros(len(rows), dtype=np.dtype([("param", "<u8"), ("off", "<i8"), ("n", "<i4"), ("wd", "<f4")]))
+            for i, r in enumerate(rows):
+                arr[i] = r
+            assert arr.dtype.itemsize == C.sizeof(L.OptChunk)
+            self._tables.append((g, torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(rows)))
+        self._scratch = torch.zeros(1024 + 2, device=device, dtype=torch.float32)
+        self._layout_key = tuple((id(p), p.data_ptr(), off, n) for p, off, n in layout)
+
+    @torch.no_grad()
+    def step_flat(self, flat: torch.Tensor, layout, max_norm: float = 0.0) -> torch.Tensor:
+        """One optimisation step from the flat gradient buffer; returns the (pre-clipping) gradient norm, on the device."""
+        from . import _lib as L
+        lib = L.load()
+        key = tuple((id(p), p.data_ptr(), off, n) for p, off, n in layout)
+        if key != self._layout_key:
+            self._bind(layout, flat.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        self._opt_called = True  # what torch's wrapped step() records for the LR scheduler's call-order check
+        out = self._scratch[1024:]
+        L.check(lib.stlt_grad_norm(flat.data_ptr(), flat.numel(), float(max_norm), self._scratch.data_ptr(), out.data_ptr(), stream),
+                "stlt_grad_norm")
+        for g, table, n_chunks in self._tables:
+            if n_chunks == 0:
+                continue
+            step = None
+            for p in g["params"]:
+                st = self.state.get(p)
+                if st is not None and "exp_avg" in st:
+                    st["step"] = st["step"] + 1
+                    step = int(st["step"].item())
+            if step is None:
+                continue
+            L.check(lib.stlt_adamw_step(table.data_ptr(), n_chunks, flat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                        out.data_ptr() if max_norm > 0 else None, float(g["lr"]), float(g["betas"][0]),
+                                        float(g["betas"][1]), float(g["eps"]), step, stream), "stlt_adamw_step")
+        return out[0]
+
+    def step(self, closure=None):
+        raise RuntimeError("FusedAdamW consumes the flat gradient buffer of the native backward: call step_flat(flat, layout)")
+
+
 class Trainer:
     def __init__(self, model, dataset_name: str = "something", learning_rate: float = 5e-5, weight_decay: float = 1e-3,
-                 clip_val: float = 5.0, warmup_steps: int = 0, total_steps: int = 1, rank: int = 0, world: int = 1):
+                 clip_val: float = 5.0, warmup_steps: int = 0, total_steps: int = 1, rank: int = 0, world: int = 1,
+                 fused_optimizer: Optional[bool] = None):
         self.model, self.dataset_name, self.clip_val = model, dataset_name, clip_val
         self.rank, self.world = rank, world
-        self.optimizer = torch.optim.AdamW(add_weight_decay(model, weight_decay), lr=learning_rate)
+        if fused_optimizer is None:  # the fused path needs the native model's flat gradient buffer on a GPU
+            first = next(iter(model.parameters()), None)
+            fused_optimizer = hasattr(model, "_grad_params") and first is not None and first.is_cuda
+        self.fused = fused_optimizer
+        opt = FusedAdamW if fused_optimizer else torch.optim.AdamW  # same defaults (betas 0.9/0.999, eps 1e-8)
+        self.optimizer = opt(add_weight_decay(model, weight_decay), lr=learning_rate)
         self.scheduler = linear_schedule_with_warmup(self.optimizer, warmup_steps, total_steps)
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
         """One optimisation step on this rank's shard of the global batch (train.py:119-135)."""
         self.model.train(True)
         self.optimizer.zero_grad()
+        self.model._flat_grads_only = self.fused
         logits = self.model(batch)
         loss = criterion(logits, batch["labels"], self.dataset_name)
         loss.backward()
-        allreduce_gradients(self.model, self.world)
-        grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_val)
-        self.optimizer.step()
+        if self.fused:
+            # the reverse sweep left every gradient in one flat buffer: all-reduce it in place, then norm + clip +
+            # AdamW straight from it (no per-parameter .grad tensors, no flatten / unflatten copies)
+            flat, layout = self.model._last_flat_grad, self.model._flat_layout
+            if self.world > 1:
+                torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+                flat.div_(self.world)
+            grad_norm = self.optimizer.step_flat(flat, layout, self.clip_val)
+        else:
+            allreduce_gradients(self.model, self.world)
+            grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_val)
+            self.optimizer.step()
         self.scheduler.step()
         return {"loss": loss.detach(), "grad_norm": grad_norm.detach()}
 
