@@ -207,8 +207,10 @@ int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const floa
                      size_t workspace_bytes, float* logits_caf, float* logits_stlt, float* logits_resnet3d,
                      float* logits_ensemble, stlt_stream_t stream);
 
-/* ---- training step (reference src/train.py:119-135: forward, loss.backward(); the optimizer stays in torch) ----
- * stlt_train_forward runs the dense schedule and records every intermediate the reverse sweep needs in `tape`
+/* ---- training step (reference src/train.py:119-135: forward, loss.backward(); optimiser step further below) ----
+ * stlt_train_forward runs every layer on every row — except that the last layer of each tower runs its out-proj /
+ * norms / FFN only on the rows read afterwards (CLS row per frame, frame lengths-1 per clip; same loss and gradients,
+ * dropout masks keep the rows' original indices) — and records every intermediate the reverse sweep needs in `tape`
  * (fp32; rows padded to a multiple of 32; the caller allocates it ZERO-FILLED once and the library never writes the
  * padding).  stlt_train_backward is the reverse sweep: given dlogits (B, n_classes) it ACCUMULATES (+=) parameter
  * gradients into the buffers named by `grads` — the same struct as the parameters, every pointer being the gradient

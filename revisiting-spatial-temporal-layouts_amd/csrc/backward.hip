@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ w, float eps, int64_t M, int d,
                                                      float* __restrict__ ds, int64_t ldds,
                                                      float* __restrict__ partials /* [blocks][3][d] */, StltDrop dr,
-                                                     uint32_t site_b2, float* __restrict__ ds_drop, uint32_t site_dy) {
+                                                     uint32_t site_b2, float* __restrict__ ds_drop, uint32_t site_dy,
+                                                     const int* __restrict__ drop_rows) {
   __shared__ float red[3 * NV * 256];  // block-level sums of dw | db | column sums of the branch gradient
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
   const float inv_d = 1.0f / (float)d;
   for (int64_t row = gw; row < M; row += n_waves) {
+    const uint64_t drow = (dr.thr && drop_rows) ? (uint64_t)drop_rows[row] : (uint64_t)row;  // dropout masks follow the row's original position
     f32x4 x[NV], g[NV];
     float sum = 0.f;
 #pragma unroll
@@ -45,11 +47,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         x[i] = *reinterpret_cast<const f32x4*>(a + row * lda + e);
         if (b2) {
           f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + row * ldb + e);
-          if (dr.thr && site_b2) bv = stlt_drop4(dr, site_b2, (uint64_t)row * d + e, bv);  // the forward added drop(b2)
+          if (dr.thr && site_b2) bv = stlt_drop4(dr, site_b2, drow * d + e, bv);  // the forward added drop(b2)
           x[i] += bv;
         }
         g[i] = *reinterpret_cast<const f32x4*>(dy + row * lddy + e);
-        if (dr.thr && site_dy) g[i] = stlt_drop4(dr, site_dy, (uint64_t)row * d + e, g[i]);  // dropout on the LN output
+        if (dr.thr && site_dy) g[i] = stlt_drop4(dr, site_dy, drow * d + e, g[i]);  // dropout on the LN output
         sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
       } else {
         x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const f32x4 o = (g[i] - mg - x[i] * mgx) * rstd;
         *reinterpret_cast<f32x4*>(ds + row * ldds + e) = o;
         if (ds_drop) {
-          const f32x4 od = stlt_drop4(dr, site_b2, (uint64_t)row * d + e, o);  // gradient wrt the un-dropped b2
+          const f32x4 od = stlt_drop4(dr, site_b2, drow * d + e, o);  // gradient wrt the un-dropped b2
           *reinterpret_cast<f32x4*>(ds_drop + row * ldds + e) = od;
           cs_acc[i] += od;
         } else {
@@ -134,12 +136,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ GELU (exact erf) forward / backward
+// drop_rows (with ncols4 = row width / 4): rows picked out of a larger buffer keep the dropout masks of their
+// original positions, i.e. element (row, col) uses index drop_rows[row] * width + col
+__device__ __forceinline__ uint64_t drop_index(int64_t i4, const int* __restrict__ drop_rows, int64_t ncols4) {
+  if (!drop_rows) return (uint64_t)i4 * 4;
+  const int64_t row = i4 / ncols4;
+  return ((uint64_t)drop_rows[row] * ncols4 + (uint64_t)(i4 - row * ncols4)) * 4;
+}
+
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ h, int64_t n4,
-                                                       StltDrop dr, uint32_t site) {
+                                                       StltDrop dr, uint32_t site, const int* __restrict__ drop_rows, int64_t ncols4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
     f32x4 o = {gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
-    if (dr.thr) o = stlt_drop4(dr, site, (uint64_t)i * 4, o);
+    if (dr.thr) o = stlt_drop4(dr, site, drop_index(i, drop_rows, ncols4), o);
     reinterpret_cast<f32x4*>(h)[i] = o;
   }
 }
@@ -150,10 +160,11 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ u,
-                                                       float* __restrict__ du, int64_t n4, StltDrop dr, uint32_t site) {
+                                                       float* __restrict__ du, int64_t n4, StltDrop dr, uint32_t site,
+                                                       const int* __restrict__ drop_rows, int64_t ncols4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 g = reinterpret_cast<const f32x4*>(dh)[i];
-    if (dr.thr) g = stlt_drop4(dr, site, (uint64_t)i * 4, g);
+    if (dr.thr) g = stlt_drop4(dr, site, drop_index(i, drop_rows, ncols4), g);
     const f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
     f32x4 o = {g.x * gelu_grad(v.x), g.y * gelu_grad(v.y), g.z * gelu_grad(v.z), g.w * gelu_grad(v.w)};
     reinterpret_cast<f32x4*>(du)[i] = o;
@@ -164,7 +175,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
 // accumulated on the way: a block owns 1024 columns x a row range, thread = 4 columns.
 __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const float* __restrict__ dh, const float* __restrict__ u,
                                                               float* __restrict__ du, int64_t M, int N, int64_t rows_per_block,
-                                                              float* __restrict__ partials, StltDrop dr, uint32_t site) {
+                                                              float* __restrict__ partials, StltDrop dr, uint32_t site,
+                                                              const int* __restrict__ drop_rows) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= N) return;
   const int64_t m0 = (int64_t)blockIdx.y * rows_per_block;
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const float* __res
   for (int64_t m = m0; m < m1; ++m) {
     const int64_t i = m * N + c;
     f32x4 g = *reinterpret_cast<const f32x4*>(dh + i);
-    if (dr.thr) g = stlt_drop4(dr, site, (uint64_t)i, g);
+    if (dr.thr) g = stlt_drop4(dr, site, drop_rows ? (uint64_t)drop_rows[m] * N + c : (uint64_t)i, g);
     const f32x4 v = *reinterpret_cast<const f32x4*>(u + i);
     const f32x4 o = {g.x * gelu_grad(v.x), g.y * gelu_grad(v.y), g.z * gelu_grad(v.z), g.w * gelu_grad(v.w)};
     *reinterpret_cast<f32x4*>(du + i) = o;
@@ -461,7 +473,8 @@ int64_t ln_bwd_scratch_floats(int64_t d) { return 512 * 3 * d; }
 
 int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
                   float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
-                  hipStream_t s, StltDrop dr, uint32_t site_b2, float* ds_drop, uint32_t site_dy, float* g_colsum) {
+                  hipStream_t s, StltDrop dr, uint32_t site_b2, float* ds_drop, uint32_t site_dy, float* g_colsum,
+                  const int* drop_rows) {
   if (!dy || !a || !w || !ds || !scratch) return stlt_set_error(STLT_EINVAL, "ln_bwd: null pointer");
   if (d <= 0 || d % 4 || d > 2048) return stlt_set_error(STLT_EINVAL, "ln_bwd: bad d=%lld", (long long)d);
   if (M == 0) return 0;
@@ -470,7 +483,7 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   StltProfScope ps(STLT_K_ADDLN, s);
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
                                             ldb, w, eps, M, (int)d, ds, ldds, scratch, dr, site_b2,
-                                            (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy));
+                                            (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy, drop_rows));
   if (int e = stlt_check_launch("ln_bwd_kernel")) return e;
   // partial rows are interleaved [block][dw|db|colsum][d]: strided reductions
   if (g_w) { if (int e = launch_reduce_slabs(scratch, 3 * d, (int)blocks, g_w, d, 1, s)) return e; }
@@ -492,17 +505,18 @@ int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g
   return launch_reduce_slabs(scratch, N, parts, g, N, 1, s);
 }
 
-int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr, uint32_t site) {
+int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows, int64_t ncols) {
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, u, h, n / 4, dr, site);
+  if (drop_rows && (ncols <= 0 || ncols % 4)) return stlt_set_error(STLT_EINVAL, "gelu: row width must be a positive multiple of 4");
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, u, h, n / 4, dr, site, drop_rows, ncols / 4);
   return stlt_check_launch("gelu_fwd_kernel");
 }
 
 int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
-                           hipStream_t s, StltDrop dr, uint32_t site) {
+                           hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows) {
   if (!dh || !u || !du || !g_colsum || !scratch) return stlt_set_error(STLT_EINVAL, "gelu_bwd: null pointer");
   if (N % 4 || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gelu: column count must be a multiple of 4");
   if (M == 0 || N == 0) return 0;
@@ -510,17 +524,19 @@ int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M
   if ((M + rows - 1) / rows > 512) rows = (M + 511) / 512;  // at most 512 partial rows (scratch >= 512*N floats)
   const int64_t parts = (M + rows - 1) / rows;
   hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)((N + 1023) / 1024), (unsigned)parts), dim3(256), 0, s, dh, u, du, M, (int)N,
-                     rows, scratch, dr, site);
+                     rows, scratch, dr, site, drop_rows);
   if (int e = stlt_check_launch("gelu_bwd_colsum_kernel")) return e;
   return launch_reduce_slabs(scratch, N, (int)parts, g_colsum, N, 1, s);
 }
 
-int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr, uint32_t site) {
+int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows,
+                    int64_t ncols) {
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dh, u, du, n / 4, dr, site);
+  if (drop_rows && (ncols <= 0 || ncols % 4)) return stlt_set_error(STLT_EINVAL, "gelu: row width must be a positive multiple of 4");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dh, u, du, n / 4, dr, site, drop_rows, ncols / 4);
   return stlt_check_launch("gelu_bwd_kernel");
 }
 
@@ -578,9 +594,9 @@ int launch_embed_bwd(const float* dx, const int64_t* categories, const float* bo
 
 int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
                       float* dx_spatial, float* g_pos, float* g_type, hipStream_t s, const int* row_of) {
-  if (!ds || !frame_types || (!dx_spatial && !row_of)) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
+  if (!ds || !frame_types) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
   if (B * T == 0) return 0;
-  if (!row_of) {  // (ragged callers scatter the CLS rows themselves: launch_scatter_rows)
+  if (dx_spatial) {  // null: the caller routes the CLS-row gradient itself (ragged layout / CLS-rows-only last layer)
     hipLaunchKernelGGL(frames_bwd_scatter_kernel, dim3((unsigned)(B * T)), dim3(256), 0, s, ds, B * T, (int)N, (int)d, dx_spatial);
     if (int e = stlt_check_launch("frames_bwd_scatter_kernel")) return e;
   }

@@ -96,7 +96,7 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
                         hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* w, const float* b,
                          float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
-                         uint32_t site = 0);
+                         uint32_t site = 0, const int* drop_rows = nullptr);  // drop_rows: row -> row index used for the dropout mask
 int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
                         const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T,
                         int64_t d, float* out, hipStream_t s, float* pre_out = nullptr, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
@@ -115,6 +115,8 @@ struct RaggedIndex {
   int *counts;                                        // [0] real tokens, [1] real frames, [2] != 0: input breaks the collater contract
 };
 // sp_grp_ptr[g] = first token row of compacted frame g*frames_per_group (g = 0..n_groups), the last entry = n_tokens
+// padded layout: ix.f_cls_row[f] = f*N, ix.last_row[b] = b*T + lengths[b]-1
+int launch_padded_rows(const int64_t* lengths, int64_t B, int64_t T, int64_t N, const RaggedIndex& idx, hipStream_t s);
 int launch_ragged_groups(const RaggedIndex& idx, int64_t n_tokens, int64_t n_frames, int frames_per_group, hipStream_t s);
 int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s);  // dst = 0; dst[rows[i]] = src[i]
 size_t ragged_index_bytes(int64_t B, int64_t T, int64_t N);
@@ -130,13 +132,15 @@ int64_t ln_bwd_scratch_floats(int64_t d);
 int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, const float* b2, int64_t ldb, const float* w,
                   float eps, int64_t M, int64_t d, float* ds, int64_t ldds, float* g_w, float* g_b, float* scratch,
                   hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site_b2 = 0, float* ds_drop = nullptr,
-                  uint32_t site_dy = 0, float* g_colsum = nullptr);  // g_colsum += column sums of the branch gradient (ds_drop, else ds)
+                  uint32_t site_dy = 0, float* g_colsum = nullptr,  // g_colsum += column sums of the branch gradient (ds_drop, else ds)
+                  const int* drop_rows = nullptr);
 int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g, float* scratch, hipStream_t s);
-int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
+int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0,
+                    const int* drop_rows = nullptr, int64_t ncols = 0);
 int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
-                    uint32_t site = 0);
+                    uint32_t site = 0, const int* drop_rows = nullptr, int64_t ncols = 0);
 int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
-                           hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);  // scratch >= 512*N floats
+                           hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0, const int* drop_rows = nullptr);  // scratch >= 512*N floats
 // ragged attention backward: groups of whole segments (rows [grp_ptr[g], grp_ptr[g+1]), at most max_rows <= 64 each)
 struct AttnBwdRagged { const int* grp_ptr; const int* seg_start; const int* seg_end; int64_t n_groups; int64_t n_rows; int max_rows; };
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,

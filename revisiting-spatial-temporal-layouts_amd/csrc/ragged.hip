@@ -117,6 +117,19 @@ __global__ __launch_bounds__(256) void ragged_fill_kernel(const uint8_t* __restr
   }
 }
 
+// padded schedule: the rows the tail layers pick — CLS token of every frame, frame lengths-1 of every clip
+__global__ __launch_bounds__(256) void padded_rows_kernel(const int64_t* __restrict__ lengths, int64_t B, int T, int N,
+                                                          int* __restrict__ cls_row, int* __restrict__ last_row) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < B * T) cls_row[i] = (int)(i * N);
+  if (i < B) {
+    int64_t t = lengths[i] - 1;
+    t = t < 0 ? t + T : t;  // python indexing of lengths-1 == -1
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    last_row[i] = (int)(i * T + t);
+  }
+}
+
 __global__ __launch_bounds__(256) void ragged_groups_kernel(const int* __restrict__ f_cls_row, int n_tokens, int n_frames, int fpg,
                                                             int n_groups, int* __restrict__ grp_ptr) {
   const int g = blockIdx.x * 256 + threadIdx.x;
@@ -205,4 +218,11 @@ int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d,
   if (n == 0) return 0;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, src, rows, n, (int)d, dst);
   return stlt_check_launch("scatter_rows_kernel");
+}
+
+int launch_padded_rows(const int64_t* lengths, int64_t B, int64_t T, int64_t N, const RaggedIndex& ix, hipStream_t s) {
+  if (!lengths) return stlt_set_error(STLT_EINVAL, "padded_rows: null lengths");
+  if (B * T * N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "padded_rows: batch too large for 32-bit row indices");
+  hipLaunchKernelGGL(padded_rows_kernel, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, s, lengths, B, (int)T, (int)N, ix.f_cls_row, ix.last_row);
+  return stlt_check_launch("padded_rows_kernel");
 }

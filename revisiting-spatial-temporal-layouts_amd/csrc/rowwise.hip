@@ -100,17 +100,20 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ x
                                                      const float* __restrict__ res, int64_t ldres,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float eps, int64_t M, int d, float* __restrict__ out,
-                                                     int64_t ldout, StltDrop dr, uint32_t site) {
+                                                     int64_t ldout, StltDrop dr, uint32_t site,
+                                                     const int* __restrict__ drop_rows) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
+  // rows picked out of a larger buffer keep the dropout masks of their original positions
+  const uint64_t drow = (dr.thr && drop_rows) ? (uint64_t)drop_rows[row] : (uint64_t)row;
   f32x4 v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int e = (i * 64 + lane) * 4;
     if (e < d) {
       v[i] = *reinterpret_cast<const f32x4*>(x + row * ldx + e);
-      if (dr.thr) v[i] = stlt_drop4(dr, site, (uint64_t)row * d + e, v[i]);  // dropout1 / dropout2 of the encoder layer (before the residual)
+      if (dr.thr) v[i] = stlt_drop4(dr, site, drow * d + e, v[i]);  // dropout1 / dropout2 of the encoder layer (before the residual)
       if (res) v[i] += *reinterpret_cast<const f32x4*>(res + row * ldres + e);
     } else {
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -202,7 +205,8 @@ int launch_embed(const int64_t* categories, const float* boxes, const float* sco
 }
 
 int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* w, const float* b,
-                         float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s, StltDrop dr, uint32_t site) {
+                         float eps, int64_t M, int64_t d, float* out, int64_t ldout, hipStream_t s, StltDrop dr, uint32_t site,
+                         const int* drop_rows) {
   if (int e = check_d(d)) return e;
   if (!x || !w || !b || !out) return stlt_set_error(STLT_EINVAL, "stlt_add_layernorm_fwd: null pointer");
   if (ldx % 4 || ldout % 4 || (res && ldres % 4)) return stlt_set_error(STLT_EINVAL, "stlt_add_layernorm_fwd: leading dims must be multiples of 4");
@@ -210,7 +214,7 @@ int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
   StltProfScope ps(STLT_K_ADDLN, s);
   dim3 grid((unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((add_ln_kernel<NV>), grid, dim3(256), 0, s, x, ldx, res, ldres, w, b, eps,
-                                            M, (int)d, out, ldout, dr, site));
+                                            M, (int)d, out, ldout, dr, site, drop_rows));
   return stlt_check_launch("add_ln_kernel");
 }
 

@@ -174,6 +174,79 @@ static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, cons
   return 0;
 }
 
+// Last layer of a tower when only n of its M output rows are read afterwards (the CLS row of every frame after
+// the spatial tower, models.py:79; frame lengths-1 of every clip after the temporal tower, models.py:189-192): the
+// in-projection and the attention run on all rows (every row is a key / value), out-proj, norms and FFN on the picked
+// rows only.  Tape: x, qkv, ctx hold M rows; a, x1, u, h, f hold n rows; the gathered ctx / x rows are parked in the
+// unused upper part of a / x1 (rows n..2n-1, hence the 2n <= M condition at the call sites) and re-gathered by the
+// reverse sweep.  Dropout masks keep the indices of the rows' original positions.
+static int layer_forward_tail(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
+                              const uint8_t* kpm, int causal, int kid, const int* seg_start, const int* seg_end, const int* rows,
+                              int64_t n, float* y, StltDrop dr, uint32_t site0, hipStream_t s) {
+  TRY(launch_linear(t.x, d, lp.in_proj_w, lp.in_proj_b, t.qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
+  if (seg_start) TRY(launch_attn_ragged(t.qkv, seg_start, seg_end, causal, M, H, d / H, t.ctx, kid, s, dr, site0));
+  else TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s, dr, site0));
+  float* g_ctx = t.a + n * d;
+  float* g_x = t.x1 + n * d;
+  TRY(launch_gather_rows(t.ctx, d, rows, n, d, g_ctx, s));
+  TRY(launch_gather_rows(t.x, d, rows, n, d, g_x, s));
+  TRY(launch_linear(g_ctx, d, lp.out_proj_w, lp.out_proj_b, t.a, d, n, d, d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(t.a, d, g_x, d, lp.norm1_w, lp.norm1_b, 1e-5f, n, d, t.x1, d, s, dr, site0 + 1, rows));
+  TRY(launch_linear(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, 4 * d, n, 4 * d, d, STLT_ACT_NONE, s));
+  TRY(launch_gelu_fwd(t.u, t.h, n * 4 * d, s, dr, site0 + 2, rows, 4 * d));
+  TRY(launch_linear(t.h, 4 * d, lp.lin2_w, lp.lin2_b, t.f, d, n, d, 4 * d, STLT_ACT_NONE, s));
+  TRY(launch_add_layernorm(t.f, d, t.x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, n, d, y, d, s, dr, site0 + 3, rows));
+  return 0;
+}
+
+static int zero_rows(float* buf, int64_t width, int64_t r0, int64_t r1, hipStream_t s) {
+  if (r1 <= r0) return 0;
+  if (hipError_t e = hipMemsetAsync(buf + r0 * width, 0, (size_t)(r1 - r0) * width * sizeof(float), s); e != hipSuccess)
+    return stlt_set_error((int)e, "train_backward: memset: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// Reverse of layer_forward_tail.  dy: gradient wrt the n output rows; on return bufA holds the gradient wrt all M
+// input rows.  Scratch roles as in layer_backward; the gradient-side operands of the weight-gradient products are
+// zeroed between n and its round-up to 32 first (those rows belong to other layers' data in the shared buffers).
+static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
+                               int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, const int* rows, int64_t n,
+                               const float* dy, float* bufA, float* bufB, float* bufC, float* bufD, float* bufQ, float* bufH,
+                               const Scratch& sc, StltDrop dr, uint32_t site0, hipStream_t s, const AttnBwdRagged* rg) {
+  auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
+  const int64_t np = up32(n);
+  float* br = dr.thr ? bufD : bufB;
+  TRY(zero_rows(bufB, d, n, np, s));
+  TRY(zero_rows(bufD, d, n, np, s));
+  TRY(zero_rows(bufH, 4 * d, n, np, s));
+  // y = LN2(x1 + drop(f))
+  TRY(launch_ln_bwd(dy, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, n, d, bufB, d, G(&stlt_layer_params::norm2_w),
+                    G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0, G(&stlt_layer_params::lin2_b), rows));
+  TRY(weight_grad(br, d, t.h, 4 * d, np, G(&stlt_layer_params::lin2_w), sc, s));
+  TRY(launch_gemm(0, 1, br, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, n, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
+  if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_gelu_bwd_colsum(bufH, t.u, bufH, n, 4 * d, gb, sc.red, s, dr, site0 + 2, rows));
+  else TRY(launch_gelu_bwd(bufH, t.u, bufH, n * 4 * d, s, dr, site0 + 2, rows, 4 * d));
+  TRY(weight_grad(bufH, 4 * d, t.x1, d, np, G(&stlt_layer_params::lin1_w), sc, s));
+  TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, n, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
+  // x1 = LN1(x[rows] + drop(a)), a = ctx[rows]·Woᵀ + bo: gather the two inputs again (bufQ is free until the attention backward)
+  float* g_x = bufQ;
+  float* g_ctx = bufQ + np * d;
+  TRY(launch_gather_rows(t.x, d, rows, n, d, g_x, s));
+  TRY(launch_gather_rows(t.ctx, d, rows, n, d, g_ctx, s));
+  TRY(launch_ln_bwd(bufC, d, g_x, d, t.a, d, lp.norm1_w, 1e-5f, n, d, bufB, d, G(&stlt_layer_params::norm1_w),
+                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufD, 0, G(&stlt_layer_params::out_proj_b), rows));  // bufB = ds1, br = da
+  TRY(weight_grad(br, d, g_ctx, d, np, G(&stlt_layer_params::out_proj_w), sc, s));
+  TRY(launch_gemm(0, 1, br, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, n, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx of the picked rows
+  // the other rows' attention outputs were never read: their dctx is zero
+  TRY(launch_scatter_rows(bufC, rows, n, d, bufH, M, s));                                           // bufH (as M x d) = dctx
+  TRY(launch_attn_bwd(t.qkv, bufH, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv
+  TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
+  TRY(launch_scatter_rows(bufB, rows, n, d, bufC, M, s));                                           // residual path: ds1 on the picked rows only
+  TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, bufC, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
+  // the 4d-wide view of bufH lost its zero rows past M to the dctx image only below M*d floats: nothing to restore
+  return 0;
+}
+
 static int check_train(const stlt_params* p, const stlt_inputs* in) {
   if (!p || !in) return stlt_set_error(STLT_EINVAL, "null params/inputs");
   if (p->d <= 0 || p->H <= 0 || p->d % p->H != 0 || p->d / p->H != 64) return stlt_set_error(STLT_EINVAL, "head dim must be 64");
@@ -228,36 +301,54 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
   // launches over the real rows only (ragged.hip); dropout masks are then drawn per compacted row.
   const bool ragged = (flags & STLT_FLAG_SKIP_PADDING) != 0;
   int64_t tok = B * T * N, BT = B * T;
-  RaggedIndex ix{};
+  const RaggedIndex ix = ragged_index_carve(t.ridx, B, T, N);
   if (ragged) {
-    ix = ragged_index_carve(t.ridx, B, T, N);
     TRY(launch_ragged_index(in->kpm_boxes, in->kpm_frames, in->lengths, B, T, N, ix, s));
     TRY(read_ragged_counts(ix, tok, BT, s));
+  } else {
+    TRY(launch_padded_rows(in->lengths, B, T, N, ix, s));  // rows the tail layers pick: f*N and b*T + lengths-1
   }
+  // the last layer of each tower only has to produce the rows that are read afterwards (layer_forward_tail)
+  const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = p->n_temporal > 0 && 2 * B <= BT;
   float* x0 = p->n_spatial > 0 ? t.sp[0].x : t.sp_out;
   TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
                    p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x0, s, t.s_embed, dr, ragged ? ix.t_orig : nullptr));
   for (int64_t l = 0; l < p->n_spatial; ++l) {
-    float* y = l + 1 < p->n_spatial ? t.sp[l + 1].x : t.sp_out;
-    TRY(layer_forward(p->spatial[l], d, H, t.sp[l], tok, B * T, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, y, dr, (uint32_t)(8 * (l + 1)), s,
-                      ragged ? ix.t_seg_start : nullptr, ragged ? ix.t_seg_end : nullptr));
+    const uint32_t site = (uint32_t)(8 * (l + 1));
+    if (l == p->n_spatial - 1 && sp_tail) {
+      TRY(layer_forward_tail(p->spatial[l], d, H, t.sp[l], tok, B * T, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL,
+                             ragged ? ix.t_seg_start : nullptr, ragged ? ix.t_seg_end : nullptr, ix.f_cls_row, BT, t.sp_out, dr, site, s));
+    } else {
+      float* y = l + 1 < p->n_spatial ? t.sp[l + 1].x : t.sp_out;
+      TRY(layer_forward(p->spatial[l], d, H, t.sp[l], tok, B * T, N, in->kpm_boxes, 0, STLT_K_ATTN_SPATIAL, y, dr, site, s,
+                        ragged ? ix.t_seg_start : nullptr, ragged ? ix.t_seg_end : nullptr));
+    }
   }
   float* g0 = p->n_temporal > 0 ? t.tp[0].x : t.tp_out;
-  if (ragged) {  // CLS rows are not evenly strided any more: gather them (tp_out is free until the last temporal layer writes it)
-    TRY(launch_gather_rows(t.sp_out, d, ix.f_cls_row, BT, d, t.tp_out, s));
-    TRY(launch_frames_embed(t.tp_out, d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b, p->ln_eps, B, T,
-                            d, g0, s, t.s_frames, dr, ix.f_orig, BT));
-  } else {
-    TRY(launch_frames_embed(t.sp_out, N * d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b,
-                            p->ln_eps, B, T, d, g0, s, t.s_frames, dr));
+  const float* cls = t.sp_out;  // (frames, d) when the tail layer ran, else the CLS rows inside the token buffer
+  int64_t cls_stride = d;
+  if (!sp_tail) {
+    if (ragged) {  // CLS rows are not evenly strided: gather them (tp_out is free until the last temporal layer writes it)
+      TRY(launch_gather_rows(t.sp_out, d, ix.f_cls_row, BT, d, t.tp_out, s));
+      cls = t.tp_out;
+    } else {
+      cls_stride = N * d;
+    }
   }
+  TRY(launch_frames_embed(cls, cls_stride, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b, p->ln_eps, B, T,
+                          d, g0, s, t.s_frames, dr, ragged ? ix.f_orig : nullptr, BT));
   for (int64_t l = 0; l < p->n_temporal; ++l) {
-    float* y = l + 1 < p->n_temporal ? t.tp[l + 1].x : t.tp_out;
-    TRY(layer_forward(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, y, dr,
-                      (uint32_t)(8 * (p->n_spatial + l + 1)), s, ragged ? ix.f_seg_start : nullptr, ragged ? ix.f_seg_end : nullptr));
+    const uint32_t site = (uint32_t)(8 * (p->n_spatial + l + 1));
+    if (l == p->n_temporal - 1 && tp_tail) {
+      TRY(layer_forward_tail(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL,
+                             ragged ? ix.f_seg_start : nullptr, ragged ? ix.f_seg_end : nullptr, ix.last_row, B, t.h0, dr, site, s));
+    } else {
+      float* y = l + 1 < p->n_temporal ? t.tp[l + 1].x : t.tp_out;
+      TRY(layer_forward(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, y, dr, site, s,
+                        ragged ? ix.f_seg_start : nullptr, ragged ? ix.f_seg_end : nullptr));
+    }
   }
-  if (ragged) TRY(launch_gather_rows(t.tp_out, d, ix.last_row, B, d, t.h0, s));
-  else TRY(launch_gather_last(t.tp_out, in->lengths, B, T, d, t.h0, s));
+  if (!tp_tail) TRY(launch_gather_rows(t.tp_out, d, ix.last_row, B, d, t.h0, s));                    // models.py:189-192
   TRY(launch_linear(t.h0, d, p->fc1_w, p->fc1_b, t.u0, d, B, d, d, STLT_ACT_NONE, s));
   TRY(launch_gelu_fwd(t.u0, t.z1, B * d, s));
   TRY(launch_add_layernorm(t.z1, d, nullptr, 0, p->head_ln_w, p->head_ln_b, p->ln_eps, B, d, t.z2, d, s));
@@ -285,10 +376,9 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // contract over the row count rounded up to 32, so the gradient-side operands' rows between the count and its
   // round-up are zeroed here (the padded schedule never dirties them; a ragged row count changes every step).
   const bool ragged = (flags & STLT_FLAG_SKIP_PADDING) != 0;
-  RaggedIndex ix{};
+  const RaggedIndex ix = ragged_index_carve(t.ridx, B, T, N);  // filled by the forward (ragged index, or the padded layout's picked rows)
   AttnBwdRagged rg_sp{}, rg_tp{};
   if (ragged) {
-    ix = ragged_index_carve(t.ridx, B, T, N);
     TRY(read_ragged_counts(ix, tok, BT, s));
     tokp = up32(tok);
     btp = up32(BT);
@@ -297,20 +387,14 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     TRY(launch_ragged_groups(ix, tok, BT, fpg, s));
     rg_sp = AttnBwdRagged{ix.sp_grp_ptr, ix.t_seg_start, ix.t_seg_end, (BT + fpg - 1) / fpg, tok, (int)(fpg * N)};
     rg_tp = AttnBwdRagged{ix.clip_frm_off, ix.f_seg_start, ix.f_seg_end, B, BT, (int)T};
-    auto zero_pad = [&](float* buf, int64_t width, int64_t rows, int64_t rows_p) -> int {
-      if (rows_p == rows) return 0;
-      if (hipError_t e = hipMemsetAsync(buf + rows * width, 0, (size_t)(rows_p - rows) * width * sizeof(float), s); e != hipSuccess)
-        return stlt_set_error((int)e, "train_backward: memset: %s", hipGetErrorString(e));
-      return 0;
-    };
-    for (float* b : {sc.sB, sc.sD}) TRY(zero_pad(b, d, tok, tokp));
-    TRY(zero_pad(sc.sQKV, 3 * d, tok, tokp));
-    TRY(zero_pad(sc.sH, 4 * d, tok, tokp));
-    for (float* b : {sc.tB, sc.tD}) TRY(zero_pad(b, d, BT, btp));
-    TRY(zero_pad(sc.tQKV, 3 * d, BT, btp));
-    TRY(zero_pad(sc.tH, 4 * d, BT, btp));
+    for (float* b : {sc.sB, sc.sD}) TRY(zero_rows(b, d, tok, tokp, s));
+    TRY(zero_rows(sc.sQKV, 3 * d, tok, tokp, s));
+    TRY(zero_rows(sc.sH, 4 * d, tok, tokp, s));
+    for (float* b : {sc.tB, sc.tD}) TRY(zero_rows(b, d, BT, btp, s));
+    TRY(zero_rows(sc.tQKV, 3 * d, BT, btp, s));
+    TRY(zero_rows(sc.tH, 4 * d, BT, btp, s));
   }
-
+  const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = p->n_temporal > 0 && 2 * B <= BT;  // as the forward decided
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
   if (g->fc2_b) TRY(launch_colsum_acc(dlogits, K, B, K, W(g->fc2_b), sc.red, s));
@@ -321,25 +405,37 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   if (g->fc1_w) TRY(launch_small_gemm(sc.hB, 1, d, t.h0, d, 1, W(g->fc1_w), d, d, d, B, 1, s));     // (d,d) += du0ᵀ·h0
   if (g->fc1_b) TRY(launch_colsum_acc(sc.hB, d, B, d, W(g->fc1_b), sc.red, s));
   TRY(launch_small_gemm(sc.hB, d, 1, p->fc1_w, d, 1, sc.hA, d, B, d, d, 0, s));                     // hA = dh0
-  if (ragged) TRY(launch_scatter_rows(sc.hA, ix.last_row, B, d, sc.tA, btp, s));                    // tA = d(backbone out)
-  else TRY(launch_scatter_last(sc.hA, in->lengths, B, T, d, sc.tA, s));
-
   // ---- temporal transformer
-  for (int64_t l = p->n_temporal - 1; l >= 0; --l)
+  int64_t l_tp = p->n_temporal - 1;
+  if (tp_tail) {
+    TRY(layer_backward_tail(p->temporal[l_tp], g->temporal ? &g->temporal[l_tp] : nullptr, t.tp[l_tp], d, H, BT, btp, B, T, in->kpm_frames, 1,
+                            ix.last_row, B, sc.hA, sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr,
+                            (uint32_t)(8 * (p->n_spatial + l_tp + 1)), s, ragged ? &rg_tp : nullptr));
+    --l_tp;
+  } else {
+    TRY(launch_scatter_rows(sc.hA, ix.last_row, B, d, sc.tA, btp, s));                              // tA = d(backbone out)
+  }
+  for (int64_t l = l_tp; l >= 0; --l)
     TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
                        sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s,
                        ragged ? &rg_tp : nullptr));
   // ---- frames embeddings (models.py:98-111)
   TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, sc.tB, d, W(g->frames_ln_w),
-                    W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));
-  if (ragged) {
-    TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, nullptr, W(g->pos_emb), W(g->type_emb), s, ix.f_row_of));
-    TRY(launch_scatter_rows(sc.tB, ix.f_cls_row, BT, d, sc.sA, tokp, s));                           // sA = d(spatial out), CLS rows only
-  } else {
-    TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, sc.sA, W(g->pos_emb), W(g->type_emb), s));  // sA = d(spatial out), CLS rows only
-  }
+                    W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));                // tB = gradient wrt the frames' CLS rows
+  const bool dense_scatter = !ragged && !sp_tail;  // padded dense schedule: the CLS rows sit at stride N in the token buffer
+  TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, dense_scatter ? sc.sA : nullptr, W(g->pos_emb), W(g->type_emb), s,
+                        ragged ? ix.f_row_of : nullptr));
   // ---- spatial transformer
-  for (int64_t l = p->n_spatial - 1; l >= 0; --l)
+  int64_t l_sp = p->n_spatial - 1;
+  if (sp_tail) {
+    TRY(layer_backward_tail(p->spatial[l_sp], g->spatial ? &g->spatial[l_sp] : nullptr, t.sp[l_sp], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
+                            ix.f_cls_row, BT, sc.tB, sc.sA, sc.sB, sc.sC, sc.sD, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l_sp + 1)), s,
+                            ragged ? &rg_sp : nullptr));
+    --l_sp;
+  } else if (ragged) {
+    TRY(launch_scatter_rows(sc.tB, ix.f_cls_row, BT, d, sc.sA, tokp, s));                            // sA = d(spatial out), CLS rows only
+  }
+  for (int64_t l = l_sp; l >= 0; --l)
     TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
                        sc.sA, sc.sB, sc.sC, sc.sD, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr));
   // ---- category / box / score embeddings (models.py:29-39)
