@@ -402,30 +402,31 @@ __global__ __launch_bounds__(256) void frames_bwd_scatter_kernel(const float* __
 
 __global__ __launch_bounds__(256) void frames_bwd_params_kernel(const float* __restrict__ ds,
                                                                 const int64_t* __restrict__ frame_types, int64_t B, int T,
-                                                                int d, float* __restrict__ g_pos, float* __restrict__ g_type,
+                                                                int d, float* __restrict__ partials /* [chunks][T+5][d] */,
                                                                 const int* __restrict__ row_of /* ragged: frame b*T+t -> row of ds, -1 = padded */) {
-  // grid.y = T position rows followed by 5 type rows; fixed summation order over clips
+  // grid = (column blocks, T position rows followed by 5 type rows, clip chunks); a block sums its chunk of clips in
+  // clip order, the chunk partials are added in chunk order afterwards: fixed summation order
   const int row = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d) return;
+  const int64_t per = (B + gridDim.z - 1) / gridDim.z;
+  const int64_t b0 = (int64_t)blockIdx.z * per, b1 = b0 + per < B ? b0 + per : B;
   float acc = 0.f;
   if (row < T) {
-    for (int64_t b = 0; b < B; ++b) {
+    for (int64_t b = b0; b < b1; ++b) {
       const int64_t r = row_of ? row_of[b * T + row] : b * T + row;
       if (r >= 0) acc += ds[r * d + c];
     }
-    if (g_pos) g_pos[(int64_t)row * d + c] += acc;
-  } else {
+  } else if (row - T != 0) {  // frame type 0 is the padding index: no gradient (models.py:91)
     const int ft = row - T;
-    if (ft == 0 || !g_type) return;
-    for (int64_t i = 0; i < B * T; ++i) {
+    for (int64_t i = b0 * T; i < b1 * T; ++i) {
       int64_t v = frame_types[i];
       v = v < 0 ? 0 : (v > 4 ? 4 : v);
       const int64_t r = row_of ? row_of[i] : i;
       if (v == ft && r >= 0) acc += ds[r * d + c];
     }
-    g_type[(int64_t)ft * d + c] += acc;
   }
+  partials[((int64_t)blockIdx.z * (T + 5) + row) * d + c] = acc;
 }
 
 // ------------------------------------------------------------------ K8a backward: scatter the head's input gradient
@@ -478,7 +479,7 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   if (!dy || !a || !w || !ds || !scratch) return stlt_set_error(STLT_EINVAL, "ln_bwd: null pointer");
   if (d <= 0 || d % 4 || d > 2048) return stlt_set_error(STLT_EINVAL, "ln_bwd: bad d=%lld", (long long)d);
   if (M == 0) return 0;
-  int64_t blocks = (M + 16 * RW_WAVES - 1) / (16 * RW_WAVES);  // ~16 rows per persistent wave
+  int64_t blocks = (M + 4 * RW_WAVES - 1) / (4 * RW_WAVES);  // ~4 rows per persistent wave until the cap binds
   if (blocks > 512) blocks = 512;  // one partial row set per block (scratch is sized for that)
   StltProfScope ps(STLT_K_ADDLN, s);
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
@@ -593,16 +594,20 @@ int launch_embed_bwd(const float* dx, const int64_t* categories, const float* bo
 }
 
 int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
-                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s, const int* row_of) {
-  if (!ds || !frame_types) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
+                      float* dx_spatial, float* g_pos, float* g_type, float* scratch, hipStream_t s, const int* row_of) {
+  if (!ds || !frame_types || !scratch) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
   if (B * T == 0) return 0;
   if (dx_spatial) {  // null: the caller routes the CLS-row gradient itself (ragged layout / CLS-rows-only last layer)
     hipLaunchKernelGGL(frames_bwd_scatter_kernel, dim3((unsigned)(B * T)), dim3(256), 0, s, ds, B * T, (int)N, (int)d, dx_spatial);
     if (int e = stlt_check_launch("frames_bwd_scatter_kernel")) return e;
   }
-  hipLaunchKernelGGL(frames_bwd_params_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)(T + 5)), dim3(256), 0, s, ds,
-                     frame_types, B, (int)T, (int)d, g_pos, g_type, row_of);
-  return stlt_check_launch("frames_bwd_params_kernel");
+  const int chunks = B < 16 ? (int)B : 16;  // scratch >= 16 * (T+5) * d floats
+  hipLaunchKernelGGL(frames_bwd_params_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)(T + 5), (unsigned)chunks), dim3(256), 0, s, ds,
+                     frame_types, B, (int)T, (int)d, scratch, row_of);
+  if (int e = stlt_check_launch("frames_bwd_params_kernel")) return e;
+  if (g_pos) { if (int e = launch_reduce_slabs(scratch, (T + 5) * d, chunks, g_pos, T * d, 1, s)) return e; }
+  if (g_type) { if (int e = launch_reduce_slabs(scratch + T * d, (T + 5) * d, chunks, g_type, 5 * d, 1, s)) return e; }
+  return 0;
 }
 
 int launch_scatter_last(const float* dh, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* dout, hipStream_t s) {

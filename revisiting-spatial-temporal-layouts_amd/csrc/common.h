@@ -151,7 +151,8 @@ int launch_embed_bwd(const float* dx, const int64_t* categories, const float* bo
                      int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,
                      float* g_score_b, float* scratch, hipStream_t s, const int* src_index = nullptr);
 int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
-                      float* dx_spatial, float* g_pos, float* g_type, hipStream_t s, const int* row_of = nullptr);
+                      float* dx_spatial, float* g_pos, float* g_type, float* scratch, hipStream_t s,
+                      const int* row_of = nullptr);  // scratch >= 16*(T+5)*d floats
 int launch_scatter_last(const float* dh, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* dout, hipStream_t s);
 int launch_small_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk, int64_t sbn, float* c,
                       int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t s);

@@ -82,6 +82,7 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   s.slabs = take((int64_t)s.slab_floats);
   int64_t red = ln_bwd_scratch_floats(d);
   if (512 * 4 * d > red) red = 512 * 4 * d;  // gelu_bwd column-sum partials (512 x 4d); attn_bwd needs 256 x 3d
+  if (16 * (T + 5) * d > red) red = 16 * (T + 5) * d;  // frames-embedding parameter partials
   const int64_t eb = embed_bwd_scratch_floats(B * T * N, C, d);
   if (eb > red) red = eb;
   s.red = take(red);
@@ -423,7 +424,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, sc.tB, d, W(g->frames_ln_w),
                     W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));                // tB = gradient wrt the frames' CLS rows
   const bool dense_scatter = !ragged && !sp_tail;  // padded dense schedule: the CLS rows sit at stride N in the token buffer
-  TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, dense_scatter ? sc.sA : nullptr, W(g->pos_emb), W(g->type_emb), s,
+  TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, dense_scatter ? sc.sA : nullptr, W(g->pos_emb), W(g->type_emb), sc.red, s,
                         ragged ? ix.f_row_of : nullptr));
   // ---- spatial transformer
   int64_t l_sp = p->n_spatial - 1;
