@@ -92,6 +92,13 @@ int stlt_attn_cross_fwd(const float* q, int64_t ldq, const float* k, const float
                         int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx,
                         stlt_stream_t stream);
 
+/* K3 on a ragged layout: self-attention over M compacted rows of a packed (M, 3*H*dh) buffer cut into variable-length
+ * segments (one frame's objects, one clip's frames) — what STLT_FLAG_SKIP_PADDING runs instead of the padded K3.
+ * seg_start[r] / seg_end[r] (int32, device): first row / one past the last row of row r's segment; segments are
+ * contiguous and cover [0, M).  ctx[r] = softmax over the keys of r's segment (only those at rows <= r when causal). */
+int stlt_attn_ragged_fwd(const float* qkv, const int32_t* seg_start, const int32_t* seg_end, int causal, int64_t M,
+                         int64_t H, int64_t dh, float* ctx, stlt_stream_t stream);
+
 /* Residual + LayerNorm (norm1/norm2 of nn.TransformerEncoderLayer, eps 1e-5; ClassificationHead.layer_norm
  * models.py:159,163 with res == NULL).  out[m,:] = LN_eps( x[m*ldx + :] + res[m*ldres + :] ). */
 int stlt_add_layernorm_fwd(const float* x, int64_t ldx, const float* res, int64_t ldres,

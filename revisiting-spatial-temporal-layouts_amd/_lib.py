@@ -86,6 +86,7 @@ SIGNATURES = {
     "stlt_attn_core_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_attn_cross_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_int64, C.c_int64, _vp, _vp]),
+    "stlt_attn_ragged_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_add_layernorm_fwd": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_float, C.c_int64, C.c_int64,
                                          _vp, C.c_int64, _vp]),
     "stlt_frames_embed_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64,

@@ -133,6 +133,12 @@ int stlt_attn_cross_fwd(const float* q, int64_t ldq, const float* k, const float
                              causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL, (hipStream_t)stream);
 }
 
+int stlt_attn_ragged_fwd(const float* qkv, const int32_t* seg_start, const int32_t* seg_end, int causal, int64_t M, int64_t H,
+                         int64_t dh, float* ctx, stlt_stream_t stream) {
+  return launch_attn_ragged(qkv, seg_start, seg_end, causal, M, H, dh, ctx, causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL,
+                            (hipStream_t)stream);
+}
+
 int stlt_add_layernorm_fwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* ln_w,
                            const float* ln_b, float eps, int64_t M, int64_t d, float* out, int64_t ldout,
                            stlt_stream_t stream) {

@@ -156,6 +156,25 @@ def attn_cross(q: torch.Tensor, kv: torch.Tensor, kpm_k: Optional[torch.Tensor],
     return ctx
 
 
+def attn_ragged(qkv: torch.Tensor, seg_lengths, heads: int, causal: bool = False) -> torch.Tensor:
+    """Self-attention over compacted rows cut into consecutive segments of the given lengths (include/stlt_hip.h:
+    stlt_attn_ragged_fwd).  qkv: (M, 3*d) packed [q;k;v] rows, M = sum(seg_lengths). -> (M, d)"""
+    lib = L.load()
+    _chk(qkv, torch.float32, "qkv")
+    M, d3 = qkv.shape
+    d = d3 // 3
+    lens = torch.as_tensor(seg_lengths, dtype=torch.int64)
+    assert int(lens.sum()) == M and bool((lens > 0).all())
+    ends = torch.cumsum(lens, 0)
+    starts = ends - lens
+    seg_start = torch.repeat_interleave(starts, lens).to(torch.int32).to(qkv.device)
+    seg_end = torch.repeat_interleave(ends, lens).to(torch.int32).to(qkv.device)
+    ctx = torch.empty(M, d, device=qkv.device, dtype=torch.float32)
+    L.check(lib.stlt_attn_ragged_fwd(_p(qkv), _p(seg_start), _p(seg_end), int(causal), M, heads, d // heads, _p(ctx), _stream()),
+            "stlt_attn_ragged_fwd")
+    return ctx
+
+
 def add_layernorm(x: torch.Tensor, res: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor, eps: float):
     """out = LayerNorm_eps(x + res) over the last dim (res may be None)."""
     lib = L.load()

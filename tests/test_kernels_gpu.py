@@ -243,3 +243,24 @@ def test_gemm_scratch_too_small_is_rejected(pkg):
     buf = torch.empty(1024, dtype=torch.uint8, device=DEV)
     assert lib.stlt_gemm_set_scratch(buf.data_ptr(), 1024) != 0
     assert lib.stlt_gemm_set_scratch(None, 0) == 0
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("lens", [[7, 1, 3, 7, 7, 2, 5], [1] * 70, [32, 17, 32, 5], [64, 3, 70, 1, 33], [5], [31, 1, 32, 33, 64, 2, 2, 2]])
+def test_attn_ragged_matches_per_segment_softmax(pkg, lens, causal):
+    """Ragged K3: segments shorter than, equal to and longer than the 32-row tile, straddling tile boundaries."""
+    H = 4
+    d = 64 * H
+    M = sum(lens)
+    qkv = _rand(M, 3 * d, seed=M + int(causal), scale=1.5)
+    got = pkg.ops.attn_ragged(qkv.to(DEV), lens, H, causal=causal).cpu()
+    ref = torch.zeros(M, d, dtype=torch.float64)
+    r0 = 0
+    for n in lens:
+        q, k, v = [qkv[r0:r0 + n, i * d:(i + 1) * d].double().view(n, H, 64).transpose(0, 1) for i in range(3)]
+        sc = q @ k.transpose(1, 2) / 8.0
+        if causal:
+            sc = sc.masked_fill(torch.ones(n, n, dtype=torch.bool).triu(1), float("-inf"))
+        ref[r0:r0 + n] = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(n, d)
+        r0 += n
+    assert (got.double() - ref).abs().max().item() <= 2e-5
