@@ -162,6 +162,9 @@ typedef struct {
 #define STLT_FLAG_SKIP_PADDING 4 /* stlt_forward with out_btd == NULL: compute the real (unmasked) tokens and frames only.  Same logits: a padded row is
                                    masked as a key everywhere and never read as a query result.  Implies both flags above.  Needs collater-shaped
                                    masks (slot 0 of a real frame unmasked, frame lengths-1 real); synchronises the stream once per call. */
+#define STLT_FLAG_TRAIN_UPPER_ONLY 8   /* stlt_train_backward: stop after the prediction head and the temporal tower (their gradients are final) */
+#define STLT_FLAG_TRAIN_LOWER_ONLY 16  /* stlt_train_backward: resume from there (frames embeddings, spatial tower, token embeddings); the scratch must be
+                                          untouched in between.  Lets a data-parallel caller all-reduce the upper gradients while the lower half runs. */
 #define STLT_FLAG_LAST_ROW_ONLY_TEMPORAL 2 /* stlt_forward with out_btd == NULL: last temporal layer's out-proj/FFN on the rows at lengths-1 only (models.py:189-192) */
 
 /* bytes of scratch the whole-path calls need for this shape */

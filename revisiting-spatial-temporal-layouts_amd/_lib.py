@@ -12,6 +12,8 @@ K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "f
 FLAG_CLS_ONLY_LAST_SPATIAL = 1
 FLAG_LAST_ROW_ONLY_TEMPORAL = 2
 FLAG_SKIP_PADDING = 4
+FLAG_TRAIN_UPPER_ONLY = 8
+FLAG_TRAIN_LOWER_ONLY = 16
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _f = C.POINTER(C.c_float)

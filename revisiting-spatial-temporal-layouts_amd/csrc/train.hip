@@ -396,6 +396,9 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     TRY(zero_rows(sc.tH, 4 * d, BT, btp, s));
   }
   const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = p->n_temporal > 0 && 2 * B <= BT;  // as the forward decided
+  const bool do_upper = !(flags & STLT_FLAG_TRAIN_LOWER_ONLY), do_lower = !(flags & STLT_FLAG_TRAIN_UPPER_ONLY);
+  if (!do_upper && !do_lower) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: UPPER_ONLY and LOWER_ONLY exclude each other");
+  if (do_upper) {
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
   if (g->fc2_b) TRY(launch_colsum_acc(dlogits, K, B, K, W(g->fc2_b), sc.red, s));
@@ -420,6 +423,8 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
                        sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s,
                        ragged ? &rg_tp : nullptr));
+  }  // upper half: sc.tA now holds the gradient wrt the temporal tower's input
+  if (!do_lower) return 0;
   // ---- frames embeddings (models.py:98-111)
   TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, sc.tB, d, W(g->frames_ln_w),
                     W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));                // tB = gradient wrt the frames' CLS rows

@@ -403,10 +403,28 @@ class _StltTrainFn(torch.autograd.Function):
         tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, p.n_spatial, p.n_temporal)), device)
         scratch = bb._train_buf("scratch", int(lib.stlt_train_scratch_bytes(B, T, N, d, p.n_categories)), device)
         dl = dlogits.contiguous().float()
-        with torch.cuda.device(device):
+        model._last_flat_grad = flat
+        model._flat_layout = layout
+
+        def run(extra_flags):
             L.check(lib.stlt_train_backward(C.byref(p), C.byref(g), C.byref(inp), tape.data_ptr(), tape.numel(),
                                             scratch.data_ptr(), scratch.numel(), dl.data_ptr(), ctx.drop[0], ctx.drop[1],
-                                            ctx.drop[2], torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
+                                            ctx.drop[2] | extra_flags, torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
+
+        sync = getattr(model, "_grad_sync", None)  # data-parallel hook: sync(flat, lo, hi) may start reducing flat[lo:hi]
+        with torch.cuda.device(device):
+            if sync is None:
+                run(0)
+            else:
+                # the temporal tower and the head come last in parameter order and first in the reverse sweep: their
+                # gradients are final after the upper half, and can travel while the lower half computes
+                upper = {id(q) for q in model.backbone.transformer.parameters()} | {id(q) for q in model.prediction_head.parameters()}
+                split = min((o for q, o, n in layout if id(q) in upper), default=off)
+                assert all((id(q) in upper) == (o >= split) for q, o, n in layout), "temporal tower + head must be the tail of the flat buffer"
+                run(L.FLAG_TRAIN_UPPER_ONLY)
+                sync(flat, split, off)
+                run(L.FLAG_TRAIN_LOWER_ONLY)
+                sync(flat, 0, split)
         model._last_flat_grad = flat  # one contiguous buffer: what a data-parallel wrapper all-reduces
         model._flat_layout = layout
         if getattr(model, "_flat_grads_only", False):  # train.FusedAdamW reads the flat buffer: skip the per-parameter .grad copies

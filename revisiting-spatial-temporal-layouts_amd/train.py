@@ -145,12 +145,27 @@ class Trainer:
         opt = FusedAdamW if fused_optimizer else torch.optim.AdamW  # same defaults (betas 0.9/0.999, eps 1e-8)
         self.optimizer = opt(add_weight_decay(model, weight_decay), lr=learning_rate)
         self.scheduler = linear_schedule_with_warmup(self.optimizer, warmup_steps, total_steps)
+        self._comm_stream = None
+
+    def _sync_slice(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        """Called by the native backward when flat[lo:hi] is final: average it over the ranks on a side stream, so the
+        all-reduce of the temporal tower's gradients overlaps the spatial half of the reverse sweep."""
+        if hi <= lo:
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=flat.device)
+        self._comm_stream.wait_stream(torch.cuda.current_stream(flat.device))
+        with torch.cuda.stream(self._comm_stream):
+            part = flat[lo:hi]
+            torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM)
+            part.div_(self.world)
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
         """One optimisation step on this rank's shard of the global batch (train.py:119-135)."""
         self.model.train(True)
         self.optimizer.zero_grad()
         self.model._flat_grads_only = self.fused
+        self.model._grad_sync = self._sync_slice if (self.fused and self.world > 1) else None
         logits = self.model(batch)
         loss = criterion(logits, batch["labels"], self.dataset_name)
         loss.backward()
@@ -158,9 +173,8 @@ class Trainer:
             # the reverse sweep left every gradient in one flat buffer: all-reduce it in place, then norm + clip +
             # AdamW straight from it (no per-parameter .grad tensors, no flatten / unflatten copies)
             flat, layout = self.model._last_flat_grad, self.model._flat_layout
-            if self.world > 1:
-                torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
-                flat.div_(self.world)
+            if self._comm_stream is not None:  # the slices were reduced on the side stream as they became final
+                torch.cuda.current_stream(flat.device).wait_stream(self._comm_stream)
             grad_norm = self.optimizer.step_flat(flat, layout, self.clip_val)
         else:
             allreduce_gradients(self.model, self.world)
