@@ -256,6 +256,13 @@ typedef struct {
   int32_t n;
   float weight_decay;
 } stlt_opt_chunk;
+/* Criterion of the reference (utils/train_inference_utils.py:64-76) and its gradient in one pass: loss_out[0] = weight *
+ * mean loss, dlogits = weight * d(mean loss)/d(logits).  CROSS_ENTROPY: labels int64 (B); BCE_WITH_LOGITS: labels float
+ * (B,K) multi-hot.  `weight` = 1 / number of logit heads (the reference averages the heads' losses).  scratch: >= B floats. */
+#define STLT_LOSS_CROSS_ENTROPY 0
+#define STLT_LOSS_BCE_WITH_LOGITS 1
+int stlt_loss_fwd_bwd(const float* logits, const void* labels, int kind, int64_t B, int64_t K, float weight,
+                      float* scratch, float* loss_out, float* dlogits, stlt_stream_t stream);
 int stlt_grad_norm(const float* flat_grad, int64_t n, float max_norm, float* scratch, float* out, stlt_stream_t stream);
 int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const float* flat_grad, float* exp_avg, float* exp_avg_sq,
                     const float* norm_and_clip, float lr, float beta1, float beta2, float eps, int64_t step, stlt_stream_t stream);

@@ -106,6 +106,7 @@ SIGNATURES = {
     "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
     "stlt_train_backward": (C.c_int, [C.POINTER(Params), C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp,
                                       C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
+    "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
     "stlt_grad_norm": (C.c_int, [_vp, C.c_int64, C.c_float, _vp, _vp, _vp]),
     "stlt_adamw_step": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
     "stlt_prof_enable": (C.c_int, [C.c_int]),

@@ -117,3 +117,83 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Criterion (reference utils/train_inference_utils.py:64-76) with its gradient in one pass: CrossEntropyLoss
+// ("something", int64 class labels) or BCEWithLogitsLoss ("action_genome", float multi-hot labels), both with the
+// default mean reduction.  One block per clip writes the clip's loss term and its dlogits row; a one-block finish sums
+// the terms in clip order (deterministic).
+namespace {
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = is_max ? fmaxf(red[threadIdx.x], red[threadIdx.x + o]) : red[threadIdx.x] + red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict__ logits, const void* __restrict__ labels, int kind,
+                                                        int K, float grad_scale, float* __restrict__ row_loss,
+                                                        float* __restrict__ dlogits) {
+  __shared__ float red[256];
+  const int64_t b = blockIdx.x;
+  const float* x = logits + b * K;
+  float* dx = dlogits + b * K;
+  if (kind == STLT_LOSS_CROSS_ENTROPY) {
+    int64_t y = static_cast<const int64_t*>(labels)[b];
+    y = y < 0 ? 0 : (y >= K ? K - 1 : y);
+    float m = -INFINITY;
+    for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, x[k]);
+    m = block_reduce(m, red, true);
+    float sum = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) sum += expf(x[k] - m);
+    sum = block_reduce(sum, red, false);
+    const float lse = m + logf(sum);
+    for (int k = threadIdx.x; k < K; k += 256) dx[k] = (expf(x[k] - lse) - (k == y ? 1.0f : 0.0f)) * grad_scale;
+    if (threadIdx.x == 0) row_loss[b] = lse - x[y];
+  } else {
+    const float* y = static_cast<const float*>(labels) + b * K;
+    float sum = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float v = x[k], t = y[k];
+      sum += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));  // numerically stable BCE-with-logits term
+      dx[k] = (1.0f / (1.0f + expf(-v)) - t) * grad_scale;
+    }
+    sum = block_reduce(sum, red, false);
+    if (threadIdx.x == 0) row_loss[b] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ row_loss, int64_t B, float scale, float* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += 256) acc += (double)row_loss[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+}
+
+}  // namespace
+
+extern "C" int stlt_loss_fwd_bwd(const float* logits, const void* labels, int kind, int64_t B, int64_t K, float weight,
+                                 float* scratch, float* loss_out, float* dlogits, stlt_stream_t stream) {
+  if (!logits || !labels || !scratch || !loss_out || !dlogits) return stlt_set_error(STLT_EINVAL, "stlt_loss_fwd_bwd: null pointer");
+  if (kind != STLT_LOSS_CROSS_ENTROPY && kind != STLT_LOSS_BCE_WITH_LOGITS) return stlt_set_error(STLT_EINVAL, "stlt_loss_fwd_bwd: unknown loss %d", kind);
+  if (B <= 0 || K <= 0 || K > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_loss_fwd_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  // mean reduction: over the clips (cross entropy) or over all B*K elements (BCE)
+  const float mean = kind == STLT_LOSS_CROSS_ENTROPY ? 1.0f / (float)B : 1.0f / ((float)B * (float)K);
+  hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, labels, kind, (int)K, weight * mean, scratch, dlogits);
+  if (int e = stlt_check_launch("loss_rows_kernel")) return e;
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, scratch, B, weight * mean, loss_out);
+  return stlt_check_launch("loss_finish_kernel");
+}

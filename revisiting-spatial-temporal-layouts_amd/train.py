@@ -44,6 +44,24 @@ def criterion(logits: Dict[str, torch.Tensor], labels: torch.Tensor, dataset_nam
     return sum(fn(v, labels) for v in logits.values()) / len(logits)
 
 
+def fused_criterion(logits: torch.Tensor, labels: torch.Tensor, dataset_name: str = "something", weight: float = 1.0):
+    """Loss and d(loss)/d(logits) of one logit head in one native pass (include/stlt_hip.h: stlt_loss_fwd_bwd).
+    -> (loss scalar tensor, dlogits): feed `logits.backward(dlogits)`."""
+    from . import _lib as L
+    lib = L.load()
+    B, K = logits.shape
+    x = logits.detach().contiguous().float()
+    if dataset_name == "something":
+        kind, y = 0, labels.to(torch.int64).contiguous()
+    else:
+        kind, y = 1, labels.to(torch.float32).contiguous()
+    out = torch.empty(B + 1, device=x.device, dtype=torch.float32)
+    dlogits = torch.empty_like(x)
+    L.check(lib.stlt_loss_fwd_bwd(x.data_ptr(), y.data_ptr(), kind, B, K, float(weight), out.data_ptr(), out[B:].data_ptr(),
+                                  dlogits.data_ptr(), torch.cuda.current_stream().cuda_stream), "stlt_loss_fwd_bwd")
+    return out[B], dlogits
+
+
 def allreduce_gradients(model: torch.nn.Module, world: int) -> None:
     """Average the gradients over ranks with one flat all-reduce (parameters without a gradient — the dead
     `encoder_layer` copy, unused `score_embeddings`, frozen weights — are skipped on every rank alike)."""
@@ -167,8 +185,17 @@ class Trainer:
         self.model._flat_grads_only = self.fused
         self.model._grad_sync = self._sync_slice if (self.fused and self.world > 1) else None
         logits = self.model(batch)
-        loss = criterion(logits, batch["labels"], self.dataset_name)
-        loss.backward()
+        if self.fused:  # loss + dlogits in one pass per head, then straight into the native reverse sweep
+            loss, heads = 0.0, list(logits.values())
+            grads = []
+            for v in heads:
+                l, g = fused_criterion(v, batch["labels"], self.dataset_name, 1.0 / len(heads))
+                loss = loss + l
+                grads.append(g)
+            torch.autograd.backward(heads, grads)
+        else:
+            loss = criterion(logits, batch["labels"], self.dataset_name)
+            loss.backward()
         if self.fused:
             # the reverse sweep left every gradient in one flat buffer: all-reduce it in place, then norm + clip +
             # AdamW straight from it (no per-parameter .grad tensors, no flatten / unflatten copies)

@@ -313,3 +313,22 @@ def test_trainer_fused_and_stock_optimizer_agree(pkg):
             d = a.numel() // 3
             a, b = torch.cat([a[:d], a[2 * d:]]), torch.cat([b[:d], b[2 * d:]])
         assert (a - b).abs().max().item() <= 5e-6, k
+
+
+@pytest.mark.parametrize("kind", ["something", "action_genome"])
+def test_fused_criterion_matches_torch(pkg, kind):
+    T = importlib.import_module("revisiting-spatial-temporal-layouts_amd.train")
+    g0 = torch.Generator().manual_seed(3)
+    B, K = 37, 157
+    logits = (torch.randn(B, K, generator=g0) * 3).to(DEV).requires_grad_(True)
+    if kind == "something":
+        labels = torch.randint(0, K, (B,), generator=g0).to(DEV)
+    else:
+        labels = (torch.rand(B, K, generator=g0) < 0.1).float().to(DEV)
+    ref = T.criterion({"a": logits}, labels, kind)
+    ref.backward()
+    loss, dl = T.fused_criterion(logits, labels, kind)
+    assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert (dl - logits.grad).abs().max().item() <= 1e-7
+    half, dl_half = T.fused_criterion(logits, labels, kind, 0.5)  # two logit heads: each contributes half
+    assert abs(half.item() - 0.5 * ref.item()) <= 2e-6 and (dl_half - 0.5 * logits.grad).abs().max().item() <= 1e-7

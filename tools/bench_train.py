@@ -54,7 +54,11 @@ def main():
     model.train(True)
     tr.optimizer.zero_grad()
     ev[0].record(); logits = model(batch); ev[1].record()
-    loss = pkg.train.criterion(logits, batch["labels"]); loss.backward(); ev[2].record()
+    if tr.fused:
+        loss, dl = pkg.train.fused_criterion(logits["stlt"], batch["labels"]); logits["stlt"].backward(dl)
+    else:
+        loss = pkg.train.criterion(logits, batch["labels"]); loss.backward()
+    ev[2].record()
     if tr.fused:
         flat = model._last_flat_grad
         if world > 1:
