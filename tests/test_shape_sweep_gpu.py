@@ -1,0 +1,73 @@
+"""Randomised layout shapes (frames T, object slots N, batch B are data shapes, not parameters: one cfg1-sized model
+serves them all) against the CPU oracle: padded and skip-padding forward, and the training gradients of both
+schedules.  Includes the corner shapes: a single object slot (CLS only), two frames, slot counts above the 32-row
+attention tile, frame counts above 64 (forward only: the attention backward holds one sequence of at most 64)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import stlt_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SHAPES = [(1, 2, 1), (3, 2, 2), (2, 5, 1), (4, 9, 3), (2, 17, 12), (3, 16, 33), (1, 31, 8), (2, 33, 5), (5, 40, 2), (2, 64, 9),
+          (1, 65, 4), (2, 100, 3)]
+
+
+@pytest.fixture(scope="module")
+def model(pkg):
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs("cfg1")))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=77, gain=1.5)
+    m.load_state_dict(sd)
+    return m.to(DEV), sd
+
+
+@pytest.mark.parametrize("B,T,N", SHAPES)
+def test_forward_padded_and_skip_padding_match_oracle(pkg, model, B, T, N):
+    m, sd = model
+    m.train(False)
+    batch = pkg.synth.make_batch(B, T, N, seed=1000 * T + N, min_len=2)
+    ref = O.stlt_forward(sd, batch, 4)["stlt"]
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        for skip in (False, True):
+            m.backbone.skip_padding = skip
+            got = m(dev)["stlt"].cpu()
+            assert (got - ref).abs().max().item() <= 1e-4, (skip, (got - ref).abs().max().item())
+    m.backbone.skip_padding = False
+
+
+@pytest.mark.parametrize("B,T,N", [s for s in SHAPES if s[1] <= 64 and s[2] <= 64])
+def test_training_gradients_match_oracle_both_schedules(pkg, model, B, T, N):
+    m, sd = model
+    m.train(True)  # dropout 0 in cfg1's kwargs
+    batch = pkg.synth.make_batch(B, T, N, seed=2000 * T + N, min_len=2)
+    labels = torch.randint(0, 174, (B,), generator=torch.Generator().manual_seed(T * 7 + N))
+    leaves = {k: (v.detach().double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    F.cross_entropy(O.stlt_forward(leaves, b64, 4, dtype=torch.float64)["stlt"], labels).backward()
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    for skip in (False, True):
+        m.backbone.skip_padding = skip
+        m.zero_grad(set_to_none=True)
+        F.cross_entropy(m(dev)["stlt"], labels.to(DEV)).backward()
+        for k, p in m.named_parameters():
+            g_ref = leaves[k].grad
+            if p.grad is None:
+                assert g_ref is None or g_ref.abs().max().item() == 0.0, k
+                continue
+            scale = max(g_ref.abs().max().item(), 1e-6)
+            assert (p.grad.cpu().double() - g_ref).abs().max().item() / scale <= 3e-4, (skip, k)
+    m.backbone.skip_padding = False
+    m.train(False)
+
+
+def test_training_beyond_64_frames_is_rejected_with_a_message(pkg, model):
+    m, _ = model
+    m.train(True)
+    batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(1, 65, 3, seed=5).items()}
+    out = m(batch)["stlt"]
+    with pytest.raises(pkg.StltHipError, match="at most 64"):
+        out.sum().backward()
+    m.train(False)
