@@ -12,8 +12,12 @@
  *   - all tensor arguments are raw DEVICE pointers owned by the caller (PyTorch allocations); the
  *     library never allocates, frees or retains them.  fp32, row-major, contiguous unless a leading
  *     dimension (ld*) is given in ELEMENTS.  ids/lengths int64, masks uint8 (1 = padded / masked).
- *   - asynchronous on `stream` (a hipStream_t passed as void*); no implicit synchronisation; safe to
- *     capture in a hipGraph.  Re-entrant: no mutable global state besides the error string.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no implicit synchronisation — the one exception
+ *     is STLT_FLAG_SKIP_PADDING, which reads two row counts back (one stream synchronisation per call); everything
+ *     else is a fixed launch sequence that can be captured in a hipGraph.
+ *   - per-thread state only: the error string and the scratch lent with stlt_gemm_set_scratch (both thread-local);
+ *     process-wide there are only write-once caches of device properties.  One model per process is the intended use.
+ *   - plain C: this header compiles as C99 and as C++ (tests/test_host_cpu.py builds a C client against the library).
  */
 #ifndef STLT_HIP_H
 #define STLT_HIP_H

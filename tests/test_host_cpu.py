@@ -9,7 +9,9 @@ import re
 import pytest
 import torch
 
-from conftest import GOLDEN, ROOT, load_golden
+import importlib
+
+from conftest import GOLDEN, PKG_NAME, ROOT, load_golden
 
 
 def test_library_exports_every_declared_symbol(pkg):
@@ -114,3 +116,30 @@ def test_synth_invariants(pkg):
         assert torch.equal(b["src_key_padding_mask_boxes"], b["categories"] == 0)
         assert ("scores" in b) == (ds == "action_genome")
         assert (b["boxes"][..., 0] <= b["boxes"][..., 2]).all() and (b["boxes"][..., 1] <= b["boxes"][..., 3]).all()
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/stlt_hip.h must serve a C host: compile it as C99 (pedantic), then build a C program against the shared
+    library that calls two host-only entry points (no GPU needed) and check what it prints."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    importlib.import_module("__graft_entry__").build()
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, PKG_NAME)
+    src = tmp_path / "client.c"
+    src.write_text('#include <stdio.h>\n#include "stlt_hip.h"\n'
+                   'int main(void) {\n'
+                   '  stlt_params p; stlt_inputs in; stlt_opt_chunk c; (void)p; (void)in; (void)c;\n'
+                   '  printf("%d %zu %zu %d\\n", stlt_version(), stlt_workspace_bytes(8, 32, 7, 768, 174), stlt_gemm_scratch_bytes(),\n'
+                   '         stlt_linear_fwd(NULL, 0, NULL, NULL, NULL, 0, 1, 1, 32, 0, NULL));\n'
+                   '  printf("%s\\n", stlt_last_error());\n  return 0;\n}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+    exe = tmp_path / "client"
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-L", libdir, "-l:libstlt_hip.so", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    ver, ws, sk, rc = out[0].split()
+    pkg = importlib.import_module(PKG_NAME)
+    assert int(ver) == 100 and int(ws) == pkg.ops.workspace_bytes(8, 32, 7, 768, 174) and int(sk) == 64 * 1024 * 1024
+    assert int(rc) == -1 and "null" in out[1]  # argument error reported through the C-ABI, message available
