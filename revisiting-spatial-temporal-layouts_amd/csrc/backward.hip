@@ -336,6 +336,134 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// Attention backward for sequences longer than AB_MAXL (up to AB_LONG_MAXL = 256, the position table's size): one
+// block per (sequence, head) walks the queries in tiles of 32; per query tile, pass A streams the keys in tiles of 32
+// through LDS for the scores and dP, the rows are normalised (whole rows of P / dS fit: 32 x (L+1) floats each), and
+// pass B streams the keys again for dQ (registers) and for this tile's contribution to dK / dV, which accumulates in
+// the output buffer (every (row, channel) element is owned by one thread, so the read-modify-write is private).
+// Plain FMA code like attn_bwd_kernel: training with layouts of more than 64 frames is rare and this keeps it exact.
+constexpr int AB_LONG_MAXL = 256;
+
+__global__ __launch_bounds__(256) void attn_bwd_long_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                            const uint8_t* __restrict__ kpm, int causal, int L, int H, float scale,
+                                                            float* __restrict__ dqkv, StltDrop dr, uint32_t site,
+                                                            const int* __restrict__ grp_ptr) {
+  extern __shared__ float ab_smem[];
+  const int PLD = L + 1;
+  float* Qs = ab_smem;                // 32 x 65: query tile
+  float* Gs = Qs + 32 * AB_LD;        // dO tile
+  float* Ks = Gs + 32 * AB_LD;        // key tile
+  float* Vs = Ks + 32 * AB_LD;        // value tile
+  float* Ps = Vs + 32 * AB_LD;        // 32 x (L+1): scores -> P
+  float* Ds = Ps + 32 * PLD;          // dP -> dS
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % H;
+  const int64_t g = blockIdx.x / H;
+  const int64_t tok0 = grp_ptr ? (int64_t)grp_ptr[g] : g * L;
+  const int len = grp_ptr ? grp_ptr[g + 1] - grp_ptr[g] : L;
+  const int d = H * AB_DH;
+  const int64_t ld = 3 * (int64_t)d;
+  const int rc = tid >> 6, c = tid & 63;  // this thread's row class (rows r = rc, rc+4, ...) and channel
+  const float* qb = qkv + tok0 * ld + head * AB_DH;
+  float* ob = dqkv + tok0 * ld + head * AB_DH;
+  for (int r = rc; r < len; r += 4) { ob[r * ld + d + c] = 0.f; ob[r * ld + 2 * d + c] = 0.f; }  // dK, dV accumulate below
+  for (int q0 = 0; q0 < len; q0 += 32) {
+    const int nq = len - q0 < 32 ? len - q0 : 32;
+    for (int i = rc; i < 32; i += 4) {
+      const bool in = i < nq;
+      Qs[i * AB_LD + c] = in ? qb[(q0 + i) * ld + c] : 0.f;
+      Gs[i * AB_LD + c] = in ? dctx[(tok0 + q0 + i) * (int64_t)d + head * AB_DH + c] : 0.f;
+    }
+    // ---- pass A: scores and dP against every key tile
+    for (int k0 = 0; k0 < len; k0 += 32) {
+      const int nkeys = len - k0 < 32 ? len - k0 : 32;
+      __syncthreads();  // previous users of Ks / Vs (and the Q / dO tile writes above) are done
+      for (int j = rc; j < 32; j += 4) {
+        const bool in = j < nkeys;
+        Ks[j * AB_LD + c] = in ? qb[(k0 + j) * ld + d + c] : 0.f;
+        Vs[j * AB_LD + c] = in ? qb[(k0 + j) * ld + 2 * d + c] : 0.f;
+      }
+      __syncthreads();
+      for (int p = tid; p < 32 * 32; p += 256) {
+        const int i = p >> 5, j = p & 31;
+        const int kj = k0 + j, qi = q0 + i;
+        const bool real = j < nkeys && (grp_ptr ? true : kpm[tok0 + kj] == 0);
+        const bool ok = i < nq && real && (!causal || kj <= qi);
+        float sc = 0.f, dp = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < AB_DH; ++e) {
+          sc += Qs[i * AB_LD + e] * Ks[j * AB_LD + e];
+          dp += Gs[i * AB_LD + e] * Vs[j * AB_LD + e];
+        }
+        if (dr.thr) {
+          const uint64_t idx = ((((uint64_t)(tok0 + qi)) * H + head) << 8) | (uint64_t)(kj & 0xff);
+          dp = stlt_keep(dr, site, idx) ? dp * dr.scale : 0.f;
+        }
+        if (j < nkeys) { Ps[i * PLD + kj] = ok ? sc * scale : -1e30f; Ds[i * PLD + kj] = dp; }
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {  // row softmax, D_i, dS (in place: Ps <- P, Ds <- dS)
+      const int i = tid;
+      float m = -1e30f;
+      for (int j = 0; j < len; ++j) m = fmaxf(m, Ps[i * PLD + j]);
+      float l = 0.f;
+      for (int j = 0; j < len; ++j) {
+        const float sv = Ps[i * PLD + j];
+        const float e = sv > -1e29f ? expf(sv - m) : 0.f;
+        Ps[i * PLD + j] = e;
+        l += e;
+      }
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      float dsum = 0.f;
+      for (int j = 0; j < len; ++j) {
+        const float pj = Ps[i * PLD + j] * inv;
+        Ps[i * PLD + j] = pj;
+        dsum += pj * Ds[i * PLD + j];
+      }
+      for (int j = 0; j < len; ++j) Ds[i * PLD + j] = Ps[i * PLD + j] * (Ds[i * PLD + j] - dsum);
+    }
+    // ---- pass B: dQ of this query tile, and its share of dK / dV
+    float dq[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dq[t] = 0.f;
+    for (int k0 = 0; k0 < len; k0 += 32) {
+      const int nkeys = len - k0 < 32 ? len - k0 : 32;
+      __syncthreads();  // the normalised rows are published; the previous tile's Ks readers are done
+      for (int j = rc; j < 32; j += 4) Ks[j * AB_LD + c] = j < nkeys ? qb[(k0 + j) * ld + d + c] : 0.f;
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int i = rc + 4 * t;
+        float acc = 0.f;
+        for (int j = 0; j < nkeys; ++j) acc += Ds[i * PLD + k0 + j] * Ks[j * AB_LD + c];
+        dq[t] += acc;
+      }
+      for (int j = rc; j < nkeys; j += 4) {
+        const int kj = k0 + j;
+        float dk = 0.f, dv = 0.f;
+        for (int i = 0; i < nq; ++i) {
+          dk += Ds[i * PLD + kj] * Qs[i * AB_LD + c];
+          float pd = Ps[i * PLD + kj];
+          if (dr.thr) {
+            const uint64_t idx = ((((uint64_t)(tok0 + q0 + i)) * H + head) << 8) | (uint64_t)(kj & 0xff);
+            pd = stlt_keep(dr, site, idx) ? pd * dr.scale : 0.f;
+          }
+          dv += pd * Gs[i * AB_LD + c];
+        }
+        ob[kj * ld + d + c] += dk * scale;  // same thread owns (kj, c) in every query tile
+        ob[kj * ld + 2 * d + c] += dv;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = rc + 4 * t;
+      if (i < nq) ob[(q0 + i) * ld + c] = dq[t] * scale;
+    }
+    __syncthreads();  // the next query tile overwrites Qs / Gs / Ps / Ds
+  }
+}
+
 // ------------------------------------------------------------------ K1 backward (parameter gradients)
 // dx = gradient wrt the pre-LayerNorm embedding sum (tok, d).  Per block: a chunk of tokens; thread = channel.
 // partial layout per block: [C category rows][4 box_w rows][box_b][score_w][score_b] x d
@@ -546,9 +674,30 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
                     const AttnBwdRagged* rg) {
   if (!qkv || !dctx || (!kpm && !rg) || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
   if (dh != AB_DH) return stlt_set_error(STLT_EINVAL, "attn_bwd: head dim must be 64");
-  if (L <= 0 || L > AB_MAXL)
-    return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld); training with longer layouts is not built yet", AB_MAXL, (long long)L);
+  if (L <= 0 || L > AB_LONG_MAXL)
+    return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld)", AB_LONG_MAXL, (long long)L);
   if (S == 0) return 0;
+  if (L > AB_MAXL) {  // long sequences: one block per (sequence, head), keys streamed in tiles
+    const int64_t n_seq = rg ? rg->n_groups : S;
+    if (rg && rg->max_rows > AB_LONG_MAXL) return stlt_set_error(STLT_EINVAL, "attn_bwd: group of %d rows unsupported", rg->max_rows);
+    if (n_seq == 0) return 0;
+    if (n_seq * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "attn_bwd: too many sequences");
+    const size_t lds_long = ((size_t)4 * 32 * AB_LD + (size_t)2 * 32 * (L + 1)) * sizeof(float);
+    static bool long_opt_in = false;
+    if (!long_opt_in) {
+      if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
+        return stlt_set_error((int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      long_opt_in = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_long_kernel, dim3((unsigned)(n_seq * H)), dim3(256), lds_long, s, qkv, dctx, kpm, causal, (int)L, (int)H,
+                       1.0f / sqrtf((float)dh), dqkv, dr, site, rg ? rg->grp_ptr : (const int*)nullptr);
+    if (int e = stlt_check_launch("attn_bwd_long_kernel")) return e;
+    if (g_colsum) {  // in-proj bias gradient: column sums of dqkv in a pass of their own (scratch >= 64 * 3 * H * dh floats)
+      if (!scratch) return stlt_set_error(STLT_EINVAL, "attn_bwd: column sums need scratch");
+      return launch_colsum_acc(dqkv, 3 * H * dh, rg ? rg->n_rows : S * L, 3 * H * dh, g_colsum, scratch, s);
+    }
+    return 0;
+  }
   const int P = L <= 32 ? (int)(32 / L) : 1;
   const int GL = rg ? rg->max_rows : P * (int)L;
   const int64_t groups = rg ? rg->n_groups : (S + P - 1) / P;

@@ -68,7 +68,7 @@ struct Scratch {
 };
 
 constexpr int MAX_SPLIT = 32;
-constexpr int AB_MAX_ROWS = 64;  // attention backward: longest sequence / largest group (backward.hip)
+constexpr int AB_MAX_ROWS = 256;  // attention backward: longest sequence (backward.hip: 64 in LDS, up to 256 streamed)
 
 static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, int64_t C) {
   Scratch s;

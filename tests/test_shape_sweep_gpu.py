@@ -1,7 +1,8 @@
 """Randomised layout shapes (frames T, object slots N, batch B are data shapes, not parameters: one cfg1-sized model
 serves them all) against the CPU oracle: padded and skip-padding forward, and the training gradients of both
 schedules.  Includes the corner shapes: a single object slot (CLS only), two frames, slot counts above the 32-row
-attention tile, frame counts above 64 (forward only: the attention backward holds one sequence of at most 64)."""
+attention tile, and frame / slot counts above 64, where the attention backward switches to its streamed long-sequence
+kernel (up to 256, the size of the position table)."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +13,7 @@ from oracle import stlt_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 SHAPES = [(1, 2, 1), (3, 2, 2), (2, 5, 1), (4, 9, 3), (2, 17, 12), (3, 16, 33), (1, 31, 8), (2, 33, 5), (5, 40, 2), (2, 64, 9),
-          (1, 65, 4), (2, 100, 3)]
+          (1, 65, 4), (2, 100, 3), (1, 6, 70), (1, 256, 2)]
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +39,7 @@ def test_forward_padded_and_skip_padding_match_oracle(pkg, model, B, T, N):
     m.backbone.skip_padding = False
 
 
-@pytest.mark.parametrize("B,T,N", [s for s in SHAPES if s[1] <= 64 and s[2] <= 64])
+@pytest.mark.parametrize("B,T,N", SHAPES)
 def test_training_gradients_match_oracle_both_schedules(pkg, model, B, T, N):
     m, sd = model
     m.train(True)  # dropout 0 in cfg1's kwargs
@@ -63,11 +64,40 @@ def test_training_gradients_match_oracle_both_schedules(pkg, model, B, T, N):
     m.train(False)
 
 
-def test_training_beyond_64_frames_is_rejected_with_a_message(pkg, model):
-    m, _ = model
-    m.train(True)
-    batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(1, 65, 3, seed=5).items()}
-    out = m(batch)["stlt"]
-    with pytest.raises(pkg.StltHipError, match="at most 64"):
-        out.sum().backward()
+def test_long_sequence_training_with_dropout_is_seeded(pkg):
+    """The streamed attention backward recomputes the same dropout masks as the forward (T = 80 > 64)."""
+    kw = pkg.synth.model_kwargs("cfg1")
+    kw["hidden_dropout_prob"] = 0.2
+    m = pkg.Stlt(pkg.StltModelConfig(**kw))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=77))
+    m.train(True).to(DEV)
+    batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(2, 80, 3, seed=5).items()}
+    labels = torch.tensor([3, 9], device=DEV)
+
+    def run(seed):
+        torch.manual_seed(seed)
+        m.zero_grad(set_to_none=True)
+        out = m(batch)["stlt"]
+        F.cross_entropy(out, labels).backward()
+        return out.detach().clone(), m.backbone.transformer.layers[0].self_attn.in_proj_weight.grad.detach().clone()
+
+    a, ga = run(1)
+    b, gb = run(1)
+    assert torch.isfinite(ga).all() and torch.equal(a, b) and torch.equal(ga, gb)
+    # finite-difference check of one direction through the whole stochastic graph (same masks: same seed)
+    w = m.backbone.transformer.layers[0].self_attn.in_proj_weight
+    direction = torch.randn_like(w) * 3e-3
+    with torch.no_grad():
+        w.add_(direction)
+    torch.manual_seed(1)
+    lp = F.cross_entropy(m(batch)["stlt"], labels).item()
+    with torch.no_grad():
+        w.sub_(2 * direction)
+    torch.manual_seed(1)
+    lm = F.cross_entropy(m(batch)["stlt"], labels).item()
+    with torch.no_grad():
+        w.add_(direction)
+    fd = (lp - lm) / 2
+    an = (ga * direction).sum().item()
+    assert abs(fd - an) <= 1e-2 * max(abs(an), 1e-3) + 2e-5, (fd, an)
     m.train(False)
