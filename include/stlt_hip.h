@@ -234,7 +234,7 @@ int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const floa
  * every encoder layer — SURVEY.md App. B) is a counter-based mask: element idx of site s is kept iff the high 32 bits of
  * splitmix64(idx + seed*0x9E3779B97F4A7C15 + s*0xD1B54A32D192ED03) are >= p*2^32, kept values are scaled by 1/(1-p).
  * The backward recomputes the masks from (p, seed): pass the same values to both calls.  p = 0 disables it.
- * Attention backward supports sequences <= 64 tokens. */
+ * Attention backward supports sequences of up to 256 tokens (the position table). */
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);
 size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories);
 /* flags: 0, or STLT_FLAG_SKIP_PADDING (the same value in both calls of a step): forward and reverse sweep run over the
