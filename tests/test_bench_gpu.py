@@ -1,0 +1,47 @@
+"""bench.py end to end: the single-process line, and the multi-rank launch the driver uses (two ranks sharing cuda:0 through
+STLT_BENCH_ONE_GPU=1 / gloo, since the test box has one GPU): one JSON line on rank 0 with the contract's fields."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline"}
+
+
+def _last_json(stdout: str):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_process_line():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "64"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "clips/s" and j["scaling"] == "weak"
+    assert j["config"]["per_gpu_batch"] == 64 and "workload" in j["config"]
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "port"
+    assert j["skip_padding"]["value"] > j["value"] and j["logit_max_abs_diff"] <= 1e-4
+
+
+def test_two_rank_launch_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, STLT_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["config"]["global_batch"] == 128 and j["value"] > 0
+    assert "cpu_baseline" not in j  # rank 0 at N = 1 only
