@@ -260,6 +260,27 @@ typedef struct {
   int32_t n;
   float weight_decay;
 } stlt_opt_chunk;
+/* ---- per-kernel backward entry points (autograd of the K-row forwards above; the fusion models' training is composed
+ * from these, the STLT training step uses the fixed reverse sweep of stlt_train_backward) ----
+ * stlt_linear_bwd: y = x·Wᵀ + b (no activation).  dx (M,K) = dy·W (nullable), dw (N,K) += dyᵀ·x (nullable), db (N) +=
+ *   column sums of dy (nullable).  scratch: stlt_linear_bwd_scratch_bytes(N).
+ * stlt_attn_bwd: backward of stlt_attn_cross_fwd (and, with q = qkv, k = qkv+d, v = qkv+2d, of stlt_attn_core_fwd):
+ *   dq / dk / dv written (not accumulated) with their own leading dimensions; sequences of at most 64 tokens.
+ * stlt_add_layernorm_bwd: out = LN_eps(x + res)·w + b.  ds = gradient wrt the sum (the gradient of both x and res);
+ *   g_w / g_b accumulate (nullable).  scratch: stlt_add_layernorm_bwd_scratch_bytes(d).
+ * stlt_gelu_fwd / stlt_gelu_bwd: exact-erf GELU and du = dh * gelu'(u), n a multiple of 4. */
+size_t stlt_linear_bwd_scratch_bytes(int64_t N);
+int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, float* dw, float* db,
+                    void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dctx, const uint8_t* kpm,
+                  int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* dq, int64_t lddq, float* dk, float* dv,
+                  int64_t lddkv, stlt_stream_t stream);
+size_t stlt_add_layernorm_bwd_scratch_bytes(int64_t d);
+int stlt_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* ln_w, float eps, int64_t M, int64_t d,
+                           float* ds, float* g_w, float* g_b, void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+int stlt_gelu_fwd(const float* u, float* h, int64_t n, stlt_stream_t stream);
+int stlt_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, stlt_stream_t stream);
+
 /* Criterion of the reference (utils/train_inference_utils.py:64-76) and its gradient in one pass: loss_out[0] = weight *
  * mean loss, dlogits = weight * d(mean loss)/d(logits).  CROSS_ENTROPY: labels int64 (B); BCE_WITH_LOGITS: labels float
  * (B,K) multi-hot.  `weight` = 1 / number of logit heads (the reference averages the heads' losses).  scratch: >= B floats. */

@@ -106,6 +106,14 @@ SIGNATURES = {
     "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
     "stlt_train_backward": (C.c_int, [C.POINTER(Params), C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp,
                                       C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
+    "stlt_linear_bwd_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "stlt_linear_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "stlt_attn_bwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                _vp, C.c_int64, _vp, _vp, C.c_int64, _vp]),
+    "stlt_add_layernorm_bwd_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "stlt_add_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "stlt_gelu_fwd": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "stlt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
     "stlt_grad_norm": (C.c_int, [_vp, C.c_int64, C.c_float, _vp, _vp, _vp]),
     "stlt_adamw_step": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),

@@ -1,0 +1,158 @@
+// Per-kernel backward entry points of the C-ABI (the *_bwd counterparts of the K-row forwards): what an op-level
+// autograd needs — the fusion models' training step is composed from these in Python (modelling/fusion.py), while the
+// STLT training step keeps its single fixed reverse sweep (train.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int XB_MAXL = 64, XB_DH = 64, XB_LD = XB_DH + 1;
+
+// Backward of the attention core for separate query / key-value token spaces (cross-attention; self-attention on a
+// packed buffer is q = qkv, k = qkv + d, v = qkv + 2d).  One block per (sequence, head), everything in LDS as fp32,
+// P recomputed.  dV = Pᵀ dO ; dP = dO Vᵀ ; dS = P ∘ (dP − rowsum(P ∘ dP)) ; dQ = scale dS K ; dK = scale dSᵀ Q.
+__global__ __launch_bounds__(256) void attn_bwd_general_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                               const float* __restrict__ v, int64_t ldkv,
+                                                               const float* __restrict__ dctx, const uint8_t* __restrict__ kpm,
+                                                               int causal, int Lq, int Lk, int H, float scale,
+                                                               float* __restrict__ dq, int64_t lddq, float* __restrict__ dk,
+                                                               float* __restrict__ dv, int64_t lddkv) {
+  extern __shared__ float xb_smem[];
+  const int PLD = Lk + 1;
+  float* Qs = xb_smem;
+  float* Gs = Qs + Lq * XB_LD;
+  float* Ks = Gs + Lq * XB_LD;
+  float* Vs = Ks + Lk * XB_LD;
+  float* Ps = Vs + Lk * XB_LD;
+  float* Ds = Ps + Lq * PLD;
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % H;
+  const int64_t sq = blockIdx.x / H;
+  const int d = H * XB_DH;
+  const int64_t q0 = sq * Lq, k0 = sq * Lk;
+  for (int idx = tid; idx < Lq * XB_DH; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    Qs[r * XB_LD + c] = q[(q0 + r) * ldq + head * XB_DH + c];
+    Gs[r * XB_LD + c] = dctx[(q0 + r) * (int64_t)d + head * XB_DH + c];
+  }
+  for (int idx = tid; idx < Lk * XB_DH; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    Ks[r * XB_LD + c] = k[(k0 + r) * ldkv + head * XB_DH + c];
+    Vs[r * XB_LD + c] = v[(k0 + r) * ldkv + head * XB_DH + c];
+  }
+  __syncthreads();
+  for (int p = tid; p < Lq * Lk; p += 256) {
+    const int i = p / Lk, j = p - i * Lk;
+    const bool ok = (!kpm || kpm[k0 + j] == 0) && (!causal || j <= i);
+    float s = 0.f, dp = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < XB_DH; ++c) {
+      s += Qs[i * XB_LD + c] * Ks[j * XB_LD + c];
+      dp += Gs[i * XB_LD + c] * Vs[j * XB_LD + c];
+    }
+    Ps[i * PLD + j] = ok ? s * scale : -1e30f;
+    Ds[i * PLD + j] = dp;
+  }
+  __syncthreads();
+  if (tid < Lq) {
+    const int i = tid;
+    float m = -1e30f;
+    for (int j = 0; j < Lk; ++j) m = fmaxf(m, Ps[i * PLD + j]);
+    float l = 0.f;
+    for (int j = 0; j < Lk; ++j) {
+      const float sv = Ps[i * PLD + j];
+      const float e = sv > -1e29f ? expf(sv - m) : 0.f;
+      Ps[i * PLD + j] = e;
+      l += e;
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float dsum = 0.f;
+    for (int j = 0; j < Lk; ++j) {
+      const float pj = Ps[i * PLD + j] * inv;
+      Ps[i * PLD + j] = pj;
+      dsum += pj * Ds[i * PLD + j];
+    }
+    for (int j = 0; j < Lk; ++j) Ds[i * PLD + j] = Ps[i * PLD + j] * (Ds[i * PLD + j] - dsum);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < Lq * XB_DH; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    float acc = 0.f;
+    for (int j = 0; j < Lk; ++j) acc += Ds[r * PLD + j] * Ks[j * XB_LD + c];
+    dq[(q0 + r) * lddq + head * XB_DH + c] = acc * scale;
+  }
+  for (int idx = tid; idx < Lk * XB_DH; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    float ak = 0.f, av = 0.f;
+    for (int i = 0; i < Lq; ++i) {
+      ak += Ds[i * PLD + r] * Qs[i * XB_LD + c];
+      av += Ps[i * PLD + r] * Gs[i * XB_LD + c];
+    }
+    dk[(k0 + r) * lddkv + head * XB_DH + c] = ak * scale;
+    dv[(k0 + r) * lddkv + head * XB_DH + c] = av;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t stlt_linear_bwd_scratch_bytes(int64_t N) {
+  return STLT_GEMM_SCRATCH_BYTES + (size_t)(N > 0 ? N : 0) * 64 * sizeof(float);
+}
+
+int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, float* dw, float* db,
+                    void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
+  if (!x || !w || !dy || !scratch) return stlt_set_error(STLT_EINVAL, "stlt_linear_bwd: null pointer");
+  if (M < 0 || N <= 0 || K <= 0) return stlt_set_error(STLT_EINVAL, "stlt_linear_bwd: bad shape");
+  if (scratch_bytes < stlt_linear_bwd_scratch_bytes(N)) return stlt_set_error(STLT_EWORKSPACE, "stlt_linear_bwd: scratch %zu B < required %zu B", scratch_bytes, stlt_linear_bwd_scratch_bytes(N));
+  if (M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  StltGemmScratch lend(scratch, STLT_GEMM_SCRATCH_BYTES);
+  float* red = (float*)((char*)scratch + STLT_GEMM_SCRATCH_BYTES);
+  const bool mfma_ok = N % 32 == 0 && K % 4 == 0;  // contraction lengths / leading dimensions the MFMA kernel takes
+  if (dx) {  // dx (M,K) = dy (M,N) · W (N,K)
+    if (mfma_ok) { if (int e = launch_gemm(0, 1, dy, N, w, K, nullptr, nullptr, 0, dx, K, 0, M, K, N, 1, STLT_ACT_NONE, s)) return e; }
+    else if (int e = launch_small_gemm(dy, N, 1, w, K, 1, dx, K, M, K, N, 0, s)) return e;
+  }
+  if (dw) {  // dw (N,K) += dyᵀ (N,M) · x (M,K): the MFMA kernel contracts over multiples of 32 rows, the rest goes to the strided kernel
+    const int64_t Mf = (N % 4 == 0 && K % 4 == 0) ? M / 32 * 32 : 0;
+    if (Mf > 0) { if (int e = launch_gemm(1, 1, dy, N, x, K, nullptr, dw, K, dw, K, 0, N, K, Mf, 1, STLT_ACT_NONE, s)) return e; }
+    if (M > Mf) { if (int e = launch_small_gemm(dy + Mf * N, 1, N, x + Mf * K, K, 1, dw, K, N, K, M - Mf, 1, s)) return e; }
+  }
+  if (db) { if (int e = launch_colsum_acc(dy, N, M, N, db, red, s)) return e; }
+  return 0;
+}
+
+int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dctx, const uint8_t* kpm,
+                  int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* dq, int64_t lddq, float* dk, float* dv,
+                  int64_t lddkv, stlt_stream_t stream) {
+  if (!q || !k || !v || !dctx || !dq || !dk || !dv) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: null pointer");
+  if (dh != XB_DH) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: head dim must be 64");
+  if (Lq <= 0 || Lk <= 0 || Lq > XB_MAXL || Lk > XB_MAXL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: sequences of at most %d tokens (got %lld / %lld)", XB_MAXL, (long long)Lq, (long long)Lk);
+  if (causal && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: causal masking needs Lq == Lk");
+  if (S == 0) return 0;
+  if (S * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: too many sequences");
+  const size_t lds = ((size_t)2 * Lq * XB_LD + (size_t)2 * Lk * XB_LD + (size_t)2 * Lq * (Lk + 1)) * sizeof(float);
+  static bool opt_in = false;
+  if (!opt_in) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
+      return stlt_set_error((int)e, "stlt_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    opt_in = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_general_kernel, dim3((unsigned)(S * H)), dim3(256), lds, (hipStream_t)stream, q, ldq, k, v, ldkv, dctx, kpm, causal,
+                     (int)Lq, (int)Lk, (int)H, 1.0f / sqrtf((float)dh), dq, lddq, dk, dv, lddkv);
+  return stlt_check_launch("attn_bwd_general_kernel");
+}
+
+size_t stlt_add_layernorm_bwd_scratch_bytes(int64_t d) { return (size_t)ln_bwd_scratch_floats(d > 0 ? d : 0) * sizeof(float); }
+
+int stlt_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* ln_w, float eps, int64_t M, int64_t d,
+                           float* ds, float* g_w, float* g_b, void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
+  if (scratch_bytes < stlt_add_layernorm_bwd_scratch_bytes(d)) return stlt_set_error(STLT_EWORKSPACE, "stlt_add_layernorm_bwd: scratch too small");
+  return launch_ln_bwd(dy, d, x, d, res, d, ln_w, eps, M, d, ds, d, g_w, g_b, (float*)scratch, (hipStream_t)stream);
+}
+
+int stlt_gelu_fwd(const float* u, float* h, int64_t n, stlt_stream_t stream) { return launch_gelu_fwd(u, h, n, (hipStream_t)stream); }
+int stlt_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, stlt_stream_t stream) { return launch_gelu_bwd(dh, u, du, n, (hipStream_t)stream); }
+
+}  // extern "C"

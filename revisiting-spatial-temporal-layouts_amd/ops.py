@@ -228,3 +228,133 @@ def prof_collect():
     cnt = (C.c_int64 * n)()
     L.check(L.load().stlt_prof_collect(ms, cnt), "stlt_prof_collect")
     return {L.K_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Op-level autograd over the per-kernel backward entry points (include/stlt_hip.h: stlt_linear_bwd, stlt_attn_bwd,
+# stlt_add_layernorm_bwd, stlt_gelu_bwd).  The STLT training step does not use these (it has one fixed reverse sweep);
+# they are what the fusion models' training step is composed from (modelling/fusion.py).
+_SCRATCH = {}
+
+
+def _scratch(nbytes: int, device) -> torch.Tensor:
+    buf = _SCRATCH.get(device)
+    if buf is None or buf.numel() < nbytes:
+        _SCRATCH[device] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x wᵀ + b (no activation), x (..., K)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, w = ctx.saved_tensors
+        N, K = w.shape
+        M = x.numel() // K
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.zeros(N, device=w.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        nbytes = int(lib.stlt_linear_bwd_scratch_bytes(N))
+        sc = _scratch(nbytes, x.device)
+        L.check(lib.stlt_linear_bwd(_p(x), _p(w), _p(dy), M, N, K, _p(dx), _p(dw), _p(db), sc.data_ptr(), sc.numel(), _stream()),
+                "stlt_linear_bwd")
+        return dx, dw, db
+
+
+class AttnFn(torch.autograd.Function):
+    """softmax(q kᵀ / sqrt(dh) + mask) v per head.  q (S,Lq,d), k / v (S,Lk,d): last dim contiguous, k and v with the same
+    row stride (views of a packed projection are fine).  kpm (S,Lk) over the keys or None."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kpm, causal, heads):
+        lib = L.load()
+        S, Lq, d = q.shape
+        Lk = k.shape[1]
+        for t, name in ((q, "q"), (k, "k"), (v, "v")):
+            if t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+                raise L.StltHipError(f"AttnFn: {name} must be row-strided with a contiguous last dim")
+        if k.stride(1) != v.stride(1):
+            raise L.StltHipError("AttnFn: k and v need the same row stride")
+        kpm8 = torch.zeros(S, Lk, dtype=torch.uint8, device=q.device) if kpm is None else _mask_u8(kpm.contiguous(), "kpm")
+        ctxt = torch.empty(S, Lq, d, device=q.device, dtype=torch.float32)
+        L.check(lib.stlt_attn_cross_fwd(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), _p(kpm8), int(bool(causal)),
+                                        S, Lq, Lk, heads, d // heads, _p(ctxt), _stream()), "stlt_attn_cross_fwd")
+        ctx.save_for_backward(q, k, v, kpm8)
+        ctx.meta = (bool(causal), heads)
+        return ctxt
+
+    @staticmethod
+    def backward(ctx, dctx):
+        lib = L.load()
+        q, k, v, kpm8 = ctx.saved_tensors
+        causal, heads = ctx.meta
+        S, Lq, d = q.shape
+        Lk = k.shape[1]
+        dctx = dctx.contiguous()
+        dq = torch.empty(S, Lq, d, device=q.device, dtype=torch.float32)
+        dk = torch.empty(S, Lk, d, device=q.device, dtype=torch.float32)
+        dv = torch.empty(S, Lk, d, device=q.device, dtype=torch.float32)
+        L.check(lib.stlt_attn_bwd(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), _p(dctx), _p(kpm8), int(causal),
+                                  S, Lq, Lk, heads, d // heads, _p(dq), d, _p(dk), _p(dv), d, _stream()), "stlt_attn_bwd")
+        return dq, dk, dv, None, None, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """LayerNorm_eps(x + res) * w + b over the last dim (res may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, res, w, b, eps):
+        x = x.contiguous()
+        res = None if res is None else res.contiguous()
+        ctx.save_for_backward(x, res, w)
+        ctx.eps = eps
+        return add_layernorm(x, res, w, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, res, w = ctx.saved_tensors
+        d = x.shape[-1]
+        M = x.numel() // d
+        dy = dy.contiguous()
+        ds = torch.empty_like(x)
+        gw = torch.zeros_like(w)
+        gb = torch.zeros_like(w)
+        sc = _scratch(int(lib.stlt_add_layernorm_bwd_scratch_bytes(d)), x.device)
+        L.check(lib.stlt_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(w), float(ctx.eps), M, d, _p(ds), _p(gw), _p(gb), sc.data_ptr(),
+                                           sc.numel(), _stream()), "stlt_add_layernorm_bwd")
+        return ds, (ds if res is not None else None), gw, gb, None
+
+
+class GeluFn(torch.autograd.Function):
+    """Exact-erf GELU."""
+
+    @staticmethod
+    def forward(ctx, u):
+        lib = L.load()
+        u = u.contiguous()
+        if u.numel() % 4:
+            raise L.StltHipError("GeluFn: element count must be a multiple of 4")
+        h = torch.empty_like(u)
+        L.check(lib.stlt_gelu_fwd(_p(u), _p(h), u.numel(), _stream()), "stlt_gelu_fwd")
+        ctx.save_for_backward(u)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = L.load()
+        (u,) = ctx.saved_tensors
+        dh = dh.contiguous()
+        du = torch.empty_like(u)
+        L.check(lib.stlt_gelu_bwd(_p(dh), _p(u), _p(du), u.numel(), _stream()), "stlt_gelu_bwd")
+        return du

@@ -264,3 +264,70 @@ def test_attn_ragged_matches_per_segment_softmax(pkg, lens, causal):
         ref[r0:r0 + n] = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(n, d)
         r0 += n
     assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+# ---- op-level autograd over the per-kernel backward entry points, against torch autograd in float64
+def _leaf(t):
+    return t.detach().clone().to(DEV).requires_grad_(True)
+
+
+@pytest.mark.parametrize("M,N,K", [(40, 64, 32), (300, 768, 96), (1000, 174, 256), (2048, 768, 768), (33, 132, 64), (7, 768, 2048)])
+def test_linear_autograd(pkg, M, N, K):
+    x, w, b, g = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3, scale=0.1), _rand(M, N, seed=4)
+    xd, wd, bd = _leaf(x), _leaf(w), _leaf(b)
+    pkg.ops.LinearFn.apply(xd, wd, bd).backward(g.to(DEV))
+    x64, w64, b64 = [t.double().requires_grad_(True) for t in (x, w, b)]
+    (x64 @ w64.t() + b64).backward(g.double())
+    for got, ref, name in ((xd.grad, x64.grad, "dx"), (wd.grad, w64.grad, "dw"), (bd.grad, b64.grad, "db")):
+        scale = max(ref.abs().max().item(), 1e-6)
+        assert (got.cpu().double() - ref).abs().max().item() / scale <= 2e-5, name
+
+
+@pytest.mark.parametrize("Lq,Lk,causal,packed", [(32, 33, False, False), (33, 32, False, False), (7, 7, False, True), (32, 32, True, True),
+                                                  (64, 64, True, True), (5, 61, False, False)])
+def test_attention_autograd(pkg, Lq, Lk, causal, packed):
+    S, H = 3, 4
+    d = 64 * H
+    g = _rand(S, Lq, d, seed=9)
+    kpm = torch.rand(S, Lk, generator=torch.Generator().manual_seed(3)) < 0.3
+    kpm[:, 0] = False
+    if packed:  # q, k, v are views of one packed projection
+        qkv = _leaf(_rand(S, Lq, 3 * d, seed=5, scale=1.5))
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        leaves = [qkv]
+    else:
+        qd = _leaf(_rand(S, Lq, d, seed=5, scale=1.5))
+        kv = _leaf(_rand(S, Lk, 2 * d, seed=6, scale=1.5))
+        q, k, v = qd, kv[..., :d], kv[..., d:]
+        leaves = [qd, kv]
+    pkg.ops.AttnFn.apply(q, k, v, kpm.to(DEV), causal, H).backward(g.to(DEV))
+    ref_leaves = [t.detach().cpu().double().requires_grad_(True) for t in leaves]
+    if packed:
+        q64, k64, v64 = ref_leaves[0][..., :d], ref_leaves[0][..., d:2 * d], ref_leaves[0][..., 2 * d:]
+    else:
+        q64, k64, v64 = ref_leaves[0], ref_leaves[1][..., :d], ref_leaves[1][..., d:]
+    sp = lambda t, Lx: t.reshape(S, Lx, H, 64).transpose(1, 2)
+    sc = sp(q64, Lq) @ sp(k64, Lk).transpose(-1, -2) / 8.0
+    sc = sc.masked_fill(kpm[:, None, None, :], float("-inf"))
+    if causal:
+        sc = sc.masked_fill(torch.ones(Lq, Lk, dtype=torch.bool).triu(1), float("-inf"))
+    (torch.softmax(sc, -1) @ sp(v64, Lk)).transpose(1, 2).reshape(S, Lq, d).backward(g.double())
+    for got, ref in zip(leaves, ref_leaves):
+        scale = max(ref.grad.abs().max().item(), 1e-6)
+        assert (got.grad.cpu().double() - ref.grad).abs().max().item() / scale <= 2e-5
+
+
+@pytest.mark.parametrize("with_res", [True, False])
+def test_add_layernorm_and_gelu_autograd(pkg, with_res):
+    M, d = 77, 768
+    x, r, w, b, g = _rand(M, d, seed=1), _rand(M, d, seed=2), 1 + _rand(d, seed=3, scale=0.1), _rand(d, seed=4, scale=0.1), _rand(M, d, seed=5)
+    xd, rd, wd, bd = _leaf(x), _leaf(r), _leaf(w), _leaf(b)
+    out = pkg.ops.AddLayerNormFn.apply(xd, rd if with_res else None, wd, bd, 1e-5)
+    pkg.ops.GeluFn.apply(out).backward(g.to(DEV))
+    x64, r64, w64, b64 = [t.double().requires_grad_(True) for t in (x, r, w, b)]
+    s = x64 + r64 if with_res else x64
+    torch.nn.functional.gelu(torch.nn.functional.layer_norm(s, (d,), w64, b64, 1e-5)).backward(g.double())
+    pairs = [(xd.grad, x64.grad), (wd.grad, w64.grad), (bd.grad, b64.grad)] + ([(rd.grad, r64.grad)] if with_res else [])
+    for got, ref in pairs:
+        scale = max(ref.abs().max().item(), 1e-6)
+        assert (got.cpu().double() - ref).abs().max().item() / scale <= 2e-5
