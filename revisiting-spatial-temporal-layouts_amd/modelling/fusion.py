@@ -5,8 +5,13 @@ Differences from the reference, by design of the scope (SURVEY §2 row 17, §8f 
   * the R3D-50 trunk does not run: the batch carries ``appearance_features`` (B, 2048, 2, 4, 4) — what
     ``Resnet3D.forward_features`` returns — instead of ``video_frames``; the state dict therefore has every reference
     key EXCEPT ``…appearance_branch.resnet.*`` (load reference checkpoints with ``strict=False``);
-  * inference only (no autograd path for the fusion layers yet).
-As for STLT, the modules only hold parameters; the arithmetic is ``stlt_caf_forward`` in libstlt_hip.so.
+  * inference is one native call (``stlt_caf_forward``).  Training — with autograd enabled and trainable parameters —
+    composes the same arithmetic from the op-level autograd Functions of ``ops.py`` (native forward AND backward kernels
+    per op: linear, attention, add+LayerNorm, GELU), with the LAYOUT BRANCH FROZEN (it runs through the native forward
+    without a tape; unfreeze-and-train of the layout branch inside a fusion model is not built).  Dropout (reference
+    models.py:333,341,350,358,368,376 and the appearance encoder's fixed 0.1) is applied with torch's generator at the
+    post-attention / feed-forward sites; attention-probability dropout is not applied on this path.
+As for STLT, the modules only hold parameters.
 """
 from __future__ import annotations
 
@@ -14,6 +19,7 @@ import ctypes as C
 from typing import Dict
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import _lib as L
@@ -104,10 +110,94 @@ class CrossAttentionFusionBackbone(nn.Module):
         state["_ws"] = _Workspace()
         return state
 
+    # ---- training path: op-level autograd over native kernels -------------------------------------------------
+    @staticmethod
+    def _lin(x, lin):
+        return ops.LinearFn.apply(x, lin.weight, lin.bias)
+
+    def _attn_block(self, blk: _AttnBlock, x, ctx, kpm, causal, p_drop):
+        """SelfAttentionLayer (ctx is x) / CrossAttentionLayer, models.py:345-382: LN(dropout(MHA(x, ctx, ctx)) + x)."""
+        H, d = self.config.num_attention_heads, x.shape[-1]
+        W, b = blk.attn.in_proj_weight, blk.attn.in_proj_bias
+        if ctx is x:
+            qkv = ops.LinearFn.apply(x, W, b)
+            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        else:
+            q = ops.LinearFn.apply(x, W[:d], b[:d])
+            kv = ops.LinearFn.apply(ctx, W[d:], b[d:])
+            k, v = kv[..., :d], kv[..., d:]
+        a = ops.AttnFn.apply(q, k, v, kpm, causal, H)
+        o = ops.LinearFn.apply(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
+        o = F.dropout(o, p_drop, self.training)
+        return ops.AddLayerNormFn.apply(o, x, blk.ln.weight, blk.ln.bias, self.config.layer_norm_eps)
+
+    def _appearance_train(self, feats):
+        """TransformerResnet.forward_features from the feature map on (models.py:257-271), batch-major (B, S+1, d)."""
+        ab = self.appearance_branch
+        B, Cc = feats.shape[0], feats.shape[1]
+        d = ab.projector.weight.shape[0]
+        x = ops.LinearFn.apply(feats.flatten(2).transpose(1, 2).contiguous(), ab.projector.weight.view(d, Cc), ab.projector.bias)
+        x = torch.cat((ab.cls_token.view(1, 1, d).expand(B, -1, -1), x), dim=1) + ab.pos_embed.view(1, -1, d)
+        H = self.config.num_attention_heads
+        for l in ab.transformer.layers:  # nn.TransformerEncoderLayer defaults: ReLU, post-norm, eps 1e-5, dropout 0.1
+            sa = l.self_attn
+            qkv = ops.LinearFn.apply(x, sa.in_proj_weight, sa.in_proj_bias)
+            a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], None, False, H)
+            a = F.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), 0.1, self.training)
+            x = ops.AddLayerNormFn.apply(a, x, l.norm1.weight, l.norm1.bias, 1e-5)
+            h = F.dropout(torch.relu(self._lin(x, l.linear1)), 0.1, self.training)
+            h = F.dropout(self._lin(h, l.linear2), 0.1, self.training)
+            x = ops.AddLayerNormFn.apply(h, x, l.norm2.weight, l.norm2.bias, 1e-5)
+        return x
+
+    def _head_train(self, h, x):
+        eps = self.config.layer_norm_eps
+        z = ops.GeluFn.apply(self._lin(x.contiguous(), h.fc1))
+        z = ops.AddLayerNormFn.apply(z, None, h.layer_norm.weight, h.layer_norm.bias, eps)
+        return self._lin(z, h.fc2)
+
+    def run_train(self, batch: Dict[str, torch.Tensor], fusion_head, layout_head=None, appearance_head=None):
+        """Differentiable forward (see the module docstring).  -> same tuple as run()."""
+        if any(q.requires_grad for q in self.layout_branch.parameters()):
+            raise L.StltHipError("training a fusion model needs a frozen layout branch in this build: "
+                                 "`for q in model.<backbone>.layout_branch.parameters(): q.requires_grad_(False)`")
+        feats = ops._chk(batch["appearance_features"].contiguous(), torch.float32, "appearance_features")
+        was_training = self.layout_branch.training
+        self.layout_branch.train(False)
+        with torch.no_grad():
+            Lh = self.layout_branch.forward_batch_major(batch)  # (B,T,d), no tape: the branch is frozen
+        self.layout_branch.train(was_training)
+        Ah = self._appearance_train(feats)
+        B = Lh.shape[0]
+        idx = torch.arange(B, device=Lh.device)
+        last = batch["lengths"].to(Lh.device) - 1
+        lay_state, app_state = Lh[idx, last], Ah[:, 0]
+        kpm = batch["src_key_padding_mask_frames"]
+        p = self.config.hidden_dropout_prob
+        eps = self.config.layer_norm_eps
+        for m in self.mm_fusion:  # CrossModalModule.forward, models.py:403-431
+            la = self._attn_block(m.cross_attn, Lh, Ah, None, False, p)
+            aa = self._attn_block(m.cross_attn, Ah, Lh, kpm, False, p)
+            la = self._attn_block(m.layout_attn, la, la, kpm, True, p)
+            aa = self._attn_block(m.appearance_attn, aa, aa, None, False, p)
+            f = self._lin(ops.GeluFn.apply(self._lin(la, m.layout_ffn.linear1)), m.layout_ffn.linear2)
+            Lh = ops.AddLayerNormFn.apply(F.dropout(f, p, self.training), la, m.layout_ffn.ln.weight, m.layout_ffn.ln.bias, eps)
+            Ah = self._attn_block(m.appearance_ffn, aa, aa, None, False, p)
+        fused = torch.cat((Lh[idx, last], Ah[:, 0]), dim=-1)
+        caf = self._head_train(fusion_head, fused)
+        if layout_head is None:
+            return (caf,)
+        stlt = self._head_train(layout_head, lay_state)
+        res = self._head_train(appearance_head, app_state)
+        return caf, stlt, res, (stlt + res + caf) / 3
+
     def run(self, batch: Dict[str, torch.Tensor], fusion_head, layout_head=None, appearance_head=None):
         """-> (logits_caf, logits_stlt | None, logits_resnet3d | None, logits_ensemble | None)"""
+        heads = [h for h in (fusion_head, layout_head, appearance_head) if h is not None]
+        if torch.is_grad_enabled() and any(q.requires_grad for mod in [self] + heads for q in mod.parameters()):
+            return self.run_train(batch, fusion_head, layout_head, appearance_head)
         if self.training and self.config.hidden_dropout_prob > 0:
-            raise L.StltHipError("CAF / CACNF are inference-only in this build: call model.train(False)")
+            raise L.StltHipError("train-mode dropout runs only in the autograd (training) path: call model.train(False) for inference, or enable grad")
         lib = L.load()
         inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=True)
         feats = ops._chk(batch["appearance_features"].contiguous(), torch.float32, "appearance_features")
@@ -150,7 +240,6 @@ class CrossAttentionFusion(nn.Module):
         self.classifier = FusionHead(config)
         self.logit_names = ("caf",)
 
-    @torch.no_grad()
     def forward(self, batch: Dict[str, torch.Tensor]):
         (caf,) = self.caf_backbone.run(batch, self.classifier)
         return {"caf": caf}
@@ -168,7 +257,6 @@ class CrossAttentionCentralNetFusion(nn.Module):
         self.fusion_classifier = FusionHead(config)
         self.logit_names = ("stlt", "resnet3d", "caf", "ensemble")
 
-    @torch.no_grad()
     def forward(self, batch: Dict[str, torch.Tensor]):
         caf, stlt, res, ens = self.backbone.run(batch, self.fusion_classifier, self.layout_classifier, self.appearance_classifier)
         return {"stlt": stlt, "resnet3d": res, "caf": caf, "ensemble": ens}

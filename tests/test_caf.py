@@ -53,7 +53,8 @@ def test_caf_gpu_matches_reference(pkg, model_name):
     m = cls(pkg.MultimodalModelConfig(**dict(pkg.synth.model_kwargs(NAME), **EXTRA)))
     m.load_state_dict(sd, strict=True)
     m.train(False).to("cuda")
-    out = m({k: v.to("cuda") for k, v in batch.items()})
+    with torch.no_grad():
+        out = m({k: v.to("cuda") for k, v in batch.items()})
     assert tuple(out) == m.logit_names or set(out) == set(m.logit_names)
     for k in z.files:
         got = out[k].cpu().numpy()
@@ -72,8 +73,79 @@ def test_caf_gpu_full_width_matches_oracle(pkg):
     m.train(False).to("cuda")
     batch = pkg.synth.make_batch(2, c["T"], c["N"], seed=8)
     batch["appearance_features"] = pkg.synth.make_appearance_features(2, seed=9)
-    out = m({k: v.to("cuda") for k, v in batch.items()})
     with torch.no_grad():
+        out = m({k: v.to("cuda") for k, v in batch.items()})
         ref = CO.cacnf_forward(sd, batch, c["num_attention_heads"])
     for k in ref:
         assert (out[k].cpu() - ref[k]).abs().max().item() <= 1e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["caf", "cacnf"])
+def test_fusion_training_path_matches_golden_and_oracle_gradients(pkg, model_name):
+    """With autograd on and the layout branch frozen the forward is composed from the op-level autograd Functions (native
+    forward and backward kernels): its logits must still be the reference's, and every trainable gradient must match
+    torch autograd on the CPU oracle."""
+    import torch.nn.functional as F
+    z, meta, sd, batch, c = _case(pkg.synth, model_name)
+    cls = pkg.models_factory[model_name]
+    m = cls(pkg.MultimodalModelConfig(**dict(pkg.synth.model_kwargs(NAME), **EXTRA)))
+    m.load_state_dict(sd, strict=True)
+    m.train(False).to("cuda")  # eval mode: no dropout, the appearance encoder's fixed 0.1 included
+    bb = m.caf_backbone if model_name == "caf" else m.backbone
+    dev_batch = {k: v.to("cuda") for k, v in batch.items()}
+    with pytest.raises(pkg.StltHipError, match="frozen layout branch"):
+        m(dev_batch)
+    for q in bb.layout_branch.parameters():
+        q.requires_grad_(False)
+    out = m(dev_batch)
+    for k in z.files:
+        assert out[k].requires_grad and np.abs(out[k].detach().cpu().numpy() - z[k]).max() <= 1e-4, k
+    labels = torch.randint(0, 174, (meta["batch"],), generator=torch.Generator().manual_seed(1))
+    loss = sum(F.cross_entropy(v, labels.to("cuda")) for v in out.values()) / len(out)
+    loss.backward()
+    frozen_prefix = ("caf_backbone." if model_name == "caf" else "backbone.") + "layout_branch."
+    leaves = {k: (v.clone().requires_grad_(not k.startswith(frozen_prefix)) if v.is_floating_point() else v) for k, v in sd.items()}
+    fwd = CO.caf_forward if model_name == "caf" else CO.cacnf_forward
+    ref = fwd(leaves, batch, c["num_attention_heads"])  # fp32 CPU autograd (the oracle's layout branch is fp32)
+    ref_loss = sum(F.cross_entropy(v, labels) for v in ref.values()) / len(ref)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5
+    checked = 0
+    for k, prm in m.named_parameters():
+        g_ref = leaves[k].grad if leaves[k].is_floating_point() else None
+        if k.startswith(frozen_prefix) or g_ref is None:
+            assert prm.grad is None, k
+            continue
+        if prm.grad is None:  # parameters the forward never reads (the appearance branch's own classifier)
+            assert g_ref.abs().max().item() == 0.0, k
+            continue
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        assert (prm.grad.cpu() - g_ref).abs().max().item() / scale <= 5e-4, k
+        checked += 1
+    assert checked > 40
+
+
+@pytest.mark.gpu
+def test_fusion_training_step_with_dropout_runs(pkg):
+    kw = dict(pkg.synth.model_kwargs(NAME), **EXTRA)
+    kw["hidden_dropout_prob"] = 0.1
+    m = pkg.CrossAttentionFusion(pkg.MultimodalModelConfig(**kw))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5))
+    m.train(True).to("cuda")
+    for q in m.caf_backbone.layout_branch.parameters():
+        q.requires_grad_(False)
+    c = pkg.synth.CONFIGS[NAME]
+    batch = pkg.synth.make_batch(4, c["T"], c["N"], seed=8)
+    batch["appearance_features"] = pkg.synth.make_appearance_features(4, seed=9)
+    batch = {k: v.to("cuda") for k, v in batch.items()}
+    labels = torch.tensor([1, 2, 3, 4], device="cuda")
+    opt = torch.optim.AdamW([q for q in m.parameters() if q.requires_grad], lr=1e-4)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(batch)["caf"], labels)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
