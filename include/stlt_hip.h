@@ -279,6 +279,23 @@ size_t stlt_add_layernorm_bwd_scratch_bytes(int64_t d);
 int stlt_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* ln_w, float eps, int64_t M, int64_t d,
                            float* ds, float* g_w, float* g_b, void* scratch, size_t scratch_bytes, stlt_stream_t stream);
 int stlt_gelu_fwd(const float* u, float* h, int64_t n, stlt_stream_t stream);
+/* K1 / K7 for an op-level autograd: the forward also returns the pre-LayerNorm sum; the LayerNorm part of the backward is
+ * stlt_add_layernorm_bwd on that sum (res = NULL), the rest is below: given d_pre (gradient wrt the sum) the parameter
+ * gradients ACCUMULATE into g_* (nullable); the gradient wrt the K7 input rows is d_pre itself.  Row 0 of the category /
+ * frame-type tables is the padding index and receives none (models.py:22,91). */
+int stlt_embed_fwd_train(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table, int64_t n_categories,
+                         const float* box_w, const float* box_b, const float* score_w, const float* score_b, const float* ln_w,
+                         const float* ln_b, float eps, int64_t n_tokens, int64_t d, float* pre_out, float* out, stlt_stream_t stream);
+size_t stlt_embed_bwd_scratch_bytes(int64_t n_tokens, int64_t n_categories, int64_t d);
+int stlt_embed_bwd(const float* d_pre, const int64_t* categories, const float* boxes, const float* scores, int64_t n_categories,
+                   int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w, float* g_score_b,
+                   void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+int stlt_frames_embed_fwd_train(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
+                                const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T, int64_t d,
+                                float* pre_out, float* out, stlt_stream_t stream);
+size_t stlt_frames_embed_bwd_scratch_bytes(int64_t T, int64_t d);
+int stlt_frames_embed_bwd(const float* d_pre, const int64_t* frame_types, int64_t B, int64_t T, int64_t d, float* g_pos, float* g_type,
+                          void* scratch, size_t scratch_bytes, stlt_stream_t stream);
 int stlt_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, stlt_stream_t stream);
 
 /* Criterion of the reference (utils/train_inference_utils.py:64-76) and its gradient in one pass: loss_out[0] = weight *

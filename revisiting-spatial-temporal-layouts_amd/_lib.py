@@ -112,6 +112,12 @@ SIGNATURES = {
                                 _vp, C.c_int64, _vp, _vp, C.c_int64, _vp]),
     "stlt_add_layernorm_bwd_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "stlt_add_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "stlt_embed_fwd_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "stlt_embed_bwd_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "stlt_embed_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "stlt_frames_embed_fwd_train": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "stlt_frames_embed_bwd_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "stlt_frames_embed_bwd": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
     "stlt_gelu_fwd": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "stlt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),

@@ -152,6 +152,42 @@ int stlt_add_layernorm_bwd(const float* dy, const float* x, const float* res, co
   return launch_ln_bwd(dy, d, x, d, res, d, ln_w, eps, M, d, ds, d, g_w, g_b, (float*)scratch, (hipStream_t)stream);
 }
 
+// K1 / K7 with their pre-LayerNorm sums kept (what their backward needs), and the parameter gradients of the sums.
+int stlt_embed_fwd_train(const int64_t* categories, const float* boxes, const float* scores, const float* cat_table, int64_t n_categories,
+                         const float* box_w, const float* box_b, const float* score_w, const float* score_b, const float* ln_w,
+                         const float* ln_b, float eps, int64_t n_tokens, int64_t d, float* pre_out, float* out, stlt_stream_t stream) {
+  if (!pre_out) return stlt_set_error(STLT_EINVAL, "stlt_embed_fwd_train: pre_out is null");
+  return launch_embed(categories, boxes, scores, cat_table, n_categories, box_w, box_b, score_w, score_b, ln_w, ln_b, eps, n_tokens, d, out,
+                      (hipStream_t)stream, pre_out);
+}
+
+size_t stlt_embed_bwd_scratch_bytes(int64_t n_tokens, int64_t n_categories, int64_t d) {
+  return (size_t)embed_bwd_scratch_floats(n_tokens > 0 ? n_tokens : 0, n_categories > 0 ? n_categories : 1, d > 0 ? d : 0) * sizeof(float);
+}
+
+int stlt_embed_bwd(const float* d_pre, const int64_t* categories, const float* boxes, const float* scores, int64_t n_categories,
+                   int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w, float* g_score_b,
+                   void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
+  if (scratch_bytes < stlt_embed_bwd_scratch_bytes(n_tokens, n_categories, d)) return stlt_set_error(STLT_EWORKSPACE, "stlt_embed_bwd: scratch too small");
+  return launch_embed_bwd(d_pre, categories, boxes, scores, n_categories, n_tokens, d, g_cat, g_box_w, g_box_b, g_score_w, g_score_b,
+                          (float*)scratch, (hipStream_t)stream);
+}
+
+int stlt_frames_embed_fwd_train(const float* spatial, int64_t row_stride, const int64_t* frame_types, const float* pos_table,
+                                const float* type_table, const float* ln_w, const float* ln_b, float eps, int64_t B, int64_t T, int64_t d,
+                                float* pre_out, float* out, stlt_stream_t stream) {
+  if (!pre_out) return stlt_set_error(STLT_EINVAL, "stlt_frames_embed_fwd_train: pre_out is null");
+  return launch_frames_embed(spatial, row_stride, frame_types, pos_table, type_table, ln_w, ln_b, eps, B, T, d, out, (hipStream_t)stream, pre_out);
+}
+
+size_t stlt_frames_embed_bwd_scratch_bytes(int64_t T, int64_t d) { return (size_t)16 * (size_t)((T > 0 ? T : 0) + 5) * (size_t)(d > 0 ? d : 0) * sizeof(float); }
+
+int stlt_frames_embed_bwd(const float* d_pre, const int64_t* frame_types, int64_t B, int64_t T, int64_t d, float* g_pos, float* g_type,
+                          void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
+  if (scratch_bytes < stlt_frames_embed_bwd_scratch_bytes(T, d)) return stlt_set_error(STLT_EWORKSPACE, "stlt_frames_embed_bwd: scratch too small");
+  return launch_frames_bwd(d_pre, frame_types, B, T, 1, d, nullptr, g_pos, g_type, (float*)scratch, (hipStream_t)stream);
+}
+
 int stlt_gelu_fwd(const float* u, float* h, int64_t n, stlt_stream_t stream) { return launch_gelu_fwd(u, h, n, (hipStream_t)stream); }
 int stlt_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, stlt_stream_t stream) { return launch_gelu_bwd(dh, u, du, n, (hipStream_t)stream); }
 

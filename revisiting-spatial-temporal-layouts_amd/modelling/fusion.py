@@ -7,8 +7,8 @@ Differences from the reference, by design of the scope (SURVEY §2 row 17, §8f 
     key EXCEPT ``…appearance_branch.resnet.*`` (load reference checkpoints with ``strict=False``);
   * inference is one native call (``stlt_caf_forward``).  Training — with autograd enabled and trainable parameters —
     composes the same arithmetic from the op-level autograd Functions of ``ops.py`` (native forward AND backward kernels
-    per op: linear, attention, add+LayerNorm, GELU), with the LAYOUT BRANCH FROZEN (it runs through the native forward
-    without a tape; unfreeze-and-train of the layout branch inside a fusion model is not built).  Dropout (reference
+    per op: linear, attention, add+LayerNorm, GELU, the two embedding kernels); a frozen layout branch runs through the
+    native forward without a tape, a trainable one through ``StltBackbone.forward_train``.  Dropout (reference
     models.py:333,341,350,358,368,376 and the appearance encoder's fixed 0.1) is applied with torch's generator at the
     post-attention / feed-forward sites; attention-probability dropout is not applied on this path.
 As for STLT, the modules only hold parameters.
@@ -158,15 +158,15 @@ class CrossAttentionFusionBackbone(nn.Module):
 
     def run_train(self, batch: Dict[str, torch.Tensor], fusion_head, layout_head=None, appearance_head=None):
         """Differentiable forward (see the module docstring).  -> same tuple as run()."""
-        if any(q.requires_grad for q in self.layout_branch.parameters()):
-            raise L.StltHipError("training a fusion model needs a frozen layout branch in this build: "
-                                 "`for q in model.<backbone>.layout_branch.parameters(): q.requires_grad_(False)`")
         feats = ops._chk(batch["appearance_features"].contiguous(), torch.float32, "appearance_features")
-        was_training = self.layout_branch.training
-        self.layout_branch.train(False)
-        with torch.no_grad():
-            Lh = self.layout_branch.forward_batch_major(batch)  # (B,T,d), no tape: the branch is frozen
-        self.layout_branch.train(was_training)
+        if any(q.requires_grad for q in self.layout_branch.parameters()):
+            Lh = self.layout_branch.forward_train(batch)  # (B,T,d) with its autograd graph (op-level composition)
+        else:  # frozen (load_backbone_path + freeze_backbone): one native call, no tape
+            was_training = self.layout_branch.training
+            self.layout_branch.train(False)
+            with torch.no_grad():
+                Lh = self.layout_branch.forward_batch_major(batch)
+            self.layout_branch.train(was_training)
         Ah = self._appearance_train(feats)
         B = Lh.shape[0]
         idx = torch.arange(B, device=Lh.device)

@@ -358,3 +358,74 @@ class GeluFn(torch.autograd.Function):
         du = torch.empty_like(u)
         L.check(lib.stlt_gelu_bwd(_p(dh), _p(u), _p(du), u.numel(), _stream()), "stlt_gelu_bwd")
         return du
+
+
+class EmbedFn(torch.autograd.Function):
+    """K1 (CategoryBoxEmbeddings, models.py:29-39) under autograd: native forward keeping the pre-LayerNorm sum, native backward."""
+
+    @staticmethod
+    def forward(ctx, categories, boxes, scores, cat_w, box_w, box_b, score_w, score_b, ln_w, ln_b, eps):
+        lib = L.load()
+        categories = _chk(categories.contiguous(), torch.int64, "categories")
+        boxes = _chk(boxes.contiguous(), torch.float32, "boxes")
+        scores = None if scores is None else _chk(scores.contiguous(), torch.float32, "scores")
+        tok, d = categories.numel(), cat_w.shape[1]
+        pre = torch.empty(*categories.shape, d, device=categories.device, dtype=torch.float32)
+        out = torch.empty_like(pre)
+        L.check(lib.stlt_embed_fwd_train(_p(categories), _p(boxes), _p(scores), _p(cat_w), cat_w.shape[0], _p(box_w), _p(box_b), _p(score_w),
+                                         _p(score_b), _p(ln_w), _p(ln_b), float(eps), tok, d, _p(pre), _p(out), _stream()), "stlt_embed_fwd_train")
+        ctx.save_for_backward(categories, boxes, scores, pre, ln_w, cat_w, box_w, score_w)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        categories, boxes, scores, pre, ln_w, cat_w, box_w, score_w = ctx.saved_tensors
+        tok, d, Cn = categories.numel(), pre.shape[-1], cat_w.shape[0]
+        dy = dy.contiguous()
+        d_pre = torch.empty_like(pre)
+        g_ln_w, g_ln_b = torch.zeros_like(ln_w), torch.zeros_like(ln_w)
+        sc = _scratch(max(int(lib.stlt_add_layernorm_bwd_scratch_bytes(d)), int(lib.stlt_embed_bwd_scratch_bytes(tok, Cn, d))), pre.device)
+        L.check(lib.stlt_add_layernorm_bwd(_p(dy), _p(pre), None, _p(ln_w), float(ctx.eps), tok, d, _p(d_pre), _p(g_ln_w), _p(g_ln_b),
+                                           sc.data_ptr(), sc.numel(), _stream()), "stlt_add_layernorm_bwd")
+        g_cat, g_box_w = torch.zeros_like(cat_w), torch.zeros_like(box_w)
+        g_box_b = torch.zeros(d, device=pre.device, dtype=torch.float32)
+        g_sw = torch.zeros_like(score_w) if scores is not None else None
+        g_sb = torch.zeros(d, device=pre.device, dtype=torch.float32) if scores is not None else None
+        L.check(lib.stlt_embed_bwd(_p(d_pre), _p(categories), _p(boxes), _p(scores), Cn, tok, d, _p(g_cat), _p(g_box_w), _p(g_box_b), _p(g_sw),
+                                   _p(g_sb), sc.data_ptr(), sc.numel(), _stream()), "stlt_embed_bwd")
+        return None, None, None, g_cat, g_box_w, g_box_b, g_sw, g_sb, g_ln_w, g_ln_b, None
+
+
+class FramesEmbedFn(torch.autograd.Function):
+    """K7 (FramesEmbeddings, models.py:98-111) on the (B,T,d) CLS rows under autograd."""
+
+    @staticmethod
+    def forward(ctx, cls_rows, frame_types, pos_w, type_w, ln_w, ln_b, eps):
+        lib = L.load()
+        cls_rows = _chk(cls_rows.contiguous(), torch.float32, "cls_rows")
+        frame_types = _chk(frame_types.contiguous(), torch.int64, "frame_types")
+        B, T, d = cls_rows.shape
+        pre, out = torch.empty_like(cls_rows), torch.empty_like(cls_rows)
+        L.check(lib.stlt_frames_embed_fwd_train(_p(cls_rows), d, _p(frame_types), _p(pos_w), _p(type_w), _p(ln_w), _p(ln_b), float(eps), B, T, d,
+                                                _p(pre), _p(out), _stream()), "stlt_frames_embed_fwd_train")
+        ctx.save_for_backward(frame_types, pre, ln_w, pos_w, type_w)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        frame_types, pre, ln_w, pos_w, type_w = ctx.saved_tensors
+        B, T, d = pre.shape
+        dy = dy.contiguous()
+        d_pre = torch.empty_like(pre)
+        g_ln_w, g_ln_b = torch.zeros_like(ln_w), torch.zeros_like(ln_w)
+        sc = _scratch(max(int(lib.stlt_add_layernorm_bwd_scratch_bytes(d)), int(lib.stlt_frames_embed_bwd_scratch_bytes(T, d))), pre.device)
+        L.check(lib.stlt_add_layernorm_bwd(_p(dy), _p(pre), None, _p(ln_w), float(ctx.eps), B * T, d, _p(d_pre), _p(g_ln_w), _p(g_ln_b),
+                                           sc.data_ptr(), sc.numel(), _stream()), "stlt_add_layernorm_bwd")
+        g_pos, g_type = torch.zeros_like(pos_w), torch.zeros_like(type_w)
+        L.check(lib.stlt_frames_embed_bwd(_p(d_pre), _p(frame_types), B, T, d, _p(g_pos), _p(g_type), sc.data_ptr(), sc.numel(), _stream()),
+                "stlt_frames_embed_bwd")
+        return d_pre, None, g_pos, g_type, g_ln_w, g_ln_b, None

@@ -81,11 +81,12 @@ def test_caf_gpu_full_width_matches_oracle(pkg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("freeze_layout", [True, False])
 @pytest.mark.parametrize("model_name", ["caf", "cacnf"])
-def test_fusion_training_path_matches_golden_and_oracle_gradients(pkg, model_name):
-    """With autograd on and the layout branch frozen the forward is composed from the op-level autograd Functions (native
-    forward and backward kernels): its logits must still be the reference's, and every trainable gradient must match
-    torch autograd on the CPU oracle."""
+def test_fusion_training_path_matches_golden_and_oracle_gradients(pkg, model_name, freeze_layout):
+    """With autograd on, the forward is composed from the op-level autograd Functions (native forward and backward
+    kernels); a frozen layout branch runs natively without a tape, a trainable one through StltBackbone.forward_train.
+    The logits must still be the reference's, and every trainable gradient must match torch autograd on the CPU oracle."""
     import torch.nn.functional as F
     z, meta, sd, batch, c = _case(pkg.synth, model_name)
     cls = pkg.models_factory[model_name]
@@ -94,10 +95,9 @@ def test_fusion_training_path_matches_golden_and_oracle_gradients(pkg, model_nam
     m.train(False).to("cuda")  # eval mode: no dropout, the appearance encoder's fixed 0.1 included
     bb = m.caf_backbone if model_name == "caf" else m.backbone
     dev_batch = {k: v.to("cuda") for k, v in batch.items()}
-    with pytest.raises(pkg.StltHipError, match="frozen layout branch"):
-        m(dev_batch)
-    for q in bb.layout_branch.parameters():
-        q.requires_grad_(False)
+    if freeze_layout:
+        for q in bb.layout_branch.parameters():
+            q.requires_grad_(False)
     out = m(dev_batch)
     for k in z.files:
         assert out[k].requires_grad and np.abs(out[k].detach().cpu().numpy() - z[k]).max() <= 1e-4, k
@@ -105,7 +105,8 @@ def test_fusion_training_path_matches_golden_and_oracle_gradients(pkg, model_nam
     loss = sum(F.cross_entropy(v, labels.to("cuda")) for v in out.values()) / len(out)
     loss.backward()
     frozen_prefix = ("caf_backbone." if model_name == "caf" else "backbone.") + "layout_branch."
-    leaves = {k: (v.clone().requires_grad_(not k.startswith(frozen_prefix)) if v.is_floating_point() else v) for k, v in sd.items()}
+    frozen = lambda k: freeze_layout and k.startswith(frozen_prefix)
+    leaves = {k: (v.clone().requires_grad_(not frozen(k)) if v.is_floating_point() else v) for k, v in sd.items()}
     fwd = CO.caf_forward if model_name == "caf" else CO.cacnf_forward
     ref = fwd(leaves, batch, c["num_attention_heads"])  # fp32 CPU autograd (the oracle's layout branch is fp32)
     ref_loss = sum(F.cross_entropy(v, labels) for v in ref.values()) / len(ref)
@@ -114,17 +115,35 @@ def test_fusion_training_path_matches_golden_and_oracle_gradients(pkg, model_nam
     checked = 0
     for k, prm in m.named_parameters():
         g_ref = leaves[k].grad if leaves[k].is_floating_point() else None
-        if k.startswith(frozen_prefix) or g_ref is None:
+        if frozen(k):
             assert prm.grad is None, k
             continue
-        if prm.grad is None:  # parameters the forward never reads (the appearance branch's own classifier)
-            assert g_ref.abs().max().item() == 0.0, k
+        if prm.grad is None or g_ref is None:  # parameters the forward never reads (dead encoder_layer copy, unused classifier, scores)
+            assert g_ref is None or g_ref.abs().max().item() == 0.0, k
+            assert prm.grad is None or prm.grad.abs().max().item() == 0.0, k
             continue
         scale = max(g_ref.abs().max().item(), 1e-6)
         assert (prm.grad.cpu() - g_ref).abs().max().item() / scale <= 5e-4, k
         checked += 1
-    assert checked > 40
+    assert checked > (40 if freeze_layout else 150)
 
+
+@pytest.mark.gpu
+def test_backbone_forward_train_matches_native_forward(pkg):
+    """StltBackbone under autograd (op-level composition) against its own native no-grad forward, cfg1 with scores."""
+    c = pkg.synth.CONFIGS[NAME]
+    m = pkg.StltBackbone(pkg.StltModelConfig(**pkg.synth.model_kwargs(NAME)))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=9, gain=1.5))
+    m.train(False).to("cuda")
+    batch = {k: v.to("cuda") for k, v in pkg.synth.make_batch(3, c["T"], c["N"], seed=4, with_scores=True).items()}
+    with torch.no_grad():
+        ref = m(batch)
+    out = m(batch)  # (T,B,d) like the reference
+    assert out.requires_grad and out.shape == ref.shape
+    real = (~batch["src_key_padding_mask_frames"]).t()  # padded frames' rows differ in nothing that matters, but compare the real ones
+    assert (out.detach() - ref)[real].abs().max().item() <= 2e-5
+    out.sum().backward()
+    assert m.frames_embeddings.layout_embedding.category_box_embeddings.score_embeddings.weight.grad is not None
 
 @pytest.mark.gpu
 def test_fusion_training_step_with_dropout_runs(pkg):
