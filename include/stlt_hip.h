@@ -272,9 +272,14 @@ typedef struct {
 size_t stlt_linear_bwd_scratch_bytes(int64_t N);
 int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, float* dw, float* db,
                     void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+/* attention with train-mode dropout of the probabilities (nn.MultiheadAttention(dropout=p)): counter-based mask from
+ * (seed, site, query row, head, key position); stlt_attn_bwd given the same (p, seed, site) recomputes it.  p = 0: none. */
+int stlt_attn_fwd_dropout(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm, int causal,
+                          int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float dropout_p, uint64_t seed, uint32_t site, float* ctx,
+                          stlt_stream_t stream);
 int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dctx, const uint8_t* kpm,
-                  int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* dq, int64_t lddq, float* dk, float* dv,
-                  int64_t lddkv, stlt_stream_t stream);
+                  int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float dropout_p, uint64_t seed, uint32_t site,
+                  float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv, stlt_stream_t stream);
 size_t stlt_add_layernorm_bwd_scratch_bytes(int64_t d);
 int stlt_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* ln_w, float eps, int64_t M, int64_t d,
                            float* ds, float* g_w, float* g_b, void* scratch, size_t scratch_bytes, stlt_stream_t stream);

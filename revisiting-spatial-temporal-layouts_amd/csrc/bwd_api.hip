@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void attn_bwd_general_kernel(const float* __re
                                                                const float* __restrict__ dctx, const uint8_t* __restrict__ kpm,
                                                                int causal, int Lq, int Lk, int H, float scale,
                                                                float* __restrict__ dq, int64_t lddq, float* __restrict__ dk,
-                                                               float* __restrict__ dv, int64_t lddkv) {
+                                                               float* __restrict__ dv, int64_t lddkv, StltDrop dr, uint32_t site) {
   extern __shared__ float xb_smem[];
   const int PLD = Lk + 1;
   float* Qs = xb_smem;
@@ -48,6 +48,10 @@ __global__ __launch_bounds__(256) void attn_bwd_general_kernel(const float* __re
     for (int c = 0; c < XB_DH; ++c) {
       s += Qs[i * XB_LD + c] * Ks[j * XB_LD + c];
       dp += Gs[i * XB_LD + c] * Vs[j * XB_LD + c];
+    }
+    if (dr.thr) {  // the forward multiplied P by the dropout mask before P·V: same counter-based mask here
+      const uint64_t idx = ((((uint64_t)(q0 + i)) * H + head) << 8) | (uint64_t)(j & 0xff);
+      dp = stlt_keep(dr, site, idx) ? dp * dr.scale : 0.f;
     }
     Ps[i * PLD + j] = ok ? s * scale : -1e30f;
     Ds[i * PLD + j] = dp;
@@ -85,7 +89,12 @@ __global__ __launch_bounds__(256) void attn_bwd_general_kernel(const float* __re
     float ak = 0.f, av = 0.f;
     for (int i = 0; i < Lq; ++i) {
       ak += Ds[i * PLD + r] * Qs[i * XB_LD + c];
-      av += Ps[i * PLD + r] * Gs[i * XB_LD + c];
+      float pd = Ps[i * PLD + r];
+      if (dr.thr) {
+        const uint64_t idx = ((((uint64_t)(q0 + i)) * H + head) << 8) | (uint64_t)(r & 0xff);
+        pd = stlt_keep(dr, site, idx) ? pd * dr.scale : 0.f;
+      }
+      av += pd * Gs[i * XB_LD + c];
     }
     dk[(k0 + r) * lddkv + head * XB_DH + c] = ak * scale;
     dv[(k0 + r) * lddkv + head * XB_DH + c] = av;
@@ -123,9 +132,18 @@ int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, 
   return 0;
 }
 
+int stlt_attn_fwd_dropout(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm, int causal,
+                          int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float dropout_p, uint64_t seed, uint32_t site, float* ctx,
+                          stlt_stream_t stream) {
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
+  return launch_attn_general(q, ldq, k, v, ldkv, kpm, causal, S, Lq, Lk, H, dh, ctx, causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL,
+                             (hipStream_t)stream, stlt_drop_make(dropout_p, seed), site);
+}
+
 int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dctx, const uint8_t* kpm,
-                  int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* dq, int64_t lddq, float* dk, float* dv,
-                  int64_t lddkv, stlt_stream_t stream) {
+                  int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float dropout_p, uint64_t seed, uint32_t site,
+                  float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv, stlt_stream_t stream) {
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
   if (!q || !k || !v || !dctx || !dq || !dk || !dv) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: null pointer");
   if (dh != XB_DH) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: head dim must be 64");
   if (Lq <= 0 || Lk <= 0 || Lq > XB_MAXL || Lk > XB_MAXL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: sequences of at most %d tokens (got %lld / %lld)", XB_MAXL, (long long)Lq, (long long)Lk);
@@ -140,7 +158,7 @@ int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, i
     opt_in = true;
   }
   hipLaunchKernelGGL(attn_bwd_general_kernel, dim3((unsigned)(S * H)), dim3(256), lds, (hipStream_t)stream, q, ldq, k, v, ldkv, dctx, kpm, causal,
-                     (int)Lq, (int)Lk, (int)H, 1.0f / sqrtf((float)dh), dq, lddq, dk, dv, lddkv);
+                     (int)Lq, (int)Lk, (int)H, 1.0f / sqrtf((float)dh), dq, lddq, dk, dv, lddkv, stlt_drop_make(dropout_p, seed), site);
   return stlt_check_launch("attn_bwd_general_kernel");
 }
 

@@ -10,7 +10,7 @@ Differences from the reference, by design of the scope (SURVEY §2 row 17, §8f 
     per op: linear, attention, add+LayerNorm, GELU, the two embedding kernels); a frozen layout branch runs through the
     native forward without a tape, a trainable one through ``StltBackbone.forward_train``.  Dropout (reference
     models.py:333,341,350,358,368,376 and the appearance encoder's fixed 0.1) is applied with torch's generator at the
-    post-attention / feed-forward sites; attention-probability dropout is not applied on this path.
+    post-attention / feed-forward sites and with the native counter-based mask on the attention probabilities.
 As for STLT, the modules only hold parameters.
 """
 from __future__ import annotations
@@ -126,7 +126,7 @@ class CrossAttentionFusionBackbone(nn.Module):
             q = ops.LinearFn.apply(x, W[:d], b[:d])
             kv = ops.LinearFn.apply(ctx, W[d:], b[d:])
             k, v = kv[..., :d], kv[..., d:]
-        a = ops.AttnFn.apply(q, k, v, kpm, causal, H)
+        a = ops.AttnFn.apply(q, k, v, kpm, causal, H, p_drop if self.training else 0.0)
         o = ops.LinearFn.apply(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
         o = F.dropout(o, p_drop, self.training)
         return ops.AddLayerNormFn.apply(o, x, blk.ln.weight, blk.ln.bias, self.config.layer_norm_eps)
@@ -142,7 +142,7 @@ class CrossAttentionFusionBackbone(nn.Module):
         for l in ab.transformer.layers:  # nn.TransformerEncoderLayer defaults: ReLU, post-norm, eps 1e-5, dropout 0.1
             sa = l.self_attn
             qkv = ops.LinearFn.apply(x, sa.in_proj_weight, sa.in_proj_bias)
-            a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], None, False, H)
+            a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], None, False, H, 0.1 if self.training else 0.0)
             a = F.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), 0.1, self.training)
             x = ops.AddLayerNormFn.apply(a, x, l.norm1.weight, l.norm1.bias, 1e-5)
             h = F.dropout(torch.relu(self._lin(x, l.linear1)), 0.1, self.training)

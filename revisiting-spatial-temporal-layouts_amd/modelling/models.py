@@ -280,11 +280,12 @@ class StltBackbone(nn.Module):
     # ---- differentiable forward, composed from the op-level autograd Functions of ops.py ----------------------------
     def _encoder_layer_train(self, l: _EncoderLayerParams, x: torch.Tensor, kpm, causal: bool) -> torch.Tensor:
         """nn.TransformerEncoderLayer as configured at models.py:46-52,118-124 (post-norm, GELU, eps 1e-5); dropout at the
-        post-attention / feed-forward sites with torch's generator (no attention-probability dropout on this path)."""
+        post-attention / feed-forward sites with torch's generator, on the attention probabilities with the native
+        counter-based mask."""
         p, H, d = self.config.hidden_dropout_prob, self.config.num_attention_heads, x.shape[-1]
         sa = l.self_attn
         qkv = ops.LinearFn.apply(x, sa.in_proj_weight, sa.in_proj_bias)
-        a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, causal, H)
+        a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, causal, H, p if self.training else 0.0)
         a = F.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), p, self.training)
         x = ops.AddLayerNormFn.apply(a, x, l.norm1.weight, l.norm1.bias, _ENC_EPS)
         h = F.dropout(ops.GeluFn.apply(ops.LinearFn.apply(x, l.linear1.weight, l.linear1.bias)), p, self.training)

@@ -273,10 +273,13 @@ class LinearFn(torch.autograd.Function):
 
 class AttnFn(torch.autograd.Function):
     """softmax(q kᵀ / sqrt(dh) + mask) v per head.  q (S,Lq,d), k / v (S,Lk,d): last dim contiguous, k and v with the same
-    row stride (views of a packed projection are fine).  kpm (S,Lk) over the keys or None."""
+    row stride (views of a packed projection are fine).  kpm (S,Lk) over the keys or None.  dropout_p > 0: train-mode
+    dropout of the attention probabilities with a counter-based mask (seed drawn from torch's CPU generator)."""
+
+    _site = 0x100  # a site id of its own per call keeps the masks of different attention calls apart
 
     @staticmethod
-    def forward(ctx, q, k, v, kpm, causal, heads):
+    def forward(ctx, q, k, v, kpm, causal, heads, dropout_p=0.0):
         lib = L.load()
         S, Lq, d = q.shape
         Lk = k.shape[1]
@@ -287,17 +290,20 @@ class AttnFn(torch.autograd.Function):
             raise L.StltHipError("AttnFn: k and v need the same row stride")
         kpm8 = torch.zeros(S, Lk, dtype=torch.uint8, device=q.device) if kpm is None else _mask_u8(kpm.contiguous(), "kpm")
         ctxt = torch.empty(S, Lq, d, device=q.device, dtype=torch.float32)
-        L.check(lib.stlt_attn_cross_fwd(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), _p(kpm8), int(bool(causal)),
-                                        S, Lq, Lk, heads, d // heads, _p(ctxt), _stream()), "stlt_attn_cross_fwd")
+        p = float(dropout_p)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        AttnFn._site = site = (AttnFn._site + 1) & 0xffffff if p > 0 else 0
+        L.check(lib.stlt_attn_fwd_dropout(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), _p(kpm8), int(bool(causal)),
+                                          S, Lq, Lk, heads, d // heads, p, seed, site, _p(ctxt), _stream()), "stlt_attn_fwd_dropout")
         ctx.save_for_backward(q, k, v, kpm8)
-        ctx.meta = (bool(causal), heads)
+        ctx.meta = (bool(causal), heads, p, seed, site)
         return ctxt
 
     @staticmethod
     def backward(ctx, dctx):
         lib = L.load()
         q, k, v, kpm8 = ctx.saved_tensors
-        causal, heads = ctx.meta
+        causal, heads, p, seed, site = ctx.meta
         S, Lq, d = q.shape
         Lk = k.shape[1]
         dctx = dctx.contiguous()
@@ -305,8 +311,8 @@ class AttnFn(torch.autograd.Function):
         dk = torch.empty(S, Lk, d, device=q.device, dtype=torch.float32)
         dv = torch.empty(S, Lk, d, device=q.device, dtype=torch.float32)
         L.check(lib.stlt_attn_bwd(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), _p(dctx), _p(kpm8), int(causal),
-                                  S, Lq, Lk, heads, d // heads, _p(dq), d, _p(dk), _p(dv), d, _stream()), "stlt_attn_bwd")
-        return dq, dk, dv, None, None, None
+                                  S, Lq, Lk, heads, d // heads, p, seed, site, _p(dq), d, _p(dk), _p(dv), d, _stream()), "stlt_attn_bwd")
+        return dq, dk, dv, None, None, None, None
 
 
 class AddLayerNormFn(torch.autograd.Function):
