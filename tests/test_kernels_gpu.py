@@ -369,3 +369,26 @@ def test_attention_autograd_with_probability_dropout(pkg, Lq, Lk, packed):
     fd = ((run(base + direction, 1) * w).sum() - (run(base - direction, 1) * w).sum()).item() / 2
     an = (x.grad * direction).sum().item()
     assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-2), (fd, an)
+
+
+def test_linear_randomised_shapes_plain_and_stream_k(pkg):
+    """40 random (M, N, K, activation) problems, each through the plain persistent path and the stream-K path, against fp64."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    worst = 0.0
+    for i in range(40):
+        M = int(rng.integers(1, 6000)) if i % 4 else int(rng.choice([1, 31, 255, 256, 257, 4096]))
+        N = int(rng.integers(1, 3200)) if i % 3 else int(rng.choice([1, 127, 128, 129, 174, 2304]))
+        K = 32 * int(rng.integers(1, 100 if M * N < 4_000_000 else 24))
+        act = int(rng.integers(0, 3))
+        x, w, b = _rand(M, K, seed=i), _rand(N, K, seed=100 + i, scale=1 / math.sqrt(K)), _rand(N, seed=200 + i, scale=0.1)
+        ref = x.double() @ w.double().t() + b.double()
+        ref = {0: lambda t: t, 1: O.gelu, 2: torch.relu}[act](ref)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        plain = pkg.ops.linear(xd, wd, bd, act=act).cpu().double()
+        with pkg.ops.gemm_scratch():
+            sk = pkg.ops.linear(xd, wd, bd, act=act).cpu().double()
+        tol = 2e-5 * max(1.0, math.sqrt(K / 768))
+        e1, e2 = (plain - ref).abs().max().item(), (sk - ref).abs().max().item()
+        worst = max(worst, e1, e2)
+        assert e1 <= tol and e2 <= tol, (M, N, K, act, e1, e2)
+    print(f"worst abs error over 40 random linear problems: {worst:.2e}")
