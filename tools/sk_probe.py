@@ -1,3 +1,7 @@
+"""Run one nn.Linear shape 50 times, with or without the stream-K scratch lent, for profiling under rocprofv3:
+
+    tools/prof_kernels.sh sk tools/sk_probe.py <M> <N> <K> <0|1>
+"""
 import importlib, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
