@@ -101,3 +101,35 @@ def test_long_sequence_training_with_dropout_is_seeded(pkg):
     an = (ga * direction).sum().item()
     assert abs(fd - an) <= 1e-2 * max(abs(an), 1e-3) + 2e-5, (fd, an)
     m.train(False)
+
+
+@pytest.mark.parametrize("d,H", [(64, 1), (128, 2), (512, 8), (1024, 16)])
+def test_other_hidden_sizes_forward_and_gradients(pkg, d, H):
+    """The kernels are written for head dim 64 and any hidden size that is a multiple of it (up to 2048): released
+    checkpoints use 768 / 12, the tests mostly 256 / 4 — cover a few more."""
+    kw = dict(pkg.synth.model_kwargs("cfg1"), hidden_size=d, num_attention_heads=H, num_spatial_layers=2, num_temporal_layers=2)
+    m = pkg.Stlt(pkg.StltModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=13, gain=1.5)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    batch = pkg.synth.make_batch(3, 9, 5, seed=6, min_len=2)
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    ref = O.stlt_forward(sd, batch, H)["stlt"]
+    m.train(False)
+    with torch.no_grad():
+        for skip in (False, True):
+            m.backbone.skip_padding = skip
+            assert (m(dev)["stlt"].cpu() - ref).abs().max().item() <= 1e-4, skip
+    m.backbone.skip_padding = False
+    m.train(True)
+    labels = torch.tensor([1, 2, 3])
+    leaves = {k: (v.detach().double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    F.cross_entropy(O.stlt_forward(leaves, b64, H, dtype=torch.float64)["stlt"], labels).backward()
+    F.cross_entropy(m(dev)["stlt"], labels.to(DEV)).backward()
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            continue
+        g_ref = leaves[k].grad
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        assert (prm.grad.cpu().double() - g_ref).abs().max().item() / scale <= 3e-4, k
