@@ -47,6 +47,37 @@ constexpr int STAGE_FLOATS = (BM + BN) * BK;  // 12288 floats = 48 KB per stage
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
+#ifndef STLT_GELU_BRANCH_FREE
+#define STLT_GELU_BRANCH_FREE 0
+#endif
+// GELU of the FFN1 epilogue.  The library erff takes one of two branches per lane (|z| < 1: 8 instructions; else a
+// degree-7 polynomial + exp, ~24), so its cost in a 64-lane wave depends on the data: cheap while every lane of a wave
+// is below 1, ~38 instructions once both branches are live.  STLT_GELU_BRANCH_FREE=1 selects a fixed-cost form instead:
+// erf(t) = 1 - 2^q(t) for t = min(|z|, 3.95) with q a degree-11 fit of log2(erfc) and one v_exp_f32; max abs error of
+// erf 1.1e-7 in fp32 (200k points), the order of erff's own rounding.
+__device__ __forceinline__ float gelu_epilogue(float x) {
+#if STLT_GELU_BRANCH_FREE
+  const float z = x * 0.70710678118654752440f;
+  const float t = fminf(fabsf(z), 3.95f);
+  float q = 1.1830035617776957e-07f;
+  q = fmaf(q, t, -3.0875787615514128e-06f);
+  q = fmaf(q, t, 3.5860794014297426e-05f);
+  q = fmaf(q, t, -0.00024206875241361558f);
+  q = fmaf(q, t, 0.0010191010078415275f);
+  q = fmaf(q, t, -0.002435620641335845f);
+  q = fmaf(q, t, 0.00011764218652388081f);
+  q = fmaf(q, t, 0.027792135253548622f);
+  q = fmaf(q, t, -0.14836618304252625f);
+  q = fmaf(q, t, -0.9184255599975586f);
+  q = fmaf(q, t, -1.6279090642929077f);
+  q = fmaf(q, t, 2.831300349726007e-08f);
+  const float e = copysignf(1.0f - __builtin_amdgcn_exp2f(q), z);
+  return 0.5f * x * (1.0f + e);
+#else
+  return gelu_erf(x);
+#endif
+}
+
 template <int ACT, bool STAMP, bool TA, bool TB, bool ADD, bool SK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ W, int64_t ldw,
@@ -372,7 +403,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
             for (int r = 0; r < 16; ++r) {
               float val = acc[a][b][r];
               if (ADD) val += rp[(int64_t)(rstep * ((r & 3) + 8 * (r >> 2))) * ldr];
-              if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+              if (ACT == STLT_ACT_GELU) val = gelu_epilogue(val);
               if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
               yp[(int64_t)(rstep * ((r & 3) + 8 * (r >> 2))) * ldy] = val;
             }
@@ -381,7 +412,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
             for (int r = 0; r < 16; ++r) {
               const int row = rstep * ((r & 3) + 8 * (r >> 2));
               float val = acc[a][b][r];
-              if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+              if (ACT == STLT_ACT_GELU) val = gelu_epilogue(val);
               if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
               if (n < N && mb + row < M) yp[(int64_t)row * ldy] = ADD ? val + rp[(int64_t)row * ldr] : val;
             }
@@ -439,7 +470,7 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict
       if (n < N) {
         float val = acc[e] + bv[e];
         if (R) val += R[(int64_t)m * ldr + n];
-        if (ACT == STLT_ACT_GELU) val = gelu_erf(val);
+        if (ACT == STLT_ACT_GELU) val = gelu_epilogue(val);
         if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
         Y[(int64_t)m * ldy + n] = val;
       }
