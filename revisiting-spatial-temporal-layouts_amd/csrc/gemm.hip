@@ -20,7 +20,21 @@
 //     vmcnt(6) that only waits for step s+1's data;
 //   * fragments are read one 8-wide k-chunk ahead (ping-pong registers), and the read of the next step's first
 //     chunk sits between the barrier and the last 16 MFMAs of the current step;
-//   * the bias is the accumulators' initial value, fetched one tile ahead.
+//   * the MFMA computes the TRANSPOSED tile (W fragment as the A operand, X fragment as B): a lane then owns one
+//     output row and its 16 accumulator registers are 4 groups of 4 CONSECUTIVE output columns, so the epilogue is
+//     16-byte stores (16 per wave and tile instead of 64 scalar ones: the store tail is issue-bound, it cost 4 % at
+//     K = 768); products and summation order are unchanged, results are bit-identical to the untransposed form;
+//   * the bias is the accumulators' initial value, fetched one tile ahead (read from its LDS strip straight into
+//     the accumulator registers when a tile's epilogue re-initialises them).
+//
+// Wave specialisation (template flag WS, the default for launches that are not stream-K): the workgroup has four more
+// waves (8..11, one per SIMD) that do nothing but issue the LDS-DMA, and the eight MFMA waves issue none.  The CU's
+// load path delivers ~10 B/clk and a k-step needs 6: a wave that issues a DMA queues behind the other waves' pieces
+// (~130 cycles per instruction, in order, so its MFMAs wait too), and because SIMD partners alternate whole 16-MFMA
+// runs both partners reach their DMA issue together and the matrix pipe idles meanwhile.  Ablation (timing-only
+// builds, 229376x2304x768 / 229376x768x3072): no DMA issue 131 -> 144 / 136 -> 146 TFLOP/s, no fragment reads +-0, no
+// barrier -1 %, no counted wait +-1 %, no epilogue stores +4 % / +1 %.  A loader wave parks at the barrier between
+// its bursts and costs the matrix pipe nothing.
 //
 // Operand layouts (template flags) for the backward pass of nn.Linear:
 //   TA=0: A stored (M, Kc) k-contiguous      TA=1: A stored (Kc, M) m-contiguous  (dW = dYᵀ·X reads dY this way)
@@ -39,14 +53,22 @@ namespace {
 #endif
 
 constexpr int BM = 256, BN = 128, BK = 32;
-constexpr int GEMM_WAVES = 8;
+constexpr int GEMM_WAVES = 8;                           // MFMA waves
 constexpr int GEMM_THREADS = 64 * GEMM_WAVES;
+constexpr int GEMM_LOADERS = 4;                         // WS: DMA-only waves 8..11
+constexpr int GEMM_THREADS_WS = 64 * (GEMM_WAVES + GEMM_LOADERS);
 constexpr int NSTAGE = 3;
 constexpr int STAGE_FLOATS = (BM + BN) * BK;  // 12288 floats = 48 KB per stage
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
+#ifndef STLT_GEMM_ABLATE
+#define STLT_GEMM_ABLATE 0  // timing-only builds (wrong results): bit 0 no steady-state DMA, bit 3 loaders do not wait for their DMA, bit 4 no epilogue stores, bit 5 loaders re-read k-step 0 of their first tile (cache-hot source)
+#endif
+#ifndef STLT_GEMM_WS_DEFAULT
+#define STLT_GEMM_WS_DEFAULT 1
+#endif
 #ifndef STLT_GELU_BRANCH_FREE
 #define STLT_GELU_BRANCH_FREE 0
 #endif
@@ -78,8 +100,8 @@ __device__ __forceinline__ float gelu_epilogue(float x) {
 #endif
 }
 
-template <int ACT, bool STAMP, bool TA, bool TB, bool ADD, bool SK>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
+template <int ACT, bool STAMP, bool TA, bool TB, bool ADD, bool SK, bool WS>
+__global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ W, int64_t ldw,
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ R, int64_t ldr,
@@ -130,6 +152,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     dbg[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
     dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
     dbg[4 * blockIdx.x + 3] = my_tiles;
+    dbg[4 * (size_t)gridDim.x + (size_t)gridDim.x * GEMM_WAVES * 6 + 1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime();  // shader clock, behind the stamp / trace regions
   }
   const int total_steps = SK ? (my_tiles - 1) * nk + sk_tail - sk_kt0 : my_tiles * nk;
   // does this workgroup compute every k-step of its it-th tile?  (otherwise the segment is a partial: no bias, raw store)
@@ -153,8 +176,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   //   k-contiguous operand : image [rows][32 k] (swizzled); an instruction covers 8 rows x 128 B
   //   contraction-major    : image [32 k][256 m | 128 n]; an instruction covers one 1-KB k-row (A) / two 512-B k-rows (B)
   const int drow = lane >> 3, dslot = lane & 7;
-  const float* pa[4];
-  const float* pb[2];
+  constexpr int NV = WS ? 2 : 1;  // a loader wave does the DMA share of MFMA waves 2j and 2j+1
+  const float* pa[NV][4];
+  const float* pb[NV][2];
+  const int vw0 = WS ? 2 * (wave - GEMM_WAVES) : wave;  // first "virtual wave" whose DMA share this wave issues (WS: loaders only)
   const int64_t a_kstep = TA ? (int64_t)BK * ldx : BK;
   const int64_t b_kstep = TB ? (int64_t)BK * ldw : BK;
   auto dma_set_tile = [&](int it) {
@@ -162,51 +187,56 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     tile_origin(it, m0, n0, split);
     const int64_t kbase = (int64_t)split * nk * BK;  // first contraction index of this split
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (TA) {
-        const int kr = wave * 4 + i;                 // k-row inside the step
-        int col = m0 + lane * 4;
-        col = col + 4 <= M ? col : (M >= 4 ? ((M - 4) & ~3) : 0);  // keep the 16-B read inside the row; those output rows are never stored
-        pa[i] = X + (kbase + kr) * ldx + col;
-      } else {
-        const int r = wave * 32 + i * 8 + drow;      // row inside the A tile
-        int gm = m0 + r;
-        gm = gm < M ? gm : M - 1;                    // ragged tiles re-read the last row; stores are guarded
-        pa[i] = X + (int64_t)gm * ldx + kbase + (dslot ^ ((r >> 1) & 7)) * 4;  // source-side swizzle
-      }
-    }
+    for (int u = 0; u < NV; ++u) {
+      const int vw = vw0 + u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (TB) {
-        const int kr = wave * 4 + i * 2 + (lane >> 5);
-        int col = n0 + (lane & 31) * 4;
-        col = col + 4 <= N ? col : (N >= 4 ? ((N - 4) & ~3) : 0);
-        pb[i] = W + (kbase + kr) * ldw + col;
-      } else {
-        const int r = wave * 16 + i * 8 + drow;      // row inside the B tile
-        int gn = n0 + r;
-        gn = gn < N ? gn : N - 1;
-        pb[i] = W + (int64_t)gn * ldw + kbase + (dslot ^ ((r >> 1) & 7)) * 4;
+      for (int i = 0; i < 4; ++i) {
+        if (TA) {
+          const int kr = vw * 4 + i;                 // k-row inside the step
+          int col = m0 + lane * 4;
+          col = col + 4 <= M ? col : (M >= 4 ? ((M - 4) & ~3) : 0);  // keep the 16-B read inside the row; those output rows are never stored
+          pa[u][i] = X + (kbase + kr) * ldx + col;
+        } else {
+          const int r = vw * 32 + i * 8 + drow;      // row inside the A tile
+          int gm = m0 + r;
+          gm = gm < M ? gm : M - 1;                  // ragged tiles re-read the last row; stores are guarded
+          pa[u][i] = X + (int64_t)gm * ldx + kbase + (dslot ^ ((r >> 1) & 7)) * 4;  // source-side swizzle
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (TB) {
+          const int kr = vw * 4 + i * 2 + (lane >> 5);
+          int col = n0 + (lane & 31) * 4;
+          col = col + 4 <= N ? col : (N >= 4 ? ((N - 4) & ~3) : 0);
+          pb[u][i] = W + (kbase + kr) * ldw + col;
+        } else {
+          const int r = vw * 16 + i * 8 + drow;      // row inside the B tile
+          int gn = n0 + r;
+          gn = gn < N ? gn : N - 1;
+          pb[u][i] = W + (int64_t)gn * ldw + kbase + (dslot ^ ((r >> 1) & 7)) * 4;
+        }
       }
     }
   };
   // One k-step's DMA = 6 instructions per wave, issued in three parts (A 0-1, A 2-3, B) so they can be spread
   // between the MFMA chunks of the previous step instead of queueing at the TA all at once.
-  auto issue_dma_part = [&](int part, int kt, int stage) {
-    float* sa = smem + stage * STAGE_FLOATS + (TA ? (wave * 4) * BM : (wave * 32) * BK);
-    float* sb = smem + stage * STAGE_FLOATS + BM * BK + (TB ? (wave * 4) * BN : (wave * 16) * BK);
+  auto issue_dma_part = [&](int part, int kt, int stage, int u = 0) {
+    const int vw = vw0 + u;
+    float* sa = smem + stage * STAGE_FLOATS + (TA ? (vw * 4) * BM : (vw * 32) * BK);
+    float* sb = smem + stage * STAGE_FLOATS + BM * BK + (TB ? (vw * 4) * BN : (vw * 16) * BK);
     if (part < 2) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int q = 2 * part + i;
-        const float* src = TA ? pa[q] + kt * a_kstep : pa[q] + kt * BK;
+        const float* src = TA ? pa[u][q] + kt * a_kstep : pa[u][q] + kt * BK;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(sa + q * (TA ? BM : 8 * BK)), 16, 0, 0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
       {
-        const float* src = TB ? pb[i] + kt * b_kstep : pb[i] + kt * BK;
+        const float* src = TB ? pb[u][i] + kt * b_kstep : pb[u][i] + kt * BK;
         __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(sb + i * (TB ? 2 * BN : 8 * BK)), 16, 0, 0);
       }
     }
@@ -255,7 +285,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   // would make hipcc drain the DMA in flight with a vmcnt(0) at its first use.)
   float* bias_lds = smem + NSTAGE * STAGE_FLOATS;
   auto dma_bias = [&](int it) {
-    if (bias && wave == 0) {
+    if (bias && wave == (WS ? GEMM_WAVES : 0)) {
       int m0, n0, split;
       tile_origin(it, m0, n0, split);
       float* dst = bias_lds + (it & 1) * BN;
@@ -267,35 +297,88 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
       }
     }
   };
-  auto read_bias = [&](int it, float& b0, float& b1) {
-    if (bias) {
-      const float* src = bias_lds + (it & 1) * BN + wn * 64 + lr;
-      b0 = src[0];
-      b1 = src[32];
+  if (WS && wave >= GEMM_WAVES) {
+    // ---- loader waves: the whole DMA stream of the workgroup, two k-steps ahead of the MFMA waves, same barriers
+    int l_it = 0, l_kt = SK ? sk_kt0 : 0, l_stage = 0;
+    bool l_fresh = true;  // row pointers not yet set for the tile the stream is in (first step, possibly mid-tile)
+    auto l_step = [&]() {
+      if ((STLT_GEMM_ABLATE & 32) ? l_fresh : (l_kt == 0 || l_fresh)) { dma_set_tile(l_it); l_fresh = false; }
+      const int src_kt = (STLT_GEMM_ABLATE & 32) ? 0 : l_kt;
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        issue_dma_part(0, src_kt, l_stage, u);
+        issue_dma_part(1, src_kt, l_stage, u);
+        issue_dma_part(2, src_kt, l_stage, u);
+      }
+      if (++l_kt == nk) { l_kt = 0; ++l_it; }
+      if (++l_stage == NSTAGE) l_stage = 0;
+    };
+    dma_bias(0);
+    l_step();
+    if (total_steps > 1) {
+      l_step();
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // in-order counter: step 0 (and the bias strip before it) landed
     } else {
-      b0 = 0.f;
-      b1 = 0.f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int w_it = 0, w_kt = SK ? sk_kt0 : 0;  // position of the MFMA waves (the bias strip follows their tile changes)
+    for (int step = 0; step < total_steps; ++step) {
+      if (w_kt == nk - 1 && w_it + 1 < my_tiles) dma_bias(w_it + 1);
+      if (!(STLT_GEMM_ABLATE & 1) && step + 2 < total_steps) {
+        l_step();
+        if (!(STLT_GEMM_ABLATE & 8)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // step+1 landed; only step+2's 12 instructions may stay in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (++w_kt == nk) { w_kt = 0; ++w_it; }
+    }
+    return;
+  }
+  if (!WS) dma_bias(0);
+  f32x16 acc[2][2];
+  // accumulator (a, b), register r of lane (lr, lh) holds output element
+  //   row  = wm*64 + a*32 + lr                  (TA: wm*64 + 2*lr + a, the row-interleaved tiles of the ds_read_b64 fragments)
+  //   col  = wn*64 + b*32 + i(r),  i(r) = (r&3) + 8*(r>>2) + 4*lh   (TB: wn*64 + 2*i(r) + b)
+  // Initial value = the tile's bias (forward layout only): registers 4q..4q+3 are columns 8q+4lh .. +3 of the strip.
+  auto init_acc = [&](int it, bool zero) {
+    if (bias && !TB && !zero) {
+      const float* src = bias_lds + (it & 1) * BN + wn * 64 + 4 * lh;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + b * 32 + 8 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[0][b][4 * q + j] = v[j]; acc[1][b][4 * q + j] = v[j]; }
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     }
   };
-  float bn0 = 0.f, bn1 = 0.f;
-  dma_bias(0);
-  f32x16 acc[2][2];
 
   auto mfma_chunk = [&](const Frags& f) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], f.b0[e], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[e], f.b1[e], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], f.b0[e], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[e], f.b1[e], acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[e], f.a0[e], acc[0][0], 0, 0, 0);  // (W frag, X frag): D[n][m]
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[e], f.a0[e], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[e], f.a1[e], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[e], f.a1[e], acc[1][1], 0, 0, 0);
     }
   };
 
   // ---- prologue: two steps in flight ------------------------------------------------------------------
   int d_it = 0, d_kt = SK ? sk_kt0 : 0;  // DMA stream position (runs two steps ahead of the MFMAs)
   int d_stage = 0;
-  if (SK && sk_kt0 != 0) dma_set_tile(0);  // a range that begins inside a tile
+  if (!WS && SK && sk_kt0 != 0) dma_set_tile(0);  // a range that begins inside a tile
   auto dma_part = [&](int part) {  // part 0 also moves to the next tile's row pointers when needed
+    if (WS) return;                // the loader waves own the DMA stream
     if (part == 0 && d_kt == 0) dma_set_tile(d_it);
     issue_dma_part(part, d_kt, d_stage);
     if (part == 2) {
@@ -304,19 +387,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     }
   };
   dma_part(0); dma_part(1); dma_part(2);
-  if (total_steps > 1) {
+  if (WS) {
+    // nothing of this wave's is in flight: the loaders' counted wait + this barrier publish step 0
+  } else if (total_steps > 1) {
     dma_part(0); dma_part(1); dma_part(2);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // in-order counter: step 0 (and the bias strip before it) landed
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  read_bias(0, bn0, bn1);
-  if (SK && !seg_complete(0)) { bn0 = 0.f; bn1 = 0.f; }
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[a][0][r] = bn0; acc[a][1][r] = bn1; }
+  init_acc(0, SK && !seg_complete(0));
   Frags fa = read_frags(0, 0), fb;  // ping-pong fragment registers: 4 chunk reads per step, so fa is "current" at every step start
 
   int c_it = 0, c_kt = SK ? sk_kt0 : 0;  // MFMA stream position
@@ -328,9 +408,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
   for (int step = 0; step < total_steps; ++step) {
     if (prio == 2) { if (wave < 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     const int next_stage = stage + 1 == NSTAGE ? 0 : stage + 1;
-    const bool prefetch = step + 2 < total_steps;  // step+2's operands go to the stage retired by the previous barrier
+    const bool prefetch = (STLT_GEMM_ABLATE & 1) ? false : step + 2 < total_steps;  // step+2's operands go to the stage retired by the previous barrier
     const bool bias_step = c_kt == nk - 1 && c_it + 1 < my_tiles;
-    if (bias_step) dma_bias(c_it + 1);  // older than this step's operand DMA: covered by the counted wait below
+    if (!WS && bias_step) dma_bias(c_it + 1);  // older than this step's operand DMA: covered by the counted wait below
     // chunks 0..2: read the next chunk of this stage, 16 MFMAs on the current one, a third of step+2's DMA
     fb = read_frags(stage, 1);
     mfma_chunk(fa);
@@ -347,15 +427,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
     // chunk 3: retire this stage.  Every wave has received all its reads of `stage`, and step+1's DMA has
     // landed.  The VMEM counter is in order: the only operations younger than step+1's DMA that may stay in
     // flight are the 6 DMAs of step+2 (the bias strip and a previous epilogue's stores are older than those).
-    if (prefetch) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    if (WS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own fragment reads only; a previous epilogue's stores may stay in flight
+    else if (prefetch) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     GSTAMP(1);  // wait for own DMA + LDS reads
     __builtin_amdgcn_s_barrier();
     GSTAMP(2);  // barrier
-    if (bias_step) {
-      read_bias(c_it + 1, bn0, bn1);
-      if (SK && !seg_complete(c_it + 1)) { bn0 = 0.f; bn1 = 0.f; }
-    }
     GSTAMP(3);
     if (step + 1 < total_steps) fa = read_frags(next_stage, 0);
     mfma_chunk(fb);
@@ -365,68 +442,76 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const float* _
 
     if (++c_kt == nk || (SK && step == total_steps - 1)) {
       // ---- epilogue of tile c_it (the next tile's first fragments are already in registers, its next two
-      // k-steps are in flight).  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+      // k-steps are in flight; the barrier of this last k-step published the next tile's bias strip).
       int m0, n0, split;
       tile_origin(c_it, m0, n0, split);
-      const bool interior = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
       float* Yt = Y + (int64_t)split * slab_stride;
       const bool partial = SK && !seg_complete(c_it);
-      // tile-local coordinates of accumulator (a, b, r): contraction-major operands interleave the two MFMA tiles
-      auto t_row = [&](int a, int r) { const int i = (r & 3) + 8 * (r >> 2) + 4 * lh; return TA ? wm * 64 + 2 * i + a : wm * 64 + a * 32 + i; };
-      auto t_col = [&](int b) { return TB ? wn * 64 + 2 * lr + b : wn * 64 + b * 32 + lr; };
+      // 16-byte stores need 16-byte aligned rows (wave-uniform test); otherwise, and on ragged tiles, guarded scalars
+      const bool vec_ok = (m0 + BM <= M) && (n0 + BN <= N) && (ldy & 3) == 0 && ((uintptr_t)Yt & 15) == 0 &&
+                          (!ADD || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0));
+      auto t_row = [&](int a) { return TA ? wm * 64 + 2 * lr + a : wm * 64 + a * 32 + lr; };
+      // group g = 0..7 of an M tile a: 4 consecutive columns starting at t_col4(g), held in regs() of acc[a][*]
+      //   !TB: g = 4*b + q        -> columns wn*64 + b*32 + 8q + 4lh + j      = acc[a][b][4q + j]
+      //    TB: g = 2*q + half     -> columns wn*64 + 16q + 8lh + 4half + j    = acc[a][j&1][4q + 2half + (j>>1)]
+      auto t_col4 = [&](int g) { return TB ? wn * 64 + 16 * (g >> 1) + 8 * lh + 4 * (g & 1) : wn * 64 + (g >> 2) * 32 + 8 * (g & 3) + 4 * lh; };
+      auto group = [&](int a, int g) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = TB ? acc[a][j & 1][4 * (g >> 1) + 2 * (g & 1) + (j >> 1)] : acc[a][g >> 2][4 * (g & 3) + j];
+        return v;
+      };
       if (partial) {  // raw accumulators into this workgroup's head / tail slot (a whole BMxBN image, no guards)
         float* P = partials + (size_t)(2 * v + (c_it == 0 ? 0 : 1)) * (BM * BN);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
+          for (int g = 0; g < 8; ++g) *reinterpret_cast<f32x4*>(P + t_row(a) * BN + t_col4(g)) = group(a, g);
+      } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) P[t_row(a, r) * BN + t_col(b)] = acc[a][b][r];
-          }
-      }
+        for (int a = 0; a < 2; ++a) {
+          const int m = m0 + t_row(a);
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+          for (int g = 0; g < 8; ++g) {
+            const int n = n0 + t_col4(g);
+            f32x4 val = group(a, g);
+            float* yp = Yt + (int64_t)m * ldy + n;
+            const float* rp = ADD ? R + (int64_t)m * ldr + n : nullptr;  // add-source (residual gradient)
+            if (vec_ok) {
+              if (ADD) val += *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (partial) {
+              for (int j = 0; j < 4; ++j) {
+                if (ACT == STLT_ACT_GELU) val[j] = gelu_epilogue(val[j]);
+                if (ACT == STLT_ACT_RELU) val[j] = fmaxf(val[j], 0.f);
+              }
+              if (STLT_GEMM_ABLATE & 16) asm volatile("" :: "v"(val)); else
+              *reinterpret_cast<f32x4*>(yp) = val;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = b == 0 ? bn0 : bn1;
-            continue;
-          }
-          const int n = n0 + t_col(b);
-          const int mb = m0 + t_row(a, 0);               // row of r = 0; rows advance by rstep * ((r&3) + 8*(r>>2))
-          constexpr int rstep = TA ? 2 : 1;
-          float* yp = Yt + (int64_t)mb * ldy + n;
-          const float* rp = ADD ? R + (int64_t)mb * ldr + n : nullptr;  // add-source (residual gradient)
-          if (interior) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float val = acc[a][b][r];
-              if (ADD) val += rp[(int64_t)(rstep * ((r & 3) + 8 * (r >> 2))) * ldr];
-              if (ACT == STLT_ACT_GELU) val = gelu_epilogue(val);
-              if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
-              yp[(int64_t)(rstep * ((r & 3) + 8 * (r >> 2))) * ldy] = val;
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = rstep * ((r & 3) + 8 * (r >> 2));
-              float val = acc[a][b][r];
-              if (ACT == STLT_ACT_GELU) val = gelu_epilogue(val);
-              if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
-              if (n < N && mb + row < M) yp[(int64_t)row * ldy] = ADD ? val + rp[(int64_t)row * ldr] : val;
+              for (int j = 0; j < 4; ++j) {
+                float x = val[j];
+                if (m < M && n + j < N) {
+                  if (ADD) x += rp[j];
+                  if (ACT == STLT_ACT_GELU) x = gelu_epilogue(x);
+                  if (ACT == STLT_ACT_RELU) x = fmaxf(x, 0.f);
+                  yp[j] = x;
+                }
+              }
             }
           }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = b == 0 ? bn0 : bn1;
         }
       }
+      if (c_it + 1 < my_tiles) init_acc(c_it + 1, SK && !seg_complete(c_it + 1));
       c_kt = 0;
       ++c_it;
       GSTAMP(5);  // epilogue
     }
   }
-  if (dbg && tid == 0) dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  if (dbg && tid == 0) {
+    dbg[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    dbg[4 * (size_t)gridDim.x + (size_t)gridDim.x * GEMM_WAVES * 6 + 1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+  }
   if (STAMP && dbg && lane == 0) {
     unsigned long long* o = dbg + 4 * (size_t)gridDim.x + ((size_t)blockIdx.x * GEMM_WAVES + wave) * 6;
     for (int k = 0; k < 6; ++k) o[k] = t_acc[k];
@@ -566,7 +651,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
       const int S = (int)((n_tiles * nk + G - 1) / G);
       dim3 grid((unsigned)G);
       float* P = t_gemm_scratch;
-#define LAUNCH_SK(ACTV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr)
+#define LAUNCH_SK(ACTV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, false>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr)
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
       else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
       else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
@@ -585,7 +670,11 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
     }
   }
   dim3 grid((unsigned)n_wg);
-#define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf)
+  // wave-specialised build (4 DMA-only waves beside the 8 MFMA waves) unless STLT_GEMM_WS=0 (A/B measurements)
+  static const bool ws = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
+  const dim3 block_ws(GEMM_THREADS_WS);
+#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf)
+#define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws && !STAMPV) LAUNCH1(ACTV, false, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
   else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
@@ -594,6 +683,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   else if (act == STLT_ACT_RELU) LAUNCH(STLT_ACT_RELU, false, false, false, false);
   else LAUNCH(STLT_ACT_NONE, false, false, false, false);
 #undef LAUNCH
+#undef LAUNCH1
   return stlt_check_launch("gemm_nt_kernel");
 }
 

@@ -377,6 +377,8 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // contract over the row count rounded up to 32, so the gradient-side operands' rows between the count and its
   // round-up are zeroed here (the padded schedule never dirties them; a ragged row count changes every step).
   const bool ragged = (flags & STLT_FLAG_SKIP_PADDING) != 0;
+  const bool do_upper = !(flags & STLT_FLAG_TRAIN_LOWER_ONLY), do_lower = !(flags & STLT_FLAG_TRAIN_UPPER_ONLY);
+  if (!do_upper && !do_lower) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: UPPER_ONLY and LOWER_ONLY exclude each other");
   const RaggedIndex ix = ragged_index_carve(t.ridx, B, T, N);  // filled by the forward (ragged index, or the padded layout's picked rows)
   AttnBwdRagged rg_sp{}, rg_tp{};
   if (ragged) {
@@ -388,16 +390,21 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     TRY(launch_ragged_groups(ix, tok, BT, fpg, s));
     rg_sp = AttnBwdRagged{ix.sp_grp_ptr, ix.t_seg_start, ix.t_seg_end, (BT + fpg - 1) / fpg, tok, (int)(fpg * N)};
     rg_tp = AttnBwdRagged{ix.clip_frm_off, ix.f_seg_start, ix.f_seg_end, B, BT, (int)T};
+  }
+  // Both schedules: the caller may hand in scratch that an earlier step with another (B,T,N) left dirty (two shapes
+  // can round to the same byte count), so the rows the weight-gradient products read beyond the row count are
+  // cleared every step: at most 31 rows per buffer.
+  if (do_lower) {
     for (float* b : {sc.sB, sc.sD}) TRY(zero_rows(b, d, tok, tokp, s));
     TRY(zero_rows(sc.sQKV, 3 * d, tok, tokp, s));
     TRY(zero_rows(sc.sH, 4 * d, tok, tokp, s));
+  }
+  if (do_upper) {
     for (float* b : {sc.tB, sc.tD}) TRY(zero_rows(b, d, BT, btp, s));
     TRY(zero_rows(sc.tQKV, 3 * d, BT, btp, s));
     TRY(zero_rows(sc.tH, 4 * d, BT, btp, s));
   }
   const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = p->n_temporal > 0 && 2 * B <= BT;  // as the forward decided
-  const bool do_upper = !(flags & STLT_FLAG_TRAIN_LOWER_ONLY), do_lower = !(flags & STLT_FLAG_TRAIN_UPPER_ONLY);
-  if (!do_upper && !do_lower) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: UPPER_ONLY and LOWER_ONLY exclude each other");
   if (do_upper) {
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2

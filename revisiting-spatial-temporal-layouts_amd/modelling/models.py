@@ -259,8 +259,9 @@ class StltBackbone(nn.Module):
         return self._cache[1]
 
     def _train_buf(self, name: str, nbytes: int, device) -> torch.Tensor:
-        """Zero-filled tape / scratch of the training step, allocated once per shape (the library relies on the row
-        padding staying zero and never writes it)."""
+        """Tape / scratch of the training step, allocated zero-filled and reused while the byte size matches.  Two batch
+        shapes can round to the same size with different row layouts; the library does not rely on what an earlier step
+        left behind: every step it clears the rows its weight-gradient products read beyond the row count (train.hip)."""
         bufs = self.__dict__.setdefault("_train_bufs", {})
         cur = bufs.get(name)
         if cur is None or cur.device != device or cur.numel() != nbytes:
@@ -411,6 +412,9 @@ class _StltTrainFn(torch.autograd.Function):
         d, K = cfg.hidden_size, model.prediction_head.fc2.weight.shape[0]
         n_sp, n_tp = p.n_spatial, p.n_temporal
         tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, n_sp, n_tp)), device)
+        # one tape per backbone: a second grad-enabled forward overwrites it, so every forward takes a new generation
+        # number and the backward refuses to run on a tape that is no longer its own
+        bb._tape_gen = ctx.tape_gen = getattr(bb, "_tape_gen", 0) + 1
         logits = torch.empty(B, K, device=device, dtype=torch.float32)
         # train-mode dropout (reference default hidden_dropout_prob = 0.1): counter-based masks from one seed per
         # forward, drawn from torch's CPU generator (so torch.manual_seed makes runs repeatable)
@@ -431,6 +435,10 @@ class _StltTrainFn(torch.autograd.Function):
         bb = model.backbone
         B, T, N, d = ctx.shape
         device = dlogits.device
+        if getattr(bb, "_tape_gen", 0) != ctx.tape_gen:
+            raise L.StltHipError("Stlt backward: the activation tape was overwritten by a later grad-enabled forward of the same "
+                                 "model (one tape per backbone): run each forward's backward before the next forward, or wrap "
+                                 "forwards that need no gradient in torch.no_grad()")
         inp, keep, _ = _prep_inputs(batch, need_lengths=True)
         p, _, _ = bb.c_params(model.prediction_head)
         used = model._grad_params("scores" in batch)

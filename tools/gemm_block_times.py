@@ -11,7 +11,7 @@ if len(sys.argv) > 3: M, N, K = map(int, sys.argv[1:4])
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
 y = torch.empty(M, N, device="cuda")
 for _ in range(2): pkg.ops.linear(x, w, b, out=y)
-buf = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
+buf = torch.zeros(4 * 4096 + 8192, dtype=torch.int64, device="cuda")
 lib.stlt_debug_set_buffer(buf.data_ptr())
 pkg.ops.linear(x, w, b, out=y); torch.cuda.synchronize()
 lib.stlt_debug_set_buffer(None)
@@ -21,6 +21,10 @@ t = buf[: 4 * G].view(G, 4).cpu()
 t0 = t[:, 0].min()
 st = (t[:, 0] - t0).double() / 100.0  # us
 en = (t[:, 1] - t0).double() / 100.0
+ck = buf[4 * G + G * WAVES * 6 + 1024: 4 * G + G * WAVES * 6 + 1024 + 2 * G].view(G, 2).cpu().double()
+clk = ((ck[:, 1] - ck[:, 0]) / ((t[:, 1] - t[:, 0]).double() / 100.0)).median() / 1e3  # cycles per us -> GHz
+fl = 2.0 * M * N * K
+print(f"in-kernel clock {clk:.3f} GHz ; kernel {fl / (en.max() * 1e-6) / 1e12:.1f} TFLOP/s by its own span = {fl / (en.max() * 1e-6) / 1e12 / (clk / 2.4 * 157.3):.3f} of the MFMA rate at that clock")
 print(f"workgroups={len(t)} tiles/wg min {t[:,3].min()} max {t[:,3].max()}  kernel span {en.max():.1f} us")
 print(f"start: max {st.max():.1f} us ; end: min {en.min():.1f} median {en.median():.1f} max {en.max():.1f} us ; mean idle tail {(en.max()-en).mean():.1f} us")
 for xcc in sorted(set(t[:, 2].tolist())):
@@ -40,3 +44,16 @@ if os.environ.get("STLT_GEMM_STAMP"):
     print(f"per-wave cycles total median {tot.median():.0f}; per k-step:")
     for k, n in enumerate(names):
         print(f"   {n:22s} share {ph[:, k].sum() / tot.sum():.3f}   per-step median {(ph[:, k] / steps).median():8.1f} cycles")
+    print("per wave index (median over workgroups, cycles per k-step):")
+    pw = ph.view(G, WAVES, 6) / steps
+    for wv in range(WAVES):
+        print(f"   wave {wv}: " + "  ".join(f"{names[k].split()[0]} {pw[:, wv, k].median():7.1f}" for k in range(6)) + f"  total {pw[:, wv].sum(1).median():8.1f}")
+    TR_STEPS, TR_PTS = 6, 12
+    tr = buf[4 * G + G * WAVES * 6: 4 * G + G * WAVES * 6 + WAVES * TR_STEPS * TR_PTS].view(WAVES, TR_STEPS, TR_PTS).cpu()
+    if int(tr.max()) > 0:
+        pts = ["top", "c0 done", "dma0", "c1 done", "dma1", "c2 done", "dma2", "waited", "barrier", "c3 done"]
+        t0 = int(tr[:, 0, 0].min())
+        print("timeline of workgroup 0 (cycles since the first wave entered k-step 30); one row per wave and k-step:")
+        for st in range(TR_STEPS):
+            for wv in range(WAVES):
+                print(f"  step {30 + st} wave {wv}: " + " ".join(f"{pts[k]}={int(tr[wv, st, k]) - t0:6d}" for k in range(len(pts))))
