@@ -314,6 +314,21 @@ int stlt_grad_norm(const float* flat_grad, int64_t n, float max_norm, float* scr
 int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const float* flat_grad, float* exp_avg, float* exp_avg_sq,
                     const float* norm_and_clip, float lr, float beta1, float beta2, float eps, int64_t step, stlt_stream_t stream);
 
+/* ---- evaluators on the device (reference src/utils/evaluation.py) ----
+ * stlt_eval_topk: EvaluatorSomething.process (evaluation.py:21-34) for one logit head.  counts[0] += clips whose label is
+ * the arg-max, counts[1] += clips whose label is among the five largest logits (int64 device counters, accumulated with
+ * integer atomics).  The label's rank is the number of classes with a larger logit, or an equal logit at a lower index.
+ * stlt_eval_average_precision: map() + the empty-clip rule of charades_map (evaluation.py:100-131).  scores / truths are
+ * (n, C) row-major float (scores = sigmoid of the logits, truths multi-hot); ap[c] = average precision of class c (NaN
+ * when the class has no positive), positives[c] = its number of positives; scratch >= n bytes.  n <= stlt_eval_max_clips()
+ * (a class column is sorted inside one workgroup's LDS).  Equal scores keep clip order (the reference's argsort leaves
+ * ties unspecified). */
+int stlt_eval_topk(const float* logits, int64_t ld, const int64_t* labels, int64_t B, int64_t K, int64_t* counts,
+                   stlt_stream_t stream);
+int64_t stlt_eval_max_clips(void);
+int stlt_eval_average_precision(const float* scores, const float* truths, int64_t n, int64_t C, double* ap, double* positives,
+                                uint8_t* scratch, stlt_stream_t stream);
+
 /* ---- per-kernel timing (bench.py roofline leg): hipEvents around every launch of the whole-path calls ---- */
 #define STLT_K_EMBED 0
 #define STLT_K_GEMM 1

@@ -123,6 +123,9 @@ SIGNATURES = {
     "stlt_gelu_fwd": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "stlt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
+    "stlt_eval_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp]),
+    "stlt_eval_max_clips": (C.c_int64, []),
+    "stlt_eval_average_precision": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp]),
     "stlt_grad_norm": (C.c_int, [_vp, C.c_int64, C.c_float, _vp, _vp, _vp]),
     "stlt_adamw_step": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
     "stlt_prof_enable": (C.c_int, [C.c_int]),

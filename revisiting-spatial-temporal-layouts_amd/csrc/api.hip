@@ -11,20 +11,40 @@
 namespace {
 thread_local char g_err[512] = "";
 
+// Per-kernel timing: the switch is process-wide, the records and the event pool are per device (an event belongs to the
+// device it was created on), and a launch's two events are recorded on the launch's own stream.
 struct ProfRec { int kid; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
-std::vector<ProfRec> g_prof_recs;
-std::vector<hipEvent_t> g_event_pool;
+std::vector<ProfRec> g_prof_recs[STLT_MAX_DEVICES];
+std::vector<hipEvent_t> g_event_pool[STLT_MAX_DEVICES];
 thread_local hipEvent_t g_open_start = nullptr;
 
-hipEvent_t get_event() {
-  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+hipEvent_t get_event(int dev) {
+  auto& pool = g_event_pool[dev];
+  if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
   (void)hipEventCreate(&e);
   return e;
 }
+StltPerDeviceInt g_cus;
 }  // namespace
+
+int stlt_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev;
+}
+
+int stlt_device_cus() {
+  int& n = g_cus.ref();
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, stlt_current_device()) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
 
 int stlt_set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -43,16 +63,17 @@ int stlt_check_launch(const char* what) {
 void stlt_prof_begin(int kid, hipStream_t s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_open_start = get_event();
+  g_open_start = get_event(stlt_current_device() & (STLT_MAX_DEVICES - 1));
   (void)hipEventRecord(g_open_start, s);
 }
 
 void stlt_prof_end(int kid, hipStream_t s) {
   if (!g_prof_on || !g_open_start) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  hipEvent_t b = get_event();
+  const int dev = stlt_current_device() & (STLT_MAX_DEVICES - 1);
+  hipEvent_t b = get_event(dev);
   (void)hipEventRecord(b, s);
-  g_prof_recs.push_back({kid, g_open_start, b});
+  g_prof_recs[dev].push_back({kid, g_open_start, b});
   g_open_start = nullptr;
 }
 
@@ -74,16 +95,17 @@ int stlt_prof_enable(int on) {
 int stlt_prof_collect(double* ms_out, int64_t* launches_out) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int k = 0; k < STLT_K_COUNT; ++k) { if (ms_out) ms_out[k] = 0.0; if (launches_out) launches_out[k] = 0; }
-  for (auto& r : g_prof_recs) {
+  const int dev = stlt_current_device() & (STLT_MAX_DEVICES - 1);  // the records of the device that is current
+  for (auto& r : g_prof_recs[dev]) {
     hipError_t e = hipEventSynchronize(r.b);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
     if (e != hipSuccess) return stlt_set_error((int)e, "stlt_prof_collect: %s", hipGetErrorString(e));
     if (r.kid >= 0 && r.kid < STLT_K_COUNT) { if (ms_out) ms_out[r.kid] += ms; if (launches_out) launches_out[r.kid] += 1; }
-    g_event_pool.push_back(r.a);
-    g_event_pool.push_back(r.b);
+    g_event_pool[dev].push_back(r.a);
+    g_event_pool[dev].push_back(r.b);
   }
-  g_prof_recs.clear();
+  g_prof_recs[dev].clear();
   return 0;
 }
 

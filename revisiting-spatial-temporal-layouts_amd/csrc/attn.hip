@@ -129,14 +129,17 @@ inline int attn_reverse_order() {
   return rev;
 }
 
-template <bool STAMP, bool VARLEN>
+// CAUSAL is also the kernel's name tag: the temporal pass (causal + key padding) and the spatial pass (key padding only)
+// are distinct symbols, so a kernel trace reports each one's launches and durations on its own.
+template <bool STAMP, bool VARLEN, bool CAUSAL>
 __global__ __launch_bounds__(64 * WAVES, 2) void attn_core_kernel(const AttnGeo geo,
                                                                   const uint8_t* __restrict__ kpm,
                                                                   int64_t n_items, float scale,
                                                                   float* __restrict__ ctx,
                                                                   unsigned long long* __restrict__ stamps, StltDrop dr,
                                                                   uint32_t site) {
-  const int H = geo.H, causal = geo.causal;
+  const int H = geo.H;
+  constexpr int causal = CAUSAL ? 1 : 0;
   const float* __restrict__ gq = geo.q;
   const float* __restrict__ gk = geo.k;
   const float* __restrict__ gv = geo.v;
@@ -359,24 +362,26 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
   g.reverse = attn_reverse_order();
   // persistent waves: as many workgroups as are resident at once (occupancy API x CU count), each wave strides
   // over the items; there is no inter-workgroup dependency, so a wrong residency guess only costs speed
-  static int n_cu = 0, wg_per_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false, false>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
+  const int n_cu = stlt_device_cus();
+  static StltPerDeviceInt occ;  // resident workgroups per CU, per device (the spatial and temporal instantiations use the same resources)
+  int& wg_per_cu = occ.ref();
+  if (wg_per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false, false, false>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
       wg_per_cu = 1;
-    if (getenv("STLT_DEBUG")) fprintf(stderr, "[stlt] attn: %d CUs, %d workgroups/CU of %d waves\n", n_cu, wg_per_cu, WAVES);
+    if (getenv("STLT_DEBUG")) fprintf(stderr, "[stlt] attn: device %d: %d CUs, %d workgroups/CU of %d waves\n", stlt_current_device(), n_cu, wg_per_cu, WAVES);
   }
   int64_t n_wg = (n_items + WAVES - 1) / WAVES;
   if (n_wg > (int64_t)wg_per_cu * n_cu) n_wg = (int64_t)wg_per_cu * n_cu;
   dim3 grid((unsigned)n_wg);
   const float scale = 1.0f / sqrtf((float)dh);
-  if (g_stlt_debug_buf && !getenv("STLT_GEMM_STAMP"))  // diagnostic build path only (tools/attn_stamps.py); never set by the product
-    hipLaunchKernelGGL((attn_core_kernel<true, false>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, g_stlt_debug_buf, dr, site);
-  else
-    hipLaunchKernelGGL((attn_core_kernel<false, false>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, (unsigned long long*)nullptr, dr, site);
+  if (g_stlt_debug_buf && !getenv("STLT_GEMM_STAMP")) {  // diagnostic build path only (tools/attn_stamps.py); never set by the product
+    if (causal) hipLaunchKernelGGL((attn_core_kernel<true, false, true>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, g_stlt_debug_buf, dr, site);
+    else hipLaunchKernelGGL((attn_core_kernel<true, false, false>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, g_stlt_debug_buf, dr, site);
+  } else if (causal) {
+    hipLaunchKernelGGL((attn_core_kernel<false, false, true>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, (unsigned long long*)nullptr, dr, site);
+  } else {
+    hipLaunchKernelGGL((attn_core_kernel<false, false, false>), grid, dim3(64 * WAVES), 0, s, g, kpm, n_items, scale, ctx, (unsigned long long*)nullptr, dr, site);
+  }
   return stlt_check_launch("attn_core_kernel");
 }
 
@@ -407,18 +412,20 @@ int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_en
   g.n_items = n_items;
   g.reverse = attn_reverse_order();
   StltProfScope ps(kid, s);
-  static int n_cu = 0, wg_per_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false, true>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
+  const int n_cu = stlt_device_cus();
+  static StltPerDeviceInt occ;
+  int& wg_per_cu = occ.ref();
+  if (wg_per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn_core_kernel<false, true, false>, 64 * WAVES, 0) != hipSuccess || wg_per_cu <= 0)
       wg_per_cu = 1;
   }
   int64_t n_wg = (n_items + WAVES - 1) / WAVES;
   if (n_wg > (int64_t)wg_per_cu * n_cu) n_wg = (int64_t)wg_per_cu * n_cu;
-  hipLaunchKernelGGL((attn_core_kernel<false, true>), dim3((unsigned)n_wg), dim3(64 * WAVES), 0, s, g, (const uint8_t*)nullptr, n_items,
-                     1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, dr, site);
+  if (causal)
+    hipLaunchKernelGGL((attn_core_kernel<false, true, true>), dim3((unsigned)n_wg), dim3(64 * WAVES), 0, s, g, (const uint8_t*)nullptr, n_items,
+                       1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, dr, site);
+  else
+    hipLaunchKernelGGL((attn_core_kernel<false, true, false>), dim3((unsigned)n_wg), dim3(64 * WAVES), 0, s, g, (const uint8_t*)nullptr, n_items,
+                       1.0f / sqrtf((float)dh), ctx, (unsigned long long*)nullptr, dr, site);
   return stlt_check_launch("attn_core_kernel(ragged)");
 }

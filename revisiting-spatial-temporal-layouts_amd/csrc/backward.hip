@@ -683,7 +683,8 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
     if (n_seq == 0) return 0;
     if (n_seq * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "attn_bwd: too many sequences");
     const size_t lds_long = ((size_t)4 * 32 * AB_LD + (size_t)2 * 32 * (L + 1)) * sizeof(float);
-    static bool long_opt_in = false;
+    static StltPerDeviceOnce long_once;  // a function attribute is set per device
+    bool& long_opt_in = long_once.flag();
     if (!long_opt_in) {
       if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
         return stlt_set_error((int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -706,7 +707,8 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
   if (g_colsum && !scratch) return stlt_set_error(STLT_EINVAL, "attn_bwd: column sums need scratch");
   int64_t chunks = groups < 256 ? groups : 256;  // persistent blocks per head (scratch >= 256 * 3 * H * dh floats)
   const size_t lds = ((size_t)4 * GL * AB_LD + (size_t)2 * GL * (L + 1) + 3 * GL) * sizeof(float);
-  static bool lds_opt_in = false;  // > 64 KB of dynamic LDS (one 64-token sequence: 100 KB) needs the attribute
+  static StltPerDeviceOnce lds_once;  // > 64 KB of dynamic LDS (one 64-token sequence: 100 KB) needs the attribute, per device
+  bool& lds_opt_in = lds_once.flag();
   if (!lds_opt_in) {
     if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
       return stlt_set_error((int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));

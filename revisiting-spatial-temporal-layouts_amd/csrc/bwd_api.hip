@@ -151,7 +151,8 @@ int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, i
   if (S == 0) return 0;
   if (S * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: too many sequences");
   const size_t lds = ((size_t)2 * Lq * XB_LD + (size_t)2 * Lk * XB_LD + (size_t)2 * Lq * (Lk + 1)) * sizeof(float);
-  static bool opt_in = false;
+  static StltPerDeviceOnce once;  // a function attribute is set per device
+  bool& opt_in = once.flag();
   if (!opt_in) {
     if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
       return stlt_set_error((int)e, "stlt_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -14,6 +14,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 int stlt_set_error(int code, const char* fmt, ...);
 int stlt_check_launch(const char* what);
 
+// Per-device state (api.hip).  Nothing in the library caches a property of "the first device it saw": CU counts,
+// occupancy answers and one-time function attributes are kept per HIP device, looked up by the device that is current
+// when a launcher runs (one process may drive several GPUs).
+constexpr int STLT_MAX_DEVICES = 64;
+int stlt_current_device();           // hipGetDevice; 0 if the query fails
+int stlt_device_cus();               // compute units of the current device (256 if the query fails)
+struct StltPerDeviceOnce {           // "has this one-time step run on the current device yet?"
+  bool done[STLT_MAX_DEVICES] = {};
+  bool& flag() { return done[stlt_current_device() & (STLT_MAX_DEVICES - 1)]; }
+};
+struct StltPerDeviceInt {            // small per-device cache (0 = not yet known)
+  int v[STLT_MAX_DEVICES] = {};
+  int& ref() { return v[stlt_current_device() & (STLT_MAX_DEVICES - 1)]; }
+};
+
 // diagnostics buffer (api.hip: stlt_debug_set_buffer); NULL in normal operation
 extern unsigned long long* g_stlt_debug_buf;
 

@@ -70,7 +70,7 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 #define STLT_GEMM_WS_DEFAULT 1
 #endif
 #ifndef STLT_GELU_BRANCH_FREE
-#define STLT_GELU_BRANCH_FREE 0
+#define STLT_GELU_BRANCH_FREE 1
 #endif
 // GELU of the FFN1 epilogue.  The library erff takes one of two branches per lane (|z| < 1: 8 instructions; else a
 // degree-7 polynomial + exp, ~24), so its cost in a 64-lane wave depends on the data: cheap while every lane of a wave
@@ -111,7 +111,8 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
                                                                   float* __restrict__ partials,
                                                                   unsigned long long* __restrict__ dbg) {
   constexpr int prio = STLT_GEMM_PRIO_MODE;
-  __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + 2 * BN];  // operand stages + 2 bias strips
+  constexpr int NBIAS = 2;  // bias strips, by tile parity
+  __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + NBIAS * BN];  // operand stages + bias strips
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -519,7 +520,6 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
 #undef GSTAMP
 }
 
-int g_n_cu = 0;
 
 constexpr int FIXUP_CHUNKS = 16;
 // Second half of a stream-K launch: FIXUP_CHUNKS workgroups per output tile.  A tile whose k-steps were all computed by one
@@ -606,15 +606,7 @@ __global__ __launch_bounds__(256) void reduce_tall_kernel(const float* __restric
 
 }  // namespace
 
-static int n_cu() {
-  if (g_n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_n_cu = prop.multiProcessorCount;
-    if (g_n_cu <= 0) g_n_cu = 256;
-  }
-  return g_n_cu;
-}
+static int n_cu() { return stlt_device_cus(); }
 
 // C (M,N) = opA(A)·opB(B) [+ bias | + R], contraction length K (multiple of 32).  n_split > 1: C is a slab buffer.
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
@@ -674,7 +666,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   static const bool ws = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
   const dim3 block_ws(GEMM_THREADS_WS);
 #define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf)
-#define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws && !STAMPV) LAUNCH1(ACTV, false, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
+#define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws) LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
   else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");

@@ -93,16 +93,7 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
 
 #define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 
-static int n_cu_cached() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+static int n_cu_cached() { return stlt_device_cus(); }
 
 // g_w (n_out, k_in) += dYᵀ·X with dY (Mp, n_out), X (Mp, k_in).  A weight matrix is only 18-72 output tiles, so the
 // launch runs as stream-K over the token contraction (every CU gets an equal share of k-steps; the fix-up adds the

@@ -105,8 +105,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 old = self.state.get(p, {})
                 st = self.state[p] = {"step": old.get("step", torch.tensor(0.0)),
                                       "exp_avg": self._m[off: off + n].view_as(p), "exp_avg_sq": self._v[off: off + n].view_as(p)}
-                if "exp_avg" in old:  # state loaded from a checkpoint: move it into the flat buffers
-                    st["exp_avg"].copy_(old["exp_avg"]); st["exp_avg_sq"].copy_(old["exp_avg_sq"])
+                if "exp_avg" in old and old["exp_avg"].data_ptr() != st["exp_avg"].data_ptr():  # loaded from a checkpoint / a previous binding: move it into the flat buffers
+                    st["exp_avg"].copy_(old["exp_avg"].to(device)); st["exp_avg_sq"].copy_(old["exp_avg_sq"].to(device))
                 for c0 in range(0, n, self.CHUNK):
                     rows.append((p.data_ptr() + 4 * c0, off + c0, min(self.CHUNK, n - c0), float(g["weight_decay"])))
             arr = np.zeros(len(rows), dtype=np.dtype([("param", "<u8"), ("off", "<i8"), ("n", "<i4"), ("wd", "<f4")]))
@@ -148,6 +148,12 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def step(self, closure=None):
         raise RuntimeError("FusedAdamW consumes the flat gradient buffer of the native backward: call step_flat(flat, layout)")
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces `self.state[p]` with fresh tensors, which no longer alias the flat moment buffers the
+        kernel updates: drop the binding so that the next step_flat() re-binds and copies the loaded moments in."""
+        super().load_state_dict(state_dict)
+        self._layout_key = None
 
 
 class Trainer:
@@ -208,6 +214,10 @@ class Trainer:
             grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_val)
             self.optimizer.step()
         self.scheduler.step()
+        # the two hooks only apply to this trainer's own backward: a later hand-written loop on the same model gets
+        # ordinary per-parameter .grad tensors again
+        self.model._flat_grads_only = False
+        self.model._grad_sync = None
         return {"loss": loss.detach(), "grad_norm": grad_norm.detach()}
 
     def fit(self, batches: Iterable[Dict[str, torch.Tensor]], device) -> List[Dict[str, float]]:

@@ -11,6 +11,11 @@ positive give NaN, and the mean over classes then is NaN exactly as numpy's `np.
 one batched descending sort over the (clips, classes) table plus two cumulative sums, in float64 like the reference.
 Ties: the reference's `np.argsort` is unstable, so its result for tied scores is unspecified; this one is stable.
 
+Device tensors go through hand-written HIP kernels (csrc/evalk.hip, include/stlt_hip.h: `stlt_eval_topk` — one wave
+per clip counts the classes that beat the label, hits accumulate in int64 device counters; `stlt_eval_average_precision`
+— one workgroup per class sorts its column in LDS and sums the precision at every positive in a fixed order).  CPU
+tensors (the not-gpu tests, and a reference-style host loop) take the same arithmetic as torch ops.
+
 Multi-rank: `process()` is fed the rank's shard; `evaluate()` sums the counters / gathers the score tables over the
 default process group when one is initialised.
 """
@@ -44,7 +49,20 @@ class EvaluatorSomething:
         dev = logits[self.logit_names[0]].device
         if self._counts is None:
             self._counts = torch.zeros(len(self.logit_names), 2, dtype=torch.int64, device=dev)
-        labels = labels.to(dev).view(-1, 1)
+        labels = labels.to(dev)
+        if dev.type == "cuda":  # the HIP path: no torch kernels, no synchronisation
+            from .. import _lib as L
+            lib = L.load()
+            y = labels.to(torch.int64).contiguous()
+            with torch.cuda.device(dev):
+                for i, name in enumerate(self.logit_names):
+                    x = logits[name]
+                    if x.dtype != torch.float32 or x.stride(-1) != 1 or x.dim() != 2:
+                        x = x.float().contiguous()
+                    L.check(lib.stlt_eval_topk(x.data_ptr(), x.stride(0), y.data_ptr(), x.shape[0], x.shape[1],
+                                               self._counts[i].data_ptr(), torch.cuda.current_stream().cuda_stream), "stlt_eval_topk")
+            return
+        labels = labels.view(-1, 1)
         for i, name in enumerate(self.logit_names):
             top = logits[name].topk(k=min(5, logits[name].shape[1]), dim=1).indices
             hit = top == labels
@@ -99,8 +117,30 @@ def average_precisions(scores: torch.Tensor, truths: torch.Tensor) -> torch.Tens
     return torch.where(n_pos > 0, ap, torch.full_like(ap, float("nan")))
 
 
+def _average_precisions_hip(scores: torch.Tensor, truths: torch.Tensor) -> torch.Tensor:
+    """`stlt_eval_average_precision` on device tables (the empty-clip rule is applied inside)."""
+    from .. import _lib as L
+    lib = L.load()
+    n, C = scores.shape
+    if n > int(lib.stlt_eval_max_clips()):
+        raise L.StltHipError(f"charades_map: {n} clips exceed the {int(lib.stlt_eval_max_clips())} the device kernel sorts per class")
+    s32 = scores.to(torch.float32).contiguous()  # the scores are fp32 sigmoids widened to float64 (evaluation.py:79-81): exact
+    t32 = truths.to(torch.float32).contiguous()
+    ap = torch.empty(C, dtype=torch.float64, device=scores.device)
+    pos = torch.empty(C, dtype=torch.float64, device=scores.device)
+    scratch = torch.empty(n, dtype=torch.uint8, device=scores.device)
+    with torch.cuda.device(scores.device):
+        L.check(lib.stlt_eval_average_precision(s32.data_ptr(), t32.data_ptr(), n, C, ap.data_ptr(), pos.data_ptr(), scratch.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "stlt_eval_average_precision")
+    return ap, pos
+
+
 def charades_map(scores: torch.Tensor, truths: torch.Tensor):
     """(mAP, weighted AP per class, AP per class) as the reference's `charades_map` (evaluation.py:127-132)."""
+    if scores.is_cuda:
+        aps, pos = _average_precisions_hip(scores, truths)
+        w_ap = aps * pos / pos.sum()  # gt.sum(axis=0) = positives per class (multi-hot truths)
+        return aps.mean(), w_ap, aps
     scores = scores.to(torch.float64).clone()
     truths = truths.to(torch.float64)
     empty = truths.sum(dim=1) == 0

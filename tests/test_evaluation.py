@@ -88,3 +88,47 @@ def test_partial_fill_matches_reference_zero_rows():
     sig = np.zeros((64, 20)); sig[:40] = torch.from_numpy(lg).sigmoid().numpy()
     full = np.zeros((64, 20)); full[:40] = gt
     assert abs(ev.evaluate()["map"] - O.charades_map(sig, full)[0]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_topk_kernel_random_shapes_and_ties_vs_oracle():
+    """stlt_eval_topk against the oracle's count (evaluation.py:21-34), incl. class counts that are not a multiple of the
+    wave width, strided logits, several batches accumulating, and tied logits (the label wins a tie only against classes
+    of higher index, as a stable descending sort / torch.argmax's first maximum decide)."""
+    g = torch.Generator().manual_seed(0)
+    for B, K in ((1, 5), (37, 174), (256, 157), (1000, 1000), (65, 64), (3, 7)):
+        x = torch.randn(B, K, generator=g)
+        x = (x * 4).round() / 4 if K != 1000 else x  # quarter steps: plenty of exact ties
+        y = torch.randint(0, K, (B,), generator=g)
+        ev = E.EvaluatorSomething(B, K, ("stlt",))
+        wide = torch.zeros(B, K + 3)
+        wide[:, :K] = x
+        xd = wide.cuda()[:, :K]  # row stride K+3
+        ev.process({"stlt": xd[: B // 2]}, y[: B // 2])
+        ev.process({"stlt": xd[B // 2:]}, y[B // 2:].cuda())
+        xs, ys = x.numpy(), y.numpy()
+        beat = ((xs > xs[np.arange(B), ys][:, None]) | ((xs == xs[np.arange(B), ys][:, None]) & (np.arange(K)[None, :] < ys[:, None]))).sum(1)
+        assert ev.corrects == {"stlt_top1": int((beat < 1).sum()), "stlt_top5": int((beat < 5).sum())}, (B, K)
+        if B <= 256:  # the oracle's per-row sort (same tie rule), on the sizes a Python loop finishes quickly
+            assert ev.corrects["stlt_top5"] == O.topk_correct(xs, ys, 5) and ev.corrects["stlt_top1"] == O.topk_correct(xs, ys, 1)
+
+
+@pytest.mark.gpu
+def test_average_precision_kernel_vs_oracle_random():
+    """stlt_eval_average_precision against the oracle's per-class loop on sizes around the bitonic sort's powers of two,
+    with empty clips, a class without positives and saturated (tied) scores."""
+    rng = np.random.RandomState(3)
+    for n, C in ((1, 3), (2, 2), (100, 157), (1024, 20), (1025, 9), (1814, 157), (5000, 4)):
+        sig = torch.from_numpy(rng.randn(n, C).astype(np.float32) * 3).sigmoid().numpy().astype(np.float64)
+        sig[rng.rand(n, C) < 0.05] = 1.0  # ties at the top
+        gt = (rng.rand(n, C) < 0.2).astype(np.float64)
+        if n > 4:
+            gt[rng.rand(n) < 0.1] = 0  # clips without any action
+        if C > 2:
+            gt[:, 1] = 0  # a class without positives -> NaN
+        m_ref, w_ref, ap_ref = O.charades_map(sig, gt)
+        m, w, ap = E.charades_map(torch.from_numpy(sig).cuda(), torch.from_numpy(gt).cuda())
+        # the oracle breaks ties by clip index too (a stable descending order), so everything compares at rounding level
+        np.testing.assert_allclose(ap.cpu().numpy(), ap_ref, rtol=0, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(w.cpu().numpy(), w_ref, rtol=0, atol=1e-12, equal_nan=True)
+        assert (np.isnan(m_ref) and np.isnan(m.item())) or abs(m.item() - m_ref) < 1e-12

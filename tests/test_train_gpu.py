@@ -332,3 +332,116 @@ def test_fused_criterion_matches_torch(pkg, kind):
     assert (dl - logits.grad).abs().max().item() <= 1e-7
     half, dl_half = T.fused_criterion(logits, labels, kind, 0.5)  # two logit heads: each contributes half
     assert abs(half.item() - 0.5 * ref.item()) <= 2e-6 and (dl_half - 0.5 * logits.grad).abs().max().item() <= 1e-7
+
+
+def test_fused_adamw_resumes_from_a_loaded_state_dict(pkg):
+    """step, save, load into the SAME optimizer (and into a fresh one), step: the moments the kernel updates must be the
+    loaded ones (torch's loader replaces the state tensors, so the flat buffers have to be re-bound)."""
+    import copy
+    T = importlib.import_module("revisiting-spatial-temporal-layouts_amd.train")
+    g0 = torch.Generator().manual_seed(3)
+    shapes = [(64, 40), (40,), (1000,)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, generator=g0).to(DEV)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    groups = lambda ps: [{"params": [ps[1]], "weight_decay": 0.0}, {"params": [ps[0], ps[2]], "weight_decay": 1e-2}]
+    ref, ours = torch.optim.AdamW(groups(ref_p), lr=1e-2), T.FusedAdamW(groups(our_p), lr=1e-2)
+    layout, off = [], 0
+    for p in our_p:
+        layout.append((p, off, p.numel()))
+        off += (p.numel() + 3) // 4 * 4
+
+    def both_step():
+        grads = [torch.randn(*s, generator=g0).to(DEV) for s in shapes]
+        for p, g in zip(ref_p, grads):
+            p.grad = g.clone()
+        ref.step()
+        flat = torch.zeros(off, device=DEV)
+        for (p, o, n), g in zip(layout, grads):
+            flat[o:o + n] = g.reshape(-1)
+        ours.step_flat(flat, layout, 0.0)
+
+    both_step(); both_step()
+    saved = copy.deepcopy(ours.state_dict())
+    both_step()                              # moves the moments on ...
+    snap_ref = copy.deepcopy(ref.state_dict())
+    ours.load_state_dict(saved)              # ... and the optimizer goes back to the saved state
+    ref.load_state_dict(saved)
+    for a, b in zip(our_p, ref_p):
+        b.data.copy_(a.data)
+    both_step(); both_step()
+    for a, b in zip(our_p, ref_p):
+        assert (a - b).abs().max().item() <= 2e-6
+    st_o, st_r = ours.state_dict()["state"], ref.state_dict()["state"]
+    for k in st_r:
+        assert float(st_o[k]["step"]) == float(st_r[k]["step"]) == 4.0
+        assert (st_o[k]["exp_avg"] - st_r[k]["exp_avg"]).abs().max().item() <= 1e-6
+        assert (st_o[k]["exp_avg_sq"] - st_r[k]["exp_avg_sq"]).abs().max().item() <= 1e-6
+    del snap_ref
+
+
+def test_alternating_batch_shapes_reuse_the_training_buffers_safely(pkg):
+    """(B,T,N) = (4,6,4) and (4,5,4) round to the same tape / scratch byte counts with different row layouts: a step with
+    the shorter clips after one with the longer ones must not pick up stale gradient rows (dW contracts over the row count
+    rounded up to 32).  Gradients of every step are compared with the oracle's autograd."""
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    H = c["num_attention_heads"]
+    kw = pkg.synth.model_kwargs(name)
+    m = pkg.Stlt(pkg.StltModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=41, gain=1.5)
+    m.load_state_dict(sd)
+    m.train(True)
+    m.to(DEV)
+    lib = pkg._lib.load()
+    d, n_sp, n_tp = kw["hidden_size"], kw["num_spatial_layers"], kw["num_temporal_layers"]
+    assert lib.stlt_train_tape_bytes(4, 6, 4, d, n_sp, n_tp) == lib.stlt_train_tape_bytes(4, 5, 4, d, n_sp, n_tp)
+    for it, T in enumerate([6, 5, 6, 5]):
+        batch = pkg.synth.make_batch(4, T, 4, dataset=c["dataset"], seed=90 + it)
+        labels = torch.randint(0, c["num_classes"], (4,), generator=torch.Generator().manual_seed(it))
+        ref_loss, _, ref_g = _oracle_grads(sd, batch, H, labels)
+        for q in m.parameters():
+            q.grad = None
+        out = m({k: v.to(DEV) for k, v in batch.items()})["stlt"]
+        F.cross_entropy(out, labels.to(DEV)).backward()
+        worst = 0.0
+        for k, q in m.named_parameters():
+            if q.grad is None:
+                continue
+            r = ref_g[k].float()
+            worst = max(worst, float((q.grad.cpu() - r).abs().max() / (r.abs().max() + 1e-6)))
+        assert worst <= 2e-4, (it, T, worst)
+
+
+def test_backward_refuses_a_tape_overwritten_by_a_later_forward(pkg):
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.train(True)
+    m.to(DEV)
+    b1 = {k: v.to(DEV) for k, v in pkg.synth.make_batch(2, c["T"], c["N"], seed=1).items()}
+    b2 = {k: v.to(DEV) for k, v in pkg.synth.make_batch(2, c["T"], c["N"], seed=2).items()}
+    l1 = m(b1)["stlt"]
+    l2 = m(b2)["stlt"]  # a second grad-enabled forward re-records the one tape of the backbone
+    with pytest.raises(pkg._lib.StltHipError, match="tape was overwritten"):
+        l1.sum().backward()
+    l2.sum().backward()  # the newest graph still owns the tape
+    with torch.no_grad():
+        m(b1)            # forwards without a graph leave the tape alone
+    l3 = m(b1)["stlt"]
+    l3.sum().backward()
+
+
+def test_trainer_step_leaves_the_model_usable_by_a_plain_autograd_loop(pkg):
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.to(DEV)
+    tr = pkg.train.Trainer(m, "something", learning_rate=1e-3, warmup_steps=0, total_steps=4)
+    batch = pkg.synth.make_batch(2, c["T"], c["N"], seed=7)
+    batch["labels"] = torch.randint(0, c["num_classes"], (2,))
+    dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+    tr.step(dev_batch)
+    assert not m._flat_grads_only and m._grad_sync is None
+    F.cross_entropy(m(dev_batch)["stlt"], dev_batch["labels"]).backward()
+    got = [q.grad is not None for k, q in m.named_parameters() if "prediction_head" in k]
+    assert got and all(got)
