@@ -7,7 +7,12 @@
 
 One process per GPU; clips are independent, so each rank runs its own shard of the batch with no data-path
 collective (weak scaling: per-GPU batch fixed).  A step = one Stlt.forward over the rank's resident batch.
-Rank 0 prints ONE JSON line.  After the timed region the same steps are replayed with hipEvents around every
+Rank 0 prints ONE JSON line.
+
+    python bench.py --mode train [--gpus N]      # BASELINE.json config 3: one optimisation step per "step"
+(cfg2 shapes, 64 clips per GPU, dropout 0.1 as the reference trains: forward with the tape, fused criterion, native
+reverse sweep, gradient all-reduce over RCCL when N > 1, clipping + AdamW, scheduler; same JSON contract, `roofline` priced
+with the FLOPs of every matrix-core launch of the step, forward and backward).  After the timed region the same steps are replayed with hipEvents around every
 kernel launch (library-side, on the launch stream) for the `roofline` objects, and — at N=1 — the CPU oracle
 is timed on a bounded sample for `cpu_baseline`.
 """
@@ -43,17 +48,130 @@ def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only):
     return f
 
 
+def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu):
+    """--mode train: one optimisation step of the reference's train() loop (src/train.py:119-135) per step."""
+    c = pkg.synth.CONFIGS[args.config]
+    kw = pkg.synth.model_kwargs(args.config)
+    kw["hidden_dropout_prob"] = 0.1  # the reference's training default (src/modelling/configs.py)
+    model = pkg.Stlt(pkg.StltModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    model.load_state_dict(sd)
+    model.to(dev)
+    B, T, N, d = args.batch, c["T"], c["N"], c["hidden_size"]
+    tr = pkg.train.Trainer(model, "something", learning_rate=5e-5, weight_decay=1e-3, clip_val=5.0, warmup_steps=2, total_steps=100000,
+                           rank=rank, world=world)
+    cpu_batch = pkg.synth.make_batch(B, T, N, dataset=c["dataset"], seed=1000 + rank)
+    cpu_batch["labels"] = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(rank))
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        tr.step(batch)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = tr.step(batch)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cpu" if one_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    ms_per_step = elapsed / args.steps * 1e3
+    try:
+        pkg.ops.prof_take_gemm_flops()
+        pkg.ops.prof_enable(True)
+        for _ in range(args.steps):
+            tr.step(batch)
+        torch.cuda.synchronize(dev)
+        prof = pkg.ops.prof_collect()
+        gflops = pkg.ops.prof_take_gemm_flops() / args.steps
+        pkg.ops.prof_enable(False)
+        k_ms = {k: (ms / args.steps, int(n / args.steps)) for k, (ms, n) in prof.items()}
+    except Exception as exc:  # the roofline leg must never cost the main line
+        print(f"[bench] per-kernel timing failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+        k_ms, gflops = {}, 0.0
+    gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
+    gemm_tflops = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    out = {
+        "metric": "clips/s STLT train step (T=32, N_obj=7, d=768)" if args.config == "cfg2" else f"clips/s STLT train step ({args.config})",
+        "value": round(world * B * args.steps / elapsed, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: STLT optimisation step (forward with tape, cross entropy, reverse sweep, clip 5.0, AdamW 5e-5 / wd 1e-3 "
+                               f"in two groups, warm-up schedule), T={T}, N={N}, d={d}, H={c['num_attention_heads']}, "
+                               f"{c['num_spatial_layers']}+{c['num_temporal_layers']} layers, {c['num_classes']} classes, dropout 0.1",
+                   "per_gpu_batch": B, "global_batch": B * world,
+                   "parallelism": f"batch-shard x{world}" + (", flat-gradient all-reduce (RCCL) in two slices overlapped with the reverse sweep" if world > 1 else ", no collective")},
+        "roofline": {"kernel": "gemm_nt_kernel, forward + backward (dX, dW) products of the step", "bound": "mfma", "achieved": round(gemm_tflops, 2),
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4), "flops_per_step": gflops},
+        "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
+        "loss": float(res["loss"]), "grad_norm": float(res["grad_norm"]),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import stlt_oracle as O
+            import torch.nn.functional as F
+            nb = min(8, B)
+            sample = {k: v[:nb] for k, v in cpu_batch.items()}
+            leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+            params = [v for v in leaves.values() if v.is_floating_point()]
+            opt = torch.optim.AdamW(params, lr=5e-5, weight_decay=1e-3)
+            default_threads = torch.get_num_threads()
+            cores = os.cpu_count() or default_threads
+
+            def cpu_step():
+                opt.zero_grad()
+                logits = O.stlt_forward(leaves, {k: v for k, v in sample.items() if k != "labels"}, c["num_attention_heads"])["stlt"]
+                F.cross_entropy(logits, sample["labels"]).backward()
+                torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 5.0)
+                opt.step()
+
+            def cpu_rate(n_threads, budget_s, min_it):
+                torch.set_num_threads(n_threads)
+                cpu_step()
+                n_it, t1 = 0, time.perf_counter()
+                while n_it < min_it or (time.perf_counter() - t1 < budget_s and n_it < 100):
+                    cpu_step()
+                    n_it += 1
+                return nb * n_it / (time.perf_counter() - t1), n_it
+
+            cands = sorted({t for t in (8, 16, 32, default_threads) if 0 < t <= cores})
+            probe = {t: cpu_rate(t, 0.0, 1)[0] for t in cands}
+            best = max(probe, key=probe.get)
+            rate, n_it = cpu_rate(best, 10.0, 2)
+            torch.set_num_threads(default_threads)
+            out["cpu_baseline"] = {"value": round(rate, 2), "unit": "clips/s", "cores": best, "kind": "port",
+                                   "sample": f"oracle/stlt_oracle.py under torch autograd + clip_grad_norm_ + torch.optim.AdamW (torch {torch.__version__} "
+                                             f"CPU fp32, no dropout), {n_it} steps of {nb} clips of the same workload; thread counts probed (clips/s): "
+                                             f"{ {t: round(v, 2) for t, v in probe.items()} }, host cores={cores}"}
+        except Exception as exc:
+            out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU per step (1024 makes every cfg2 GEMM a whole number of 256-tile rounds)")
+    ap.add_argument("--mode", choices=("forward", "train"), default="forward")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step; default 1024 for the forward (every cfg2 GEMM is then a whole "
+                                                           "number of 256-tile rounds), 64 for --mode train (the reference's batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-skip-padding", action="store_true", help="do not time the opt-in skip-padding variant after the main measurement (profiling runs)")
     ap.add_argument("--no-cls-only", action="store_true", help="dense schedule: run the last spatial / last temporal layer on every token")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 1024 if args.mode == "forward" else 64
 
     import torch
 
@@ -81,6 +199,14 @@ def main():
     if dist is not None:
         dist.barrier()
     pkg = importlib.import_module(PKG)
+    if args.mode == "train":
+        out = bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     c = pkg.synth.CONFIGS[args.config]
     kw = pkg.synth.model_kwargs(args.config)
     model = pkg.Stlt(pkg.StltModelConfig(**kw))

@@ -337,9 +337,18 @@ int stlt_eval_average_precision(const float* scores, const float* truths, int64_
 #define STLT_K_ADDLN 4
 #define STLT_K_FRAMES 5
 #define STLT_K_GATHER 6
-#define STLT_K_COUNT 7
+#define STLT_K_LN_BWD 7        /* LayerNorm backward (+ its partial-row reductions) */
+#define STLT_K_ATTN_BWD 8      /* attention backward */
+#define STLT_K_GELU 9          /* stand-alone GELU forward (training tape) / backward */
+#define STLT_K_EMBED_BWD 10    /* embedding / frames-embedding backward */
+#define STLT_K_OPTIM 11        /* criterion, gradient norm, AdamW */
+#define STLT_K_MISC 12         /* row gathers / scatters, column sums, ragged index, the head's small products */
+#define STLT_K_COUNT 13
 int stlt_prof_enable(int on);                       /* 1: record events around each launch (serialises nothing, adds events) */
-int stlt_prof_collect(double* ms_out, int64_t* launches_out); /* sync events, accumulate per-kernel ms / launch counts, reset */
+int stlt_prof_collect(double* ms_out, int64_t* launches_out);
+/* FLOPs (2*M*N*K summed over the launches) of the matrix-core products enqueued on the current device while timing was on,
+ * since the last call: what the roofline of a step is priced with, whatever the schedule (forward, elided layers, backward). */
+double stlt_prof_take_gemm_flops(void); /* sync events, accumulate per-kernel ms / launch counts, reset */
 
 /* Diagnostics only (tools/attn_stamps.py, tools/gemm_block_times.py): when non-NULL, stlt_attn_core_fwd runs its
  * s_memtime-stamped build (8 uint64 phase stamps per item) and stlt_linear_fwd records per-workgroup start/end

@@ -93,3 +93,10 @@ def cacnf_forward(sd, batch, H, eps=1e-12) -> Dict[str, torch.Tensor]:
            "caf": O.head_forward(sd, fused, eps, prefix="fusion_classifier.")}
     out["ensemble"] = (out["stlt"] + out["resnet3d"] + out["caf"]) / 3
     return out
+
+
+def lcf_forward(sd, batch, H, eps=1e-12) -> Dict[str, torch.Tensor]:
+    """LateConcatenationFusion.forward, models.py:296-322: FusionHead on [layout state at lengths-1 ; appearance CLS state]
+    (the backbone above with no cross-modal module and no key prefix)."""
+    _, _, fused = backbone(sd, "", batch, H, eps)
+    return {"lcf": O.head_forward(sd, fused, eps, prefix="classifier.")}

@@ -6,7 +6,7 @@ The directory name carries a hyphen, so import it with
 from . import _lib, collate, dist, infer, ops, synth, train  # noqa: F401
 from ._lib import StltHipError  # noqa: F401
 from .modelling.configs import MultimodalModelConfig, StltModelConfig, model_configs_factory  # noqa: F401
-from .modelling.fusion import CrossAttentionCentralNetFusion, CrossAttentionFusion  # noqa: F401
+from .modelling.fusion import CrossAttentionCentralNetFusion, CrossAttentionFusion, LateConcatenationFusion  # noqa: F401
 from .modelling.models import (  # noqa: F401
     CategoryBoxEmbeddings,
     ClassificationHead,

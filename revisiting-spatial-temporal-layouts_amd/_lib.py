@@ -8,7 +8,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STLT_HIP_LIB") or os.path.join(HERE, "libstlt_hip.so")  # env override: A/B experiments only
 
-K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "frames_embed", "gather_last")
+K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "frames_embed", "gather_last", "ln_bwd", "attn_bwd",
+           "gelu", "embed_bwd", "optim", "misc")
 FLAG_CLS_ONLY_LAST_SPATIAL = 1
 FLAG_LAST_ROW_ONLY_TEMPORAL = 2
 FLAG_SKIP_PADDING = 4
@@ -123,6 +124,7 @@ SIGNATURES = {
     "stlt_gelu_fwd": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "stlt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
+    "stlt_prof_take_gemm_flops": (C.c_double, []),
     "stlt_eval_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_eval_max_clips": (C.c_int64, []),
     "stlt_eval_average_precision": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp]),

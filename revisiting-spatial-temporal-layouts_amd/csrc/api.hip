@@ -19,6 +19,8 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs[STLT_MAX_DEVICES];
 std::vector<hipEvent_t> g_event_pool[STLT_MAX_DEVICES];
 thread_local hipEvent_t g_open_start = nullptr;
+thread_local int g_scope_depth = 0;
+double g_gemm_flops[STLT_MAX_DEVICES] = {};
 
 hipEvent_t get_event(int dev) {
   auto& pool = g_event_pool[dev];
@@ -61,13 +63,21 @@ int stlt_check_launch(const char* what) {
 }
 
 void stlt_prof_begin(int kid, hipStream_t s) {
+  if (g_scope_depth++ > 0) return;  // nested launcher: the outer scope times it
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_open_start = get_event(stlt_current_device() & (STLT_MAX_DEVICES - 1));
   (void)hipEventRecord(g_open_start, s);
 }
 
+void stlt_prof_add_flops(double flops) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_gemm_flops[stlt_current_device() & (STLT_MAX_DEVICES - 1)] += flops;
+}
+
 void stlt_prof_end(int kid, hipStream_t s) {
+  if (--g_scope_depth > 0) return;
   if (!g_prof_on || !g_open_start) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   const int dev = stlt_current_device() & (STLT_MAX_DEVICES - 1);
@@ -90,6 +100,14 @@ int stlt_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
   return 0;
+}
+
+double stlt_prof_take_gemm_flops(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double& f = g_gemm_flops[stlt_current_device() & (STLT_MAX_DEVICES - 1)];
+  const double out = f;
+  f = 0.0;
+  return out;
 }
 
 int stlt_prof_collect(double* ms_out, int64_t* launches_out) {

@@ -609,7 +609,7 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   if (M == 0) return 0;
   int64_t blocks = (M + 4 * RW_WAVES - 1) / (4 * RW_WAVES);  // ~4 rows per persistent wave until the cap binds
   if (blocks > 512) blocks = 512;  // one partial row set per block (scratch is sized for that)
-  StltProfScope ps(STLT_K_ADDLN, s);
+  StltProfScope ps(STLT_K_LN_BWD, s);
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
                                             ldb, w, eps, M, (int)d, ds, ldds, scratch, dr, site_b2,
                                             (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy, drop_rows));
@@ -623,6 +623,7 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
 
 // g[n] += sum_m x[m][n]   (scratch >= 64*N floats)
 int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g, float* scratch, hipStream_t s) {
+  StltProfScope ps(STLT_K_MISC, s);
   if (!x || !g || !scratch) return stlt_set_error(STLT_EINVAL, "colsum: null pointer");
   if (M == 0 || N == 0) return 0;
   int parts = (int)((M + 255) / 256);
@@ -635,6 +636,7 @@ int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g
 }
 
 int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows, int64_t ncols) {
+  StltProfScope ps(STLT_K_GELU, s);
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
   int64_t blocks = (n / 4 + 255) / 256;
@@ -646,6 +648,7 @@ int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop
 
 int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
                            hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows) {
+  StltProfScope ps(STLT_K_GELU, s);
   if (!dh || !u || !du || !g_colsum || !scratch) return stlt_set_error(STLT_EINVAL, "gelu_bwd: null pointer");
   if (N % 4 || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gelu: column count must be a multiple of 4");
   if (M == 0 || N == 0) return 0;
@@ -660,6 +663,7 @@ int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M
 
 int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows,
                     int64_t ncols) {
+  StltProfScope ps(STLT_K_GELU, s);
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
   int64_t blocks = (n / 4 + 255) / 256;
@@ -672,6 +676,7 @@ int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipSt
 int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H,
                     int64_t dh, float* dqkv, hipStream_t s, StltDrop dr, uint32_t site, float* g_colsum, float* scratch,
                     const AttnBwdRagged* rg) {
+  StltProfScope ps(STLT_K_ATTN_BWD, s);
   if (!qkv || !dctx || (!kpm && !rg) || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
   if (dh != AB_DH) return stlt_set_error(STLT_EINVAL, "attn_bwd: head dim must be 64");
   if (L <= 0 || L > AB_LONG_MAXL)
@@ -731,6 +736,7 @@ int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d) {
 int launch_embed_bwd(const float* dx, const int64_t* categories, const float* boxes, const float* scores, int64_t C,
                      int64_t n_tokens, int64_t d, float* g_cat, float* g_box_w, float* g_box_b, float* g_score_w,
                      float* g_score_b, float* scratch, hipStream_t s, const int* src_index) {
+  StltProfScope ps(STLT_K_EMBED_BWD, s);
   if (!dx || !categories || !boxes || !scratch) return stlt_set_error(STLT_EINVAL, "embed_bwd: null pointer");
   if (n_tokens == 0) return 0;
   int64_t blocks = (n_tokens + 127) / 128;
@@ -746,6 +752,7 @@ int launch_embed_bwd(const float* dx, const int64_t* categories, const float* bo
 
 int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, int64_t T, int64_t N, int64_t d,
                       float* dx_spatial, float* g_pos, float* g_type, float* scratch, hipStream_t s, const int* row_of) {
+  StltProfScope ps(STLT_K_EMBED_BWD, s);
   if (!ds || !frame_types || !scratch) return stlt_set_error(STLT_EINVAL, "frames_bwd: null pointer");
   if (B * T == 0) return 0;
   if (dx_spatial) {  // null: the caller routes the CLS-row gradient itself (ragged layout / CLS-rows-only last layer)
@@ -762,6 +769,7 @@ int launch_frames_bwd(const float* ds, const int64_t* frame_types, int64_t B, in
 }
 
 int launch_scatter_last(const float* dh, const int64_t* lengths, int64_t B, int64_t T, int64_t d, float* dout, hipStream_t s) {
+  StltProfScope ps(STLT_K_MISC, s);
   if (!dh || !lengths || !dout) return stlt_set_error(STLT_EINVAL, "scatter_last: null pointer");
   if (B == 0) return 0;
   if (hipError_t e = hipMemsetAsync(dout, 0, (size_t)B * T * d * sizeof(float), s); e != hipSuccess)
@@ -772,6 +780,7 @@ int launch_scatter_last(const float* dh, const int64_t* lengths, int64_t B, int6
 
 int launch_small_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk, int64_t sbn, float* c,
                       int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t s) {
+  StltProfScope ps(STLT_K_MISC, s);
   if (!a || !b || !c) return stlt_set_error(STLT_EINVAL, "small_gemm: null pointer");
   if (M * N == 0) return 0;
   hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, a, sam, sak, b, sbk, sbn, c, ldc,

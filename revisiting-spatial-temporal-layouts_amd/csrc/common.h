@@ -35,7 +35,8 @@ extern unsigned long long* g_stlt_debug_buf;
 // per-kernel timing hooks (api.hip)
 void stlt_prof_begin(int kid, hipStream_t s);
 void stlt_prof_end(int kid, hipStream_t s);
-struct StltProfScope {
+void stlt_prof_add_flops(double flops);
+struct StltProfScope {  // scopes nest: only the outermost one of a thread records (a launcher that calls another launcher is one entry)
   int kid; hipStream_t s;
   StltProfScope(int k, hipStream_t st) : kid(k), s(st) { stlt_prof_begin(kid, s); }
   ~StltProfScope() { stlt_prof_end(kid, s); }

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void eval_empty_rows_kernel(const float* __res
   if (row >= n) return;
   bool any = false;
   for (int j = lane; j < C; j += 64) any |= truths[row * C + j] != 0.f;
-  if (lane == 0) empty[row] = __ballot(any) == 0ull ? 1 : 0;
+  const unsigned long long seen = __ballot(any);  // all 64 lanes vote before lane 0 writes
+  if (lane == 0) empty[row] = seen == 0ull ? 1 : 0;
 }
 
 // monotone map float -> uint32 (larger float = larger key), then inverted so that an ASCENDING key sort is a
@@ -125,9 +126,9 @@ extern "C" {
 
 int stlt_eval_topk(const float* logits, int64_t ld, const int64_t* labels, int64_t B, int64_t K, int64_t* counts,
                    stlt_stream_t stream) {
+  if (B == 0) return 0;  // an empty batch has no storage to point at
   if (!logits || !labels || !counts) return stlt_set_error(STLT_EINVAL, "stlt_eval_topk: null pointer");
   if (B < 0 || K <= 0 || K > 0x7fffffff || ld < K) return stlt_set_error(STLT_EINVAL, "stlt_eval_topk: bad shape (B=%lld, K=%lld, ld=%lld)", (long long)B, (long long)K, (long long)ld);
-  if (B == 0) return 0;
   hipLaunchKernelGGL(eval_topk_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, B, (int)K,
                      reinterpret_cast<unsigned long long*>(counts));
   return stlt_check_launch("eval_topk_kernel");

@@ -630,6 +630,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   int64_t n_wg = tiles_m * tiles_n * n_split;
   if (n_wg > n_cu()) n_wg = n_cu();
   StltProfScope ps(STLT_K_GEMM, s);
+  stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
   dim3 block(GEMM_THREADS);
   // Stream-K when whole tiles would leave CUs idle (fewer tiles than CUs, or a ragged last round) and the caller
   // lent scratch for the partial tiles (StltGemmScratch / stlt_gemm_set_scratch).

@@ -94,6 +94,7 @@ int stlt_grad_norm(const float* flat_grad, int64_t n, float max_norm, float* scr
   if (!flat_grad || !scratch || !out) return stlt_set_error(STLT_EINVAL, "stlt_grad_norm: null pointer");
   if (n < 0 || ((uintptr_t)flat_grad & 15)) return stlt_set_error(STLT_EINVAL, "stlt_grad_norm: buffer must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  StltProfScope ps(STLT_K_OPTIM, s);
   int64_t blocks = (n / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat_grad, n / 4, n, scratch);
@@ -106,6 +107,7 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
                     const float* norm_and_clip, float lr, float beta1, float beta2, float eps, int64_t step, stlt_stream_t stream) {
   if (!chunks_dev || !flat_grad || !exp_avg || !exp_avg_sq) return stlt_set_error(STLT_EINVAL, "stlt_adamw_step: null pointer");
   if (step < 1 || n_chunks < 0 || n_chunks > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_adamw_step: bad step / chunk count");
+  StltProfScope ps(STLT_K_OPTIM, (hipStream_t)stream);
   if (n_chunks == 0) return 0;
   // scalars as torch computes them: python floats (double), rounded to fp32 where they meet the tensors
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -190,6 +192,7 @@ extern "C" int stlt_loss_fwd_bwd(const float* logits, const void* labels, int ki
   if (kind != STLT_LOSS_CROSS_ENTROPY && kind != STLT_LOSS_BCE_WITH_LOGITS) return stlt_set_error(STLT_EINVAL, "stlt_loss_fwd_bwd: unknown loss %d", kind);
   if (B <= 0 || K <= 0 || K > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_loss_fwd_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
+  StltProfScope ps(STLT_K_OPTIM, s);
   // mean reduction: over the clips (cross entropy) or over all B*K elements (BCE)
   const float mean = kind == STLT_LOSS_CROSS_ENTROPY ? 1.0f / (float)B : 1.0f / ((float)B * (float)K);
   hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, labels, kind, (int)K, weight * mean, scratch, dlogits);

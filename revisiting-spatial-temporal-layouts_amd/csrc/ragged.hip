@@ -180,6 +180,7 @@ RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N) {
 
 int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, const int64_t* lengths, int64_t B, int64_t T,
                         int64_t N, const RaggedIndex& ix, hipStream_t s) {
+  StltProfScope ps(STLT_K_MISC, s);
   if (!kpm_boxes || !kpm_frames) return stlt_set_error(STLT_EINVAL, "ragged_index: null mask");
   if (T > 256) return stlt_set_error(STLT_EINVAL, "ragged_index: T=%lld > 256", (long long)T);
   if (B * T * N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "ragged_index: batch too large for 32-bit row indices");
@@ -203,6 +204,7 @@ int launch_gather_rows(const float* src, int64_t ld, const int* rows, int64_t n,
 }
 
 int launch_ragged_groups(const RaggedIndex& ix, int64_t n_tokens, int64_t n_frames, int fpg, hipStream_t s) {
+  StltProfScope ps(STLT_K_MISC, s);
   if (fpg < 1) return stlt_set_error(STLT_EINVAL, "ragged_groups: frames per group must be positive");
   const int64_t n_groups = (n_frames + fpg - 1) / fpg;
   hipLaunchKernelGGL(ragged_groups_kernel, dim3((unsigned)((n_groups + 256) / 256)), dim3(256), 0, s, ix.f_cls_row, (int)n_tokens,
@@ -211,6 +213,7 @@ int launch_ragged_groups(const RaggedIndex& ix, int64_t n_tokens, int64_t n_fram
 }
 
 int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s) {
+  StltProfScope ps(STLT_K_MISC, s);
   if (!src || !rows || !dst) return stlt_set_error(STLT_EINVAL, "scatter_rows: null pointer");
   if (d % 4) return stlt_set_error(STLT_EINVAL, "scatter_rows: d must be a multiple of 4");
   if (hipError_t e = hipMemsetAsync(dst, 0, (size_t)dst_rows * d * sizeof(float), s); e != hipSuccess)
@@ -221,6 +224,7 @@ int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d,
 }
 
 int launch_padded_rows(const int64_t* lengths, int64_t B, int64_t T, int64_t N, const RaggedIndex& ix, hipStream_t s) {
+  StltProfScope ps(STLT_K_MISC, s);
   if (!lengths) return stlt_set_error(STLT_EINVAL, "padded_rows: null lengths");
   if (B * T * N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "padded_rows: batch too large for 32-bit row indices");
   hipLaunchKernelGGL(padded_rows_kernel, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, s, lengths, B, (int)T, (int)N, ix.f_cls_row, ix.last_row);

@@ -1,5 +1,5 @@
-"""Drop-in ``CrossAttentionFusion`` (CAF) and ``CrossAttentionCentralNetFusion`` (CACNF) for inference on PRECOMPUTED
-appearance features (reference src/modelling/models.py:230-271, 286-298, 328-549; BASELINE config 5).
+"""Drop-in ``CrossAttentionFusion`` (CAF), ``CrossAttentionCentralNetFusion`` (CACNF) and ``LateConcatenationFusion`` (LCF)
+on PRECOMPUTED appearance features (reference src/modelling/models.py:230-271, 286-322, 328-549; BASELINE config 5).
 
 Differences from the reference, by design of the scope:
   * the R3D-50 trunk does not run: the batch carries ``appearance_features`` (B, 2048, 2, 4, 4) — what
@@ -262,7 +262,53 @@ class CrossAttentionCentralNetFusion(nn.Module):
         return {"stlt": stlt, "resnet3d": res, "caf": caf, "ensemble": ens}
 
 
+class LateConcatenationFusion(nn.Module):
+    """LCF (reference models.py:296-322): ``forward(batch) -> {"lcf": (B, num_classes)}`` — the FusionHead on the layout
+    state at ``lengths-1`` concatenated with the appearance branch's CLS state.  That is the fusion backbone with zero
+    cross-modal layers, so it runs through the same native entry point (``stlt_caf_forward``, ``n_fusion = 0``) and the same
+    op-level training composition.  State-dict keys are the reference's (``layout_branch.*``, ``appearance_branch.*``,
+    ``classifier.*``) minus ``…resnet.*``: the helper that owns the launch logic shares these modules without being
+    registered as a child."""
+
+    def __init__(self, config: MultimodalModelConfig):
+        super().__init__()
+        self.config = config
+        self.layout_branch = StltBackbone(config.stlt_config)
+        self.appearance_branch = TransformerResnetFeatures(config)
+        self.classifier = FusionHead(config)
+        self.logit_names = ("lcf",)
+        object.__setattr__(self, "_runner", self._make_runner())
+
+    def _make_runner(self):
+        r = CrossAttentionFusionBackbone.__new__(CrossAttentionFusionBackbone)
+        nn.Module.__init__(r)
+        r.config = self.config
+        r.layout_branch, r.appearance_branch = self.layout_branch, self.appearance_branch  # shared, not copied
+        r.mm_fusion = nn.ModuleList([])
+        r._ws = _Workspace()
+        return r
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_runner", None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        object.__setattr__(self, "_runner", self._make_runner())
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        self._runner.training = mode  # the runner is not a child: keep its mode flag (dropout switch) in step
+        return self
+
+    def forward(self, batch: Dict[str, torch.Tensor]):
+        (lcf,) = self._runner.run(batch, self.classifier)
+        return {"lcf": lcf}
+
+
 from .models import models_factory  # noqa: E402
 
 models_factory["caf"] = CrossAttentionFusion
 models_factory["cacnf"] = CrossAttentionCentralNetFusion
+models_factory["lcf"] = LateConcatenationFusion

@@ -230,6 +230,11 @@ def prof_collect():
     return {L.K_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}
 
 
+def prof_take_gemm_flops() -> float:
+    """2*M*N*K summed over the matrix-core launches enqueued while timing was on, since the last call."""
+    return float(L.load().stlt_prof_take_gemm_flops())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Op-level autograd over the per-kernel backward entry points (include/stlt_hip.h: stlt_linear_bwd, stlt_attn_bwd,
 # stlt_add_layernorm_bwd, stlt_gelu_bwd).  The STLT training step does not use these (it has one fixed reverse sweep);

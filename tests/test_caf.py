@@ -1,4 +1,4 @@
-"""CAF / CACNF on precomputed appearance features (BASELINE config 5) against fixtures captured
+"""CAF / CACNF / LCF on precomputed appearance features (BASELINE config 5) against fixtures captured
 from the reference's own modules (tools/gen_golden_caf.py)."""
 import json
 import os
@@ -24,10 +24,10 @@ def _case(synth, model_name):
     return z, meta, sd, batch, c
 
 
-@pytest.mark.parametrize("model_name", ["caf", "cacnf"])
+@pytest.mark.parametrize("model_name", ["caf", "cacnf", "lcf"])
 def test_caf_oracle_matches_reference(synth, model_name):
     z, meta, sd, batch, c = _case(synth, model_name)
-    fwd = CO.caf_forward if model_name == "caf" else CO.cacnf_forward
+    fwd = {"caf": CO.caf_forward, "cacnf": CO.cacnf_forward, "lcf": CO.lcf_forward}[model_name]
     with torch.no_grad():
         out = fwd(sd, batch, c["num_attention_heads"])
     assert set(out) == set(z.files)
@@ -35,7 +35,7 @@ def test_caf_oracle_matches_reference(synth, model_name):
         assert np.abs(out[k].numpy() - z[k]).max() <= 3e-5, k
 
 
-@pytest.mark.parametrize("model_name", ["caf", "cacnf"])
+@pytest.mark.parametrize("model_name", ["caf", "cacnf", "lcf"])
 def test_caf_state_dict_keys_are_the_reference_non_r3d_keys(pkg, model_name):
     _, meta, _, _, _ = _case(pkg.synth, model_name)
     cls = pkg.models_factory[model_name]
@@ -46,7 +46,7 @@ def test_caf_state_dict_keys_are_the_reference_non_r3d_keys(pkg, model_name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["caf", "cacnf"])
+@pytest.mark.parametrize("model_name", ["caf", "cacnf", "lcf"])
 def test_caf_gpu_matches_reference(pkg, model_name):
     z, meta, sd, batch, c = _case(pkg.synth, model_name)
     cls = pkg.models_factory[model_name]

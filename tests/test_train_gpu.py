@@ -364,8 +364,8 @@ def test_fused_adamw_resumes_from_a_loaded_state_dict(pkg):
     saved = copy.deepcopy(ours.state_dict())
     both_step()                              # moves the moments on ...
     snap_ref = copy.deepcopy(ref.state_dict())
-    ours.load_state_dict(saved)              # ... and the optimizer goes back to the saved state
-    ref.load_state_dict(saved)
+    ours.load_state_dict(copy.deepcopy(saved))   # ... and the optimizer goes back to the saved state (torch's loader keeps
+    ref.load_state_dict(copy.deepcopy(saved))    # the tensors it is handed: each optimizer gets its own copy)
     for a, b in zip(our_p, ref_p):
         b.data.copy_(a.data)
     both_step(); both_step()

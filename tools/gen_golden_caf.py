@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Golden fixtures for CAF / CACNF on precomputed appearance features, captured from the REFERENCE modules
-(src/modelling/models.py:434-549) in the build container.  The R3D-50 trunk is not part of the scope: the reference's
+"""Golden fixtures for CAF / CACNF / LCF on precomputed appearance features, captured from the REFERENCE modules
+(src/modelling/models.py:296-322, 434-549) in the build container.  The R3D-50 trunk is not part of the scope: the reference's
 `Resnet3D.forward_features` is replaced at run time by a function returning batch["appearance_features"] (the tensor
 that method would produce), and a random-init R3D checkpoint is written to /tmp only to satisfy the constructor.
 Everything downstream (projector, ReLU transformer, cross-modal modules, heads) is the reference's own code."""
@@ -27,7 +27,7 @@ def main():
     name, B = "cfg1", 3
     c = synth.CONFIGS[name]
     kw = dict(synth.model_kwargs(name), appearance_num_frames=32, resnet_model_path=ck, num_appearance_layers=2, num_fusion_layers=2)
-    for model_name, cls in (("caf", RM.CrossAttentionFusion), ("cacnf", RM.CrossAttentionCentralNetFusion)):
+    for model_name, cls in (("caf", RM.CrossAttentionFusion), ("cacnf", RM.CrossAttentionCentralNetFusion), ("lcf", RM.LateConcatenationFusion)):
         model = cls(MultimodalModelConfig(**kw))
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if ".resnet." not in k}
         sd = synth.make_state_dict(shapes, seed=77)
