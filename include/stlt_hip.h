@@ -265,7 +265,8 @@ typedef struct {
  * stlt_linear_bwd: y = x·Wᵀ + b (no activation).  dx (M,K) = dy·W (nullable), dw (N,K) += dyᵀ·x (nullable), db (N) +=
  *   column sums of dy (nullable).  scratch: stlt_linear_bwd_scratch_bytes(N).
  * stlt_attn_bwd: backward of stlt_attn_cross_fwd (and, with q = qkv, k = qkv+d, v = qkv+2d, of stlt_attn_core_fwd):
- *   dq / dk / dv written (not accumulated) with their own leading dimensions; sequences of at most 64 tokens.
+ *   dq / dk / dv written (not accumulated) with their own leading dimensions; sequences of at most 256 tokens on either
+ *   side (above 64 a streamed variant: query tiles of 32, keys / values in tiles through LDS).
  * stlt_add_layernorm_bwd: out = LN_eps(x + res)·w + b.  ds = gradient wrt the sum (the gradient of both x and res);
  *   g_w / g_b accumulate (nullable).  scratch: stlt_add_layernorm_bwd_scratch_bytes(d).
  * stlt_gelu_fwd / stlt_gelu_bwd: exact-erf GELU and du = dh * gelu'(u), n a multiple of 4. */
@@ -302,6 +303,12 @@ size_t stlt_frames_embed_bwd_scratch_bytes(int64_t T, int64_t d);
 int stlt_frames_embed_bwd(const float* d_pre, const int64_t* frame_types, int64_t B, int64_t T, int64_t d, float* g_pos, float* g_type,
                           void* scratch, size_t scratch_bytes, stlt_stream_t stream);
 int stlt_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, stlt_stream_t stream);
+/* Element-wise pieces of the op-level training path.  stlt_dropout: y[i] = keep(seed, site, i) ? x[i] / (1-p) : 0 with the
+ * library's counter-based mask — the backward is the same call on the gradient (nn.Dropout at models.py:333-376 and inside
+ * nn.TransformerEncoderLayer).  stlt_relu_bwd: dx = dy where the activation's OUTPUT y is positive (the ReLU itself runs in
+ * the producing product's epilogue: stlt_linear_fwd with STLT_ACT_RELU).  Buffers 16-byte aligned; y may alias x / dx may alias dy. */
+int stlt_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint32_t site, stlt_stream_t stream);
+int stlt_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, stlt_stream_t stream);
 
 /* Criterion of the reference (utils/train_inference_utils.py:64-76) and its gradient in one pass: loss_out[0] = weight *
  * mean loss, dlogits = weight * d(mean loss)/d(logits).  CROSS_ENTROPY: labels int64 (B); BCE_WITH_LOGITS: labels float

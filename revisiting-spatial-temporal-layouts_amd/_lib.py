@@ -124,6 +124,8 @@ SIGNATURES = {
     "stlt_gelu_fwd": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "stlt_gelu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
+    "stlt_dropout": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp]),
+    "stlt_relu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "stlt_prof_take_gemm_flops": (C.c_double, []),
     "stlt_eval_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_eval_max_clips": (C.c_int64, []),

@@ -101,9 +101,184 @@ __global__ __launch_bounds__(256) void attn_bwd_general_kernel(const float* __re
   }
 }
 
+// The same backward for sequences of up to 256 tokens on either side (layouts of more than 64 frames through the fusion
+// models): one block per (sequence, head), queries in tiles of 32, keys / values streamed twice per query tile through
+// LDS (scores and dP, then dQ and the tile's share of dK / dV, which the thread that owns an output element adds up
+// over the query tiles — a fixed order, no atomics).  Same FMA arithmetic and dropout indexing as the kernel above.
+constexpr int XB_LONG_MAXL = 256;
+
+__global__ __launch_bounds__(256) void attn_bwd_general_long_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                                    const float* __restrict__ v, int64_t ldkv,
+                                                                    const float* __restrict__ dctx, const uint8_t* __restrict__ kpm,
+                                                                    int causal, int Lq, int Lk, int H, float scale,
+                                                                    float* __restrict__ dq, int64_t lddq, float* __restrict__ dk,
+                                                                    float* __restrict__ dv, int64_t lddkv, StltDrop dr, uint32_t site) {
+  extern __shared__ float xb_smem[];
+  const int PLD = Lk + 1;
+  float* Qs = xb_smem;                // 32 x 65: query tile
+  float* Gs = Qs + 32 * XB_LD;        // dO tile
+  float* Ks = Gs + 32 * XB_LD;        // key tile
+  float* Vs = Ks + 32 * XB_LD;        // value tile
+  float* Ps = Vs + 32 * XB_LD;        // 32 x (Lk+1): scores -> P
+  float* Ds = Ps + 32 * PLD;          // dP -> dS
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % H;
+  const int64_t sq = blockIdx.x / H;
+  const int d = H * XB_DH;
+  const int64_t qt0 = sq * Lq, kt0 = sq * Lk;
+  const int rc = tid >> 6, c = tid & 63;  // this thread's row class (rows rc, rc+4, ...) and channel
+  const float* qb = q + qt0 * ldq + head * XB_DH;
+  const float* kb = k + kt0 * ldkv + head * XB_DH;
+  const float* vb = v + kt0 * ldkv + head * XB_DH;
+  float* dkb = dk + kt0 * lddkv + head * XB_DH;
+  float* dvb = dv + kt0 * lddkv + head * XB_DH;
+  for (int r = rc; r < Lk; r += 4) { dkb[r * lddkv + c] = 0.f; dvb[r * lddkv + c] = 0.f; }  // accumulated over the query tiles below
+  for (int q0 = 0; q0 < Lq; q0 += 32) {
+    const int nq = Lq - q0 < 32 ? Lq - q0 : 32;
+    for (int i = rc; i < 32; i += 4) {
+      const bool in = i < nq;
+      Qs[i * XB_LD + c] = in ? qb[(q0 + i) * ldq + c] : 0.f;
+      Gs[i * XB_LD + c] = in ? dctx[(qt0 + q0 + i) * (int64_t)d + head * XB_DH + c] : 0.f;
+    }
+    for (int k0 = 0; k0 < Lk; k0 += 32) {  // pass A: scores and dP against every key tile
+      const int nkeys = Lk - k0 < 32 ? Lk - k0 : 32;
+      __syncthreads();
+      for (int j = rc; j < 32; j += 4) {
+        const bool in = j < nkeys;
+        Ks[j * XB_LD + c] = in ? kb[(k0 + j) * ldkv + c] : 0.f;
+        Vs[j * XB_LD + c] = in ? vb[(k0 + j) * ldkv + c] : 0.f;
+      }
+      __syncthreads();
+      for (int p = tid; p < 32 * 32; p += 256) {
+        const int i = p >> 5, j = p & 31;
+        const int kj = k0 + j, qi = q0 + i;
+        const bool ok = i < nq && j < nkeys && (!kpm || kpm[kt0 + kj] == 0) && (!causal || kj <= qi);
+        float sc = 0.f, dp = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < XB_DH; ++e) {
+          sc += Qs[i * XB_LD + e] * Ks[j * XB_LD + e];
+          dp += Gs[i * XB_LD + e] * Vs[j * XB_LD + e];
+        }
+        if (dr.thr) {
+          const uint64_t idx = ((((uint64_t)(qt0 + qi)) * H + head) << 8) | (uint64_t)(kj & 0xff);
+          dp = stlt_keep(dr, site, idx) ? dp * dr.scale : 0.f;
+        }
+        if (j < nkeys) { Ps[i * PLD + kj] = ok ? sc * scale : -1e30f; Ds[i * PLD + kj] = dp; }
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {  // row softmax, D_i, dS (in place: Ps <- P, Ds <- dS)
+      const int i = tid;
+      float m = -1e30f;
+      for (int j = 0; j < Lk; ++j) m = fmaxf(m, Ps[i * PLD + j]);
+      float l = 0.f;
+      for (int j = 0; j < Lk; ++j) {
+        const float sv = Ps[i * PLD + j];
+        const float e = sv > -1e29f ? expf(sv - m) : 0.f;
+        Ps[i * PLD + j] = e;
+        l += e;
+      }
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      float dsum = 0.f;
+      for (int j = 0; j < Lk; ++j) {
+        const float pj = Ps[i * PLD + j] * inv;
+        Ps[i * PLD + j] = pj;
+        dsum += pj * Ds[i * PLD + j];
+      }
+      for (int j = 0; j < Lk; ++j) Ds[i * PLD + j] = Ps[i * PLD + j] * (Ds[i * PLD + j] - dsum);
+    }
+    float dqa[8];  // pass B: dQ of this query tile, and its share of dK / dV
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dqa[t] = 0.f;
+    for (int k0 = 0; k0 < Lk; k0 += 32) {
+      const int nkeys = Lk - k0 < 32 ? Lk - k0 : 32;
+      __syncthreads();
+      for (int j = rc; j < 32; j += 4) Ks[j * XB_LD + c] = j < nkeys ? kb[(k0 + j) * ldkv + c] : 0.f;
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int i = rc + 4 * t;
+        float acc = 0.f;
+        for (int j = 0; j < nkeys; ++j) acc += Ds[i * PLD + k0 + j] * Ks[j * XB_LD + c];
+        dqa[t] += acc;
+      }
+      for (int j = rc; j < nkeys; j += 4) {
+        const int kj = k0 + j;
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < nq; ++i) {
+          ak += Ds[i * PLD + kj] * Qs[i * XB_LD + c];
+          float pd = Ps[i * PLD + kj];
+          if (dr.thr) {
+            const uint64_t idx = ((((uint64_t)(qt0 + q0 + i)) * H + head) << 8) | (uint64_t)(kj & 0xff);
+            pd = stlt_keep(dr, site, idx) ? pd * dr.scale : 0.f;
+          }
+          av += pd * Gs[i * XB_LD + c];
+        }
+        dkb[kj * lddkv + c] += ak * scale;  // the same thread owns (kj, c) in every query tile
+        dvb[kj * lddkv + c] += av;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = rc + 4 * t;
+      if (i < nq) dq[(qt0 + q0 + i) * lddq + head * XB_DH + c] = dqa[t] * scale;
+    }
+    __syncthreads();  // the next query tile overwrites Qs / Gs / Ps / Ds
+  }
+}
+
+// Element-wise pieces of the op-level training path: counter-based dropout (its own backward: the mask is a function of
+// (seed, site, element index)) and the ReLU derivative taken from the activation's output.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, StltDrop dr, uint32_t site) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      *reinterpret_cast<f32x4*>(y + i) = stlt_drop4(dr, site, (uint64_t)i, *reinterpret_cast<const f32x4*>(x + i));
+    } else {
+      for (int64_t j = i; j < n; ++j) y[j] = stlt_keep(dr, site, (uint64_t)j) ? x[j] * dr.scale : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i), a = *reinterpret_cast<const f32x4*>(y + i);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = a[e] > 0.f ? g[e] : 0.f;
+      *reinterpret_cast<f32x4*>(dx + i) = o;
+    } else {
+      for (int64_t j = i; j < n; ++j) dx[j] = y[j] > 0.f ? dy[j] : 0.f;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int stlt_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint32_t site, stlt_stream_t stream) {
+  if (!x || !y) return stlt_set_error(STLT_EINVAL, "stlt_dropout: null pointer");
+  if (!(p >= 0.f && p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
+  if (n < 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return stlt_set_error(STLT_EINVAL, "stlt_dropout: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  StltProfScope ps(STLT_K_MISC, (hipStream_t)stream);
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, stlt_drop_make(p, seed), site);
+  return stlt_check_launch("dropout_kernel");
+}
+
+int stlt_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, stlt_stream_t stream) {
+  if (!dy || !y || !dx) return stlt_set_error(STLT_EINVAL, "stlt_relu_bwd: null pointer");
+  if (n < 0 || ((uintptr_t)dy & 15) || ((uintptr_t)y & 15) || ((uintptr_t)dx & 15)) return stlt_set_error(STLT_EINVAL, "stlt_relu_bwd: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  StltProfScope ps(STLT_K_MISC, (hipStream_t)stream);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+  return stlt_check_launch("relu_bwd_kernel");
+}
 
 size_t stlt_linear_bwd_scratch_bytes(int64_t N) {
   return STLT_GEMM_SCRATCH_BYTES + (size_t)(N > 0 ? N : 0) * 64 * sizeof(float);
@@ -146,8 +321,24 @@ int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, i
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
   if (!q || !k || !v || !dctx || !dq || !dk || !dv) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: null pointer");
   if (dh != XB_DH) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: head dim must be 64");
-  if (Lq <= 0 || Lk <= 0 || Lq > XB_MAXL || Lk > XB_MAXL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: sequences of at most %d tokens (got %lld / %lld)", XB_MAXL, (long long)Lq, (long long)Lk);
+  if (Lq <= 0 || Lk <= 0 || Lq > XB_LONG_MAXL || Lk > XB_LONG_MAXL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: sequences of at most %d tokens (got %lld / %lld)", XB_LONG_MAXL, (long long)Lq, (long long)Lk);
   if (causal && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: causal masking needs Lq == Lk");
+  if (Lq > XB_MAXL || Lk > XB_MAXL) {  // streamed variant: query tiles of 32, keys in tiles through LDS
+    if (S == 0) return 0;
+    if (S * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: too many sequences");
+    const size_t lds_long = ((size_t)4 * 32 * XB_LD + (size_t)2 * 32 * (Lk + 1)) * sizeof(float);
+    static StltPerDeviceOnce long_once;
+    bool& opted = long_once.flag();
+    if (!opted) {
+      if (hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_general_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
+        return stlt_set_error((int)e, "stlt_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      opted = true;
+    }
+    StltProfScope ps(STLT_K_ATTN_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(attn_bwd_general_long_kernel, dim3((unsigned)(S * H)), dim3(256), lds_long, (hipStream_t)stream, q, ldq, k, v, ldkv, dctx, kpm,
+                       causal, (int)Lq, (int)Lk, (int)H, 1.0f / sqrtf((float)dh), dq, lddq, dk, dv, lddkv, stlt_drop_make(dropout_p, seed), site);
+    return stlt_check_launch("attn_bwd_general_long_kernel");
+  }
   if (S == 0) return 0;
   if (S * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: too many sequences");
   const size_t lds = ((size_t)2 * Lq * XB_LD + (size_t)2 * Lk * XB_LD + (size_t)2 * Lq * (Lk + 1)) * sizeof(float);

@@ -66,6 +66,9 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 #ifndef STLT_GEMM_ABLATE
 #define STLT_GEMM_ABLATE 0  // timing-only builds (wrong results): bit 0 no steady-state DMA, bit 3 loaders do not wait for their DMA, bit 4 no epilogue stores, bit 5 loaders re-read k-step 0 of their first tile (cache-hot source)
 #endif
+#ifndef STLT_GEMM_GROUPED
+#define STLT_GEMM_GROUPED 1  // 1: every XCD walks a contiguous stretch of a band-major tile order (bands of 4 M-panels, N outer inside a band); 0: round-1 order
+#endif
 #ifndef STLT_GEMM_WS_DEFAULT
 #define STLT_GEMM_WS_DEFAULT 1
 #endif
@@ -133,6 +136,15 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   // round, still keeps every CU busy; a range may begin and/or end inside a tile, and those segments go to the
   // partial-tile slots 2v (range begins inside / at this tile) and 2v+1 (range ends inside it), which
   // gemm_fixup_kernel sums in workgroup order (deterministic).
+  // Grouped order (whole-tile launches on a grid that is a multiple of 8): the 8 XCDs have private L2s, so each XCD walks
+  // its own contiguous stretch of a band-major order — bands of GROUP_M = 4 M-panels, inside a band the N-panel index
+  // outermost.  The Gx = G/8 workgroups of an XCD hold Gx consecutive positions per round = 4 M-panels x Gx/4 N-panels
+  // (4 X panels + 8 W panels instead of ~2 + all of them), and the next round moves on along N inside the same band, so the
+  // band's X panels stay in the XCD's L2 while its W panels stream.
+  constexpr int GROUP_M = 4;
+  const bool grouped = STLT_GEMM_GROUPED && !SK && n_split == 1 && (G & 7) == 0;
+  const int g_xcd = blockIdx.x & 7, g_local = blockIdx.x >> 3, g_gx = G >> 3;
+  const int g_rounds = (n_tiles + G - 1) / G;
   int my_tiles, sk_first = 0, sk_kt0 = 0, sk_tail = 0;
   if (SK) {
     const int total = n_tiles * nk;
@@ -145,6 +157,13 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
     const int last = (s1 - 1) / nk;
     my_tiles = last - sk_first + 1;
     sk_tail = s1 - last * nk;  // == nk when the range ends on a tile boundary
+  } else if (grouped) {
+    // position of this workgroup's it-th tile in the band-major order: XCD x owns positions [x*R*Gx, (x+1)*R*Gx)
+    my_tiles = 0;
+    const int p0 = g_xcd * g_rounds * g_gx + g_local;
+    if (p0 < n_tiles) my_tiles = (n_tiles - p0 + g_gx - 1) / g_gx;
+    if (my_tiles > g_rounds) my_tiles = g_rounds;
+    if (my_tiles <= 0) return;
   } else {
     my_tiles = (n_tiles - v + G - 1) / G;  // tiles v, v+G, v+2G, ...
     if (my_tiles <= 0) return;
@@ -163,6 +182,16 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   };
 
   auto tile_origin = [&](int it, int& m0, int& n0, int& split) {
+    if (grouped) {
+      const int p = (g_xcd * g_rounds + it) * g_gx + g_local;
+      const int band = p / (GROUP_M * tiles_n), w = p - band * (GROUP_M * tiles_n);
+      const int rows = tiles_m - band * GROUP_M < GROUP_M ? tiles_m - band * GROUP_M : GROUP_M;
+      const int tn_g = w / rows;
+      split = 0;
+      m0 = (band * GROUP_M + (w - tn_g * rows)) * BM;
+      n0 = tn_g * BN;
+      return;
+    }
     const int item = SK ? sk_first + it : v + it * G;
     const int tile = item / n_split;
     split = item - tile * n_split;
@@ -644,7 +673,9 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
       const int S = (int)((n_tiles * nk + G - 1) / G);
       dim3 grid((unsigned)G);
       float* P = t_gemm_scratch;
-#define LAUNCH_SK(ACTV, TAV, TBV, ADDV) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, false>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr)
+      static const bool ws_sk = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
+#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr)
+#define LAUNCH_SK(ACTV, TAV, TBV, ADDV) do { if (ws_sk) LAUNCH_SK1(ACTV, TAV, TBV, ADDV, true, dim3(GEMM_THREADS_WS)); else LAUNCH_SK1(ACTV, TAV, TBV, ADDV, false, block); } while (0)
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
       else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
       else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
@@ -652,6 +683,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
       else if (act == STLT_ACT_RELU) LAUNCH_SK(STLT_ACT_RELU, false, false, false);
       else LAUNCH_SK(STLT_ACT_NONE, false, false, false);
 #undef LAUNCH_SK
+#undef LAUNCH_SK1
       if (int e = stlt_check_launch("gemm_nt_kernel(stream-k)")) return e;
       dim3 fgrid((unsigned)(n_tiles * FIXUP_CHUNKS)), fblock(256);
 #define FIX(ACTV) hipLaunchKernelGGL((gemm_fixup_kernel<ACTV>), fgrid, fblock, 0, s, P, S, (int)nk, bias, r, ldr, c, ldc, (int)M, (int)N, (int)tiles_n)

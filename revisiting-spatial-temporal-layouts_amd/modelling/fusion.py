@@ -9,8 +9,9 @@ Differences from the reference, by design of the scope (SURVEY §2 row 17, §8f 
     composes the same arithmetic from the op-level autograd Functions of ``ops.py`` (native forward AND backward kernels
     per op: linear, attention, add+LayerNorm, GELU, the two embedding kernels); a frozen layout branch runs through the
     native forward without a tape, a trainable one through ``StltBackbone.forward_train``.  Dropout (reference
-    models.py:333,341,350,358,368,376 and the appearance encoder's fixed 0.1) is applied with torch's generator at the
-    post-attention / feed-forward sites and with the native counter-based mask on the attention probabilities.
+    models.py:333,341,350,358,368,376 and the appearance encoder's fixed 0.1) is the native counter-based mask everywhere
+    (``ops.dropout`` at the post-attention / feed-forward sites, inside the attention kernel on the probabilities); the
+    appearance encoder's ReLU runs in its product's epilogue.
 As for STLT, the modules only hold parameters.
 """
 from __future__ import annotations
@@ -19,7 +20,6 @@ import ctypes as C
 from typing import Dict
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .. import _lib as L
@@ -128,7 +128,7 @@ class CrossAttentionFusionBackbone(nn.Module):
             k, v = kv[..., :d], kv[..., d:]
         a = ops.AttnFn.apply(q, k, v, kpm, causal, H, p_drop if self.training else 0.0)
         o = ops.LinearFn.apply(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
-        o = F.dropout(o, p_drop, self.training)
+        o = ops.dropout(o, p_drop, self.training)
         return ops.AddLayerNormFn.apply(o, x, blk.ln.weight, blk.ln.bias, self.config.layer_norm_eps)
 
     def _appearance_train(self, feats):
@@ -143,10 +143,10 @@ class CrossAttentionFusionBackbone(nn.Module):
             sa = l.self_attn
             qkv = ops.LinearFn.apply(x, sa.in_proj_weight, sa.in_proj_bias)
             a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], None, False, H, 0.1 if self.training else 0.0)
-            a = F.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), 0.1, self.training)
+            a = ops.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), 0.1, self.training)
             x = ops.AddLayerNormFn.apply(a, x, l.norm1.weight, l.norm1.bias, 1e-5)
-            h = F.dropout(torch.relu(self._lin(x, l.linear1)), 0.1, self.training)
-            h = F.dropout(self._lin(h, l.linear2), 0.1, self.training)
+            h = ops.dropout(ops.LinearFn.apply(x, l.linear1.weight, l.linear1.bias, L.ACT_RELU), 0.1, self.training)
+            h = ops.dropout(self._lin(h, l.linear2), 0.1, self.training)
             x = ops.AddLayerNormFn.apply(h, x, l.norm2.weight, l.norm2.bias, 1e-5)
         return x
 
@@ -181,7 +181,7 @@ class CrossAttentionFusionBackbone(nn.Module):
             la = self._attn_block(m.layout_attn, la, la, kpm, True, p)
             aa = self._attn_block(m.appearance_attn, aa, aa, None, False, p)
             f = self._lin(ops.GeluFn.apply(self._lin(la, m.layout_ffn.linear1)), m.layout_ffn.linear2)
-            Lh = ops.AddLayerNormFn.apply(F.dropout(f, p, self.training), la, m.layout_ffn.ln.weight, m.layout_ffn.ln.bias, eps)
+            Lh = ops.AddLayerNormFn.apply(ops.dropout(f, p, self.training), la, m.layout_ffn.ln.weight, m.layout_ffn.ln.bias, eps)
             Ah = self._attn_block(m.appearance_ffn, aa, aa, None, False, p)
         fused = torch.cat((Lh[idx, last], Ah[:, 0]), dim=-1)
         caf = self._head_train(fusion_head, fused)

@@ -14,7 +14,6 @@ import math
 from typing import Dict, List, Optional
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .. import _lib as L
@@ -280,23 +279,23 @@ class StltBackbone(nn.Module):
 
     # ---- differentiable forward, composed from the op-level autograd Functions of ops.py ----------------------------
     def _encoder_layer_train(self, l: _EncoderLayerParams, x: torch.Tensor, kpm, causal: bool) -> torch.Tensor:
-        """nn.TransformerEncoderLayer as configured at models.py:46-52,118-124 (post-norm, GELU, eps 1e-5); dropout at the
-        post-attention / feed-forward sites with torch's generator, on the attention probabilities with the native
-        counter-based mask."""
+        """nn.TransformerEncoderLayer as configured at models.py:46-52,118-124 (post-norm, GELU, eps 1e-5); dropout with the
+        native counter-based mask at every site (post-attention / feed-forward through `ops.dropout`, the attention
+        probabilities inside the attention kernel)."""
         p, H, d = self.config.hidden_dropout_prob, self.config.num_attention_heads, x.shape[-1]
         sa = l.self_attn
         qkv = ops.LinearFn.apply(x, sa.in_proj_weight, sa.in_proj_bias)
         a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, causal, H, p if self.training else 0.0)
-        a = F.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), p, self.training)
+        a = ops.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), p, self.training)
         x = ops.AddLayerNormFn.apply(a, x, l.norm1.weight, l.norm1.bias, _ENC_EPS)
-        h = F.dropout(ops.GeluFn.apply(ops.LinearFn.apply(x, l.linear1.weight, l.linear1.bias)), p, self.training)
-        h = F.dropout(ops.LinearFn.apply(h, l.linear2.weight, l.linear2.bias), p, self.training)
+        h = ops.dropout(ops.GeluFn.apply(ops.LinearFn.apply(x, l.linear1.weight, l.linear1.bias)), p, self.training)
+        h = ops.dropout(ops.LinearFn.apply(h, l.linear2.weight, l.linear2.bias), p, self.training)
         return ops.AddLayerNormFn.apply(h, x, l.norm2.weight, l.norm2.bias, _ENC_EPS)
 
     def forward_train(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """(B,T,d) backbone output with an autograd graph: what a model that consumes EVERY row of the backbone (the fusion
         models) trains through.  `Stlt` itself trains through the single native reverse sweep instead (`_StltTrainFn`).
-        Layouts of at most 64 frames / 64 object slots (the op-level attention backward)."""
+        Layouts of at most 256 frames / 256 object slots (the op-level attention backward streams keys above 64)."""
         fe = self.frames_embeddings
         le = fe.layout_embedding
         cbe = le.category_box_embeddings
@@ -306,14 +305,14 @@ class StltBackbone(nn.Module):
         x = ops.EmbedFn.apply(cats, batch["boxes"], batch.get("scores"), cbe.category_embeddings.weight, cbe.box_embedding.weight,
                               cbe.box_embedding.bias, cbe.score_embeddings.weight, cbe.score_embeddings.bias, cbe.layer_norm.weight,
                               cbe.layer_norm.bias, eps)
-        x = F.dropout(x, p, self.training).view(B * T, N, -1)
+        x = ops.dropout(x, p, self.training).view(B * T, N, -1)
         kpm_boxes = batch["src_key_padding_mask_boxes"].reshape(B * T, N)
         for l in le.transformer.layers:
             x = self._encoder_layer_train(l, x, kpm_boxes, False)
         cls_rows = x[:, 0].reshape(B, T, -1)  # models.py:79
         g = ops.FramesEmbedFn.apply(cls_rows, batch["frame_types"], fe.position_embeddings.weight, fe.frame_type_embedding.weight,
                                     fe.layer_norm.weight, fe.layer_norm.bias, eps)
-        g = F.dropout(g, p, self.training)
+        g = ops.dropout(g, p, self.training)
         kpm_frames = batch["src_key_padding_mask_frames"]
         for l in self.transformer.layers:
             g = self._encoder_layer_train(l, g, kpm_frames, True)

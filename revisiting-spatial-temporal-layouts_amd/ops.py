@@ -250,22 +250,31 @@ def _scratch(nbytes: int, device) -> torch.Tensor:
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x wᵀ + b (no activation), x (..., K)."""
+    """y = act(x wᵀ + b), x (..., K); act = ACT_NONE or ACT_RELU (the ReLU of the appearance encoder, applied in the
+    product's epilogue; its derivative is taken from the output by ``stlt_relu_bwd``)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, act=L.ACT_NONE):
+        if act not in (L.ACT_NONE, L.ACT_RELU):
+            raise L.StltHipError("LinearFn: activation must be ACT_NONE or ACT_RELU (GELU has its own Function: the tape keeps the pre-activation)")
         x = x.contiguous()
-        ctx.save_for_backward(x, w)
+        y = linear(x, w, b, act=act)
+        ctx.save_for_backward(x, w, y if act == L.ACT_RELU else None)
         ctx.has_bias = b is not None
-        return linear(x, w, b)
+        ctx.act = act
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.load()
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         N, K = w.shape
         M = x.numel() // K
         dy = dy.contiguous()
+        if ctx.act == L.ACT_RELU:
+            dz = torch.empty_like(dy)
+            L.check(lib.stlt_relu_bwd(_p(dy), _p(y), _p(dz), dy.numel(), _stream()), "stlt_relu_bwd")
+            dy = dz
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
         db = torch.zeros(N, device=w.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
@@ -273,7 +282,42 @@ class LinearFn(torch.autograd.Function):
         sc = _scratch(nbytes, x.device)
         L.check(lib.stlt_linear_bwd(_p(x), _p(w), _p(dy), M, N, K, _p(dx), _p(dw), _p(db), sc.data_ptr(), sc.numel(), _stream()),
                 "stlt_linear_bwd")
-        return dx, dw, db
+        return dx, dw, db, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in train mode with the library's counter-based mask (one seed per call from torch's CPU generator, so
+    torch.manual_seed makes a run repeatable); the backward applies the same mask to the gradient."""
+
+    _site = 0x200000  # site ids of their own, apart from AttnFn's
+
+    @staticmethod
+    def forward(ctx, x, p):
+        lib = L.load()
+        x = x.contiguous()
+        p = float(p)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        DropoutFn._site = site = 0x200000 | ((DropoutFn._site + 1) & 0xfffff)
+        y = torch.empty_like(x)
+        L.check(lib.stlt_dropout(_p(x), _p(y), x.numel(), p, seed, site, _stream()), "stlt_dropout")
+        ctx.meta = (p, seed, site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        p, seed, site = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.check(lib.stlt_dropout(_p(dy), _p(dx), dy.numel(), p, seed, site, _stream()), "stlt_dropout")
+        return dx, None
+
+
+def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """F.dropout's call shape on the native kernel: identity in eval mode or at p = 0."""
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p)
 
 
 class AttnFn(torch.autograd.Function):

@@ -168,3 +168,58 @@ def test_fusion_training_step_with_dropout_runs(pkg):
         opt.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses))
+
+
+@pytest.mark.gpu
+def test_lcf_training_path_matches_golden_and_oracle_gradients(pkg):
+    """LCF under autograd: the fusion backbone's op-level composition with zero cross-modal layers; logits = the reference's,
+    gradients = torch autograd on the oracle."""
+    import torch.nn.functional as F
+    z, meta, sd, batch, c = _case(pkg.synth, "lcf")
+    m = pkg.LateConcatenationFusion(pkg.MultimodalModelConfig(**dict(pkg.synth.model_kwargs(NAME), **EXTRA)))
+    m.load_state_dict(sd, strict=True)
+    m.train(False).to("cuda")
+    out = m({k: v.to("cuda") for k, v in batch.items()})["lcf"]
+    assert out.requires_grad and np.abs(out.detach().cpu().numpy() - z["lcf"]).max() <= 1e-4
+    labels = torch.randint(0, 174, (meta["batch"],), generator=torch.Generator().manual_seed(2))
+    F.cross_entropy(out, labels.to("cuda")).backward()
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    F.cross_entropy(CO.lcf_forward(leaves, batch, c["num_attention_heads"])["lcf"], labels).backward()
+    checked = 0
+    for k, prm in m.named_parameters():
+        g_ref = leaves[k].grad
+        if prm.grad is None or g_ref is None:
+            assert (g_ref is None or g_ref.abs().max().item() == 0.0) and (prm.grad is None or prm.grad.abs().max().item() == 0.0), k
+            continue
+        assert (prm.grad.cpu() - g_ref).abs().max().item() / max(g_ref.abs().max().item(), 1e-6) <= 5e-4, k
+        checked += 1
+    assert checked > 150
+
+
+@pytest.mark.gpu
+def test_fusion_training_with_long_layouts_runs_through_the_streamed_attention_backward(pkg):
+    """T = 100 frames (> 64): the layout branch's temporal attention and the cross-attention onto the layout tokens train
+    through the streamed backward; gradients against torch autograd on the oracle."""
+    import torch.nn.functional as F
+    kw = dict(pkg.synth.model_kwargs(NAME), **EXTRA)
+    kw["layout_num_frames"] = 128
+    T = 100
+    m = pkg.CrossAttentionFusion(pkg.MultimodalModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=11)
+    m.load_state_dict(sd)
+    m.train(False).to("cuda")
+    c = pkg.synth.CONFIGS[NAME]
+    batch = pkg.synth.make_batch(2, T, c["N"], seed=3)
+    batch["appearance_features"] = pkg.synth.make_appearance_features(2, seed=4)
+    labels = torch.tensor([5, 9])
+    F.cross_entropy(m({k: v.to("cuda") for k, v in batch.items()})["caf"], labels.to("cuda")).backward()
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    F.cross_entropy(CO.caf_forward(leaves, batch, c["num_attention_heads"])["caf"], labels).backward()
+    checked = 0
+    for k, prm in m.named_parameters():
+        g_ref = leaves[k].grad
+        if prm.grad is None or g_ref is None or g_ref.abs().max().item() == 0.0:
+            continue
+        assert (prm.grad.cpu() - g_ref).abs().max().item() / g_ref.abs().max().item() <= 1e-3, k
+        checked += 1
+    assert checked > 150

@@ -284,7 +284,10 @@ def test_linear_autograd(pkg, M, N, K):
 
 
 @pytest.mark.parametrize("Lq,Lk,causal,packed", [(32, 33, False, False), (33, 32, False, False), (7, 7, False, True), (32, 32, True, True),
-                                                  (64, 64, True, True), (5, 61, False, False)])
+                                                  (64, 64, True, True), (5, 61, False, False),
+                                                  # above 64 tokens on either side: the streamed backward (query tiles of 32, keys in tiles)
+                                                  (100, 100, True, True), (65, 33, False, False), (33, 130, False, False), (256, 256, True, True),
+                                                  (70, 70, False, True)])
 def test_attention_autograd(pkg, Lq, Lk, causal, packed):
     S, H = 3, 4
     d = 64 * H
@@ -392,3 +395,35 @@ def test_linear_randomised_shapes_plain_and_stream_k(pkg):
         worst = max(worst, e1, e2)
         assert e1 <= tol and e2 <= tol, (M, N, K, act, e1, e2)
     print(f"worst abs error over 40 random linear problems: {worst:.2e}")
+
+
+def test_dropout_op_mask_scale_and_backward(pkg):
+    """ops.dropout: counter-based mask with the expected keep rate, survivors scaled by 1/(1-p), the backward applies the
+    same mask, identity in eval mode / at p = 0, odd element counts."""
+    for n, p in (((257, 33), 0.1), ((1000003,), 0.5), ((4, 768), 0.25)):
+        x = _leaf(_rand(*n, seed=2) + 3.0)  # no zeros in the input: a zero in the output is a dropped element
+        y = pkg.ops.dropout(x, p, True)
+        kept = y != 0
+        rate = kept.float().mean().item()
+        assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / x.numel()) ** 0.5 + 1e-3, (n, p, rate)
+        assert (y[kept] - x.detach()[kept] / (1 - p)).abs().max().item() <= 1e-6 * 8
+        g = _rand(*n, seed=3).to(DEV)
+        y.backward(g)
+        assert (x.grad[kept] - g[kept] / (1 - p)).abs().max().item() <= 1e-6 * 8 and (x.grad[~kept] == 0).all()
+    x = _leaf(_rand(5, 7, seed=1))
+    assert pkg.ops.dropout(x, 0.3, False) is x and pkg.ops.dropout(x, 0.0, True) is x
+
+
+def test_linear_relu_autograd(pkg):
+    """LinearFn with the ReLU in the product's epilogue: forward and all three gradients against torch (fp64)."""
+    M, N, K = 300, 96, 64
+    x, w, b, g = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.2), _rand(N, seed=3), _rand(M, N, seed=4)
+    xd, wd, bd = _leaf(x), _leaf(w), _leaf(b)
+    y = pkg.ops.LinearFn.apply(xd, wd, bd, pkg._lib.ACT_RELU)
+    y.backward(g.to(DEV))
+    x64, w64, b64 = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ref = torch.relu(x64 @ w64.t() + b64)
+    ref.backward(g.double())
+    assert (y.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-5
+    for got, r in ((xd.grad, x64.grad), (wd.grad, w64.grad), (bd.grad, b64.grad)):
+        assert (got.cpu().double() - r).abs().max().item() / max(r.abs().max().item(), 1e-6) <= 2e-5
