@@ -666,7 +666,8 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   const int64_t n_tiles = tiles_m * tiles_n, nk = K / BK;
   const int64_t rounds = (n_tiles + n_cu() - 1) / n_cu();
   const double fill = (double)n_tiles / (double)(rounds * n_cu());
-  if (n_split == 1 && t_gemm_scratch && fill < 0.9 && n_tiles * nk < 0x7fffffffLL && !g_stlt_debug_buf) {
+  static const double sk_fill = [] { const char* e = getenv("STLT_GEMM_SK_FILL"); return e ? atof(e) : 0.9; }();  // A/B knob
+  if (n_split == 1 && t_gemm_scratch && fill < sk_fill && n_tiles * nk < 0x7fffffffLL && !g_stlt_debug_buf) {
     int64_t G = n_cu() < STLT_GEMM_SK_MAX_WG ? n_cu() : STLT_GEMM_SK_MAX_WG;
     if (n_tiles * nk < 4 * G) G = (n_tiles * nk + 3) / 4;  // at least ~4 k-steps per workgroup
     if (t_gemm_scratch_bytes >= (size_t)(2 * G) * BM * BN * sizeof(float)) {

@@ -33,6 +33,11 @@ def main():
         M = B * T
         shapes += [("tp qkv", M, 3 * d, d, 0), ("tp out", M, d, d, 0), ("tp ffn1", M, 4 * d, d, 1), ("tp ffn2", M, d, 4 * d, 0)]
     dev = "cuda"
+    # lend the stream-K scratch, as the whole-path entry points do from their workspace: under-filled launches then run
+    # the way they run inside the model
+    lib = pkg._lib.load()
+    scratch = torch.empty(int(lib.stlt_gemm_scratch_bytes()), dtype=torch.uint8, device=dev)
+    pkg._lib.check(lib.stlt_gemm_set_scratch(scratch.data_ptr(), scratch.numel()), "stlt_gemm_set_scratch")
     g = torch.Generator(device=dev).manual_seed(0)
     tot_f = tot_t = 0.0
     for name, M, Nn, K, act in shapes:

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel statistics and the two PMC passes of the default bench command,
 # written to gpurun_out/ (copy what should be judged into profiles/).  python3 goes straight after `--`.
 R=${GRAFT_REPO_ROOT:-$PWD}
-tag=${1:-round1}
+tag=${1:-round2}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 cd /tmp

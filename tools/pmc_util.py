@@ -12,7 +12,10 @@ import csv, glob, json, os, re, sys
 
 
 def family(name):
-    m = re.search(r"(gemm_nt_kernel<\d|gemm_fixup_kernel|attn_core_kernel<false, (?:true|false)>|[a-z_0-9]+_kernel)", name)
+    m = re.search(r"attn_core_kernel<(?:true|false), (true|false), (true|false)>", name)
+    if m:  # <STAMP, VARLEN, CAUSAL>
+        return "attn_core_kernel/" + ("ragged-" if m.group(1) == "true" else "") + ("temporal" if m.group(2) == "true" else "spatial")
+    m = re.search(r"(gemm_nt_kernel<\d|gemm_fixup_kernel|[a-z_0-9]+_kernel)", name)
     return m.group(1) if m else name[:40]
 
 
