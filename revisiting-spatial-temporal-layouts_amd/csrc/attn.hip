@@ -86,12 +86,16 @@ struct AttnGeo {
   int64_t n_items; int reverse;
 };
 
+// 32-bit index arithmetic throughout (the launchers bound items and tokens by 2^31): the 64-bit divisions this replaced
+// were a visible part of a wave's first item, which is all a small launch consists of.
 template <bool VARLEN>
-__device__ __forceinline__ StepGeo step_geo(int64_t item, int kt, const AttnGeo& a) {
+__device__ __forceinline__ StepGeo step_geo(int64_t item64, int kt, const AttnGeo& a) {
   StepGeo s;
-  if (a.reverse) item = a.n_items - 1 - item;
-  s.head = (int)(item % a.H);
-  const int64_t tile_id = item / a.H;
+  unsigned item = (unsigned)item64;
+  if (a.reverse) item = (unsigned)a.n_items - 1u - item;
+  const unsigned H = (unsigned)a.H;
+  const unsigned tile_id = item / H;
+  s.head = (int)(item - tile_id * H);
   if (VARLEN) {
     s.qb = 0;
     s.q_tok0 = 0;
@@ -106,12 +110,13 @@ __device__ __forceinline__ StepGeo step_geo(int64_t item, int kt, const AttnGeo&
     s.kt_end = (khi - klo + TILE - 1) / TILE;
     return s;
   }
-  const int64_t g = tile_id / a.ntq;
-  s.qb = (int)(tile_id % a.ntq);
-  s.q_tok0 = g * a.GLq;
-  s.k_tok0 = g * a.GLk;
-  const int gq = (int)((a.nq_tokens - s.q_tok0) < a.GLq ? (a.nq_tokens - s.q_tok0) : a.GLq);
-  const int gk = (int)((a.nk_tokens - s.k_tok0) < a.GLk ? (a.nk_tokens - s.k_tok0) : a.GLk);
+  const unsigned g = tile_id / (unsigned)a.ntq;
+  s.qb = (int)(tile_id - g * (unsigned)a.ntq);
+  s.q_tok0 = (int64_t)(g * (unsigned)a.GLq);
+  s.k_tok0 = (int64_t)(g * (unsigned)a.GLk);
+  const int left_q = (int)a.nq_tokens - (int)s.q_tok0, left_k = (int)a.nk_tokens - (int)s.k_tok0;
+  const int gq = left_q < a.GLq ? left_q : a.GLq;
+  const int gk = left_k < a.GLk ? left_k : a.GLk;
   s.q_first = s.qb * TILE;
   s.q_rows = gq - s.q_first < TILE ? gq - s.q_first : TILE;
   s.k_first = kt * TILE;
@@ -355,7 +360,8 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
   g.H = (int)H; g.causal = causal;
   g.seg_start = nullptr; g.seg_end = nullptr;
   const int64_t groups = (S + P - 1) / P;
-  if (groups * g.ntq * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles");
+  if (groups * g.ntq * H > 0x7fffffffLL || g.nq_tokens > 0x7fffffffLL || g.nk_tokens > 0x7fffffffLL)
+    return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles / tokens (32-bit index arithmetic)");
   StltProfScope ps(kid, s);
   const int64_t n_items = groups * g.ntq * H;
   g.n_items = n_items;

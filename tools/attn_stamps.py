@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("revisiting-spatial-temporal-layouts_amd")
 lib = pkg._lib.load()
 NAMES = ["issue loads", "wait data", "QK^T", "mask+softmax", "P.V", "epilogue->LDS", "stores+drain"]
-for (S, L, causal) in ((1024, 32, True), (32768, 7, False)):
+for (S, L, causal) in ((64, 32, True), (256, 32, True), (1024, 32, True), (32768, 7, False), (4096, 36, False)):
     H = 12; d = 64 * H
     qkv = torch.randn(S, L, 3 * d, device="cuda"); kpm = torch.zeros(S, L, dtype=torch.bool, device="cuda")
     P = 32 // L if L <= 16 else 1
