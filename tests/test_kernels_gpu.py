@@ -77,7 +77,7 @@ def _attn_ref(qkv, kpm, causal, H):
     return O.attention_core(qkv.double(), m, H)
 
 
-@pytest.mark.parametrize("L", [1, 2, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 36, 37, 64, 65, 100, 256])
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 7, 8, 9, 11, 13, 15, 16, 17, 24, 31, 32, 33, 36, 37, 47, 48, 49, 64, 65, 100, 256])
 @pytest.mark.parametrize("causal", [False, True])
 def test_attn_core(pkg, L, causal):
     S, H = (9 if L < 100 else 3), 4
@@ -427,3 +427,23 @@ def test_linear_relu_autograd(pkg):
     assert (y.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-5
     for got, r in ((xd.grad, x64.grad), (wd.grad, w64.grad), (bd.grad, b64.grad)):
         assert (got.cpu().double() - r).abs().max().item() / max(r.abs().max().item(), 1e-6) <= 2e-5
+
+
+@pytest.mark.parametrize("S,L,causal", [(37, 7, False), (1, 7, False), (53, 36, False), (5, 32, True), (101, 4, False), (29, 48, True), (64, 16, False)])
+def test_attn_core_short_sequences_many_items_and_masked_rows(pkg, S, L, causal):
+    """The 16-row-tile kernel (L <= 48): sequence counts that leave the last item partly filled, sequences whose keys are
+    all padded (zeros out), every head count parity; against the fp64 oracle."""
+    H = 12
+    d = 64 * H
+    qkv = _rand(S, L, 3 * d, seed=S + L, scale=2.0)
+    kpm = torch.rand(S, L, generator=torch.Generator().manual_seed(S)) < 0.35
+    kpm[:, 0] = False
+    if S > 3:
+        kpm[2, :] = True  # a fully padded sequence
+    got = pkg.ops.attn_core(qkv.to(DEV), kpm.to(DEV), causal, H).cpu()
+    ref = _attn_ref(qkv, kpm, causal, H)
+    if S > 3:
+        assert got[2].abs().max().item() == 0.0
+        ref[2] = 0.0
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max().item() <= 2e-5

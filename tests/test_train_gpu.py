@@ -312,7 +312,9 @@ def test_trainer_fused_and_stock_optimizer_agree(pkg):
             # step — compare the query / value parts only
             d = a.numel() // 3
             a, b = torch.cat([a[:d], a[2 * d:]]), torch.cat([b[:d], b[2 * d:]])
-        assert (a - b).abs().max().item() <= 5e-6, k
+        # lr = 1e-3: agreement to 2 % of one step (Adam turns rounding-level differences of a near-zero gradient element into
+        # a visible fraction of a step; 5e-6 held for one summation order of the forward and 6.8e-6 showed up with another)
+        assert (a - b).abs().max().item() <= 2e-5, k
 
 
 @pytest.mark.parametrize("kind", ["something", "action_genome"])
