@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict_
   float* dx = dlogits + b * K;
   if (kind == STLT_LOSS_CROSS_ENTROPY) {
     int64_t y = static_cast<const int64_t*>(labels)[b];
-    y = y < 0 ? 0 : (y >= K ? K - 1 : y);
+    if (y < 0 || y >= K) {  // torch raises on an out-of-range class index; here the row's loss and gradient become NaN, which
+      const float nan = __builtin_nanf("");  // the mean loss, the gradient norm and every later step then show
+      for (int k = threadIdx.x; k < K; k += 256) dx[k] = nan;
+      if (threadIdx.x == 0) row_loss[b] = nan;
+      return;
+    }
     float m = -INFINITY;
     for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, x[k]);
     m = block_reduce(m, red, true);

@@ -208,9 +208,9 @@ class StltBackbone(nn.Module):
         return super()._apply(fn, *a, **kw)
 
     def _sentinel(self):
-        w0 = self.frames_embeddings.position_embeddings.weight
-        w1 = self.transformer.layers[-1].norm2.bias if len(self.transformer.layers) else w0
-        return (w0.data_ptr(), w1.data_ptr(), w0.device)
+        """Identity of every parameter's storage: the cached C table holds raw device pointers, so rebinding any
+        parameter (`p.data = …`, an EMA / SWA swap, pruning, replacing a Parameter) must rebuild it."""
+        return tuple(q.data_ptr() for q in self.parameters())
 
     def _build_struct(self, head: Optional["ClassificationHead"], ptr):
         """Fill a stlt_params table; `ptr(tensor)` yields the device pointer to store for that parameter (its data
@@ -251,7 +251,7 @@ class StltBackbone(nn.Module):
         return p, sp, tp  # keep the layer arrays alive with the struct
 
     def c_params(self, head: Optional["ClassificationHead"] = None):
-        key = (self._sentinel(), None if head is None else head.fc2.weight.data_ptr())
+        key = (self._sentinel(), None if head is None else tuple(q.data_ptr() for q in head.parameters()))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         self._cache = (key, self._build_struct(head, _dev_ptr))

@@ -484,3 +484,39 @@ class FramesEmbedFn(torch.autograd.Function):
         L.check(lib.stlt_frames_embed_bwd(_p(d_pre), _p(frame_types), B, T, d, _p(g_pos), _p(g_type), sc.data_ptr(), sc.numel(), _stream()),
                 "stlt_frames_embed_bwd")
         return d_pre, None, g_pos, g_type, g_ln_w, g_ln_b, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device guard: every wrapper above launches on `torch.cuda.current_stream()`, which belongs to the CURRENT device.  A
+# caller that holds tensors on another GPU of the same process (cuda:1 while cuda:0 is current) must still get its kernels
+# on the tensors' device, so each public wrapper and each autograd Function runs under `torch.cuda.device(<first tensor>)`.
+def _guarded(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index == torch.cuda.current_device():
+                    break
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+
+    return wrapper
+
+
+def _install_device_guards():
+    import types
+    g = globals()
+    for name, obj in list(g.items()):
+        if name.startswith("_") or name in ("prof_enable", "prof_collect", "prof_take_gemm_flops", "workspace_bytes", "dropout"):
+            continue
+        if isinstance(obj, types.FunctionType) and obj.__module__ == __name__:
+            g[name] = _guarded(obj)
+        elif isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function:
+            obj.forward = staticmethod(_guarded(obj.forward))
+            obj.backward = staticmethod(_guarded(obj.backward))
+
+
+_install_device_guards()

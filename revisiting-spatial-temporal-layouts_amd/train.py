@@ -224,6 +224,12 @@ class Trainer:
         """Run over an iterable of GLOBAL batches, each rank taking its contiguous shard."""
         log = []
         for batch in batches:
+            n = batch["categories"].shape[0]
+            if self.world > 1 and n % self.world != 0:
+                # the loss is a batch mean and the gradients are averaged with 1/world: unequal shards would weight clips
+                # unequally, and a rank without clips would leave the others waiting in the all-reduce
+                raise ValueError(f"global batch of {n} clips does not divide over {self.world} ranks: drop or pad the last batch "
+                                 f"(DataLoader(drop_last=True)), as DistributedSampler does")
             mine = D.shard_batch(batch, self.rank, self.world)
             mine = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in mine.items()}
             out = self.step(mine)

@@ -45,3 +45,28 @@ def test_two_rank_launch_line():
     j = _last_json(r.stdout)
     assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["config"]["global_batch"] == 128 and j["value"] > 0
     assert "cpu_baseline" not in j  # rank 0 at N = 1 only
+
+
+def test_train_mode_single_process_line():
+    r = subprocess.run([sys.executable, "bench.py", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "8"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["value"] > 0 and "train step" in j["metric"]
+    assert j["roofline"]["bound"] == "mfma" and j["roofline"]["flops_per_step"] > 0 and 0 < j["roofline"]["frac"] < 1
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "port"
+    assert j["loss"] == j["loss"] and j["grad_norm"] > 0  # finite
+
+
+def test_train_mode_two_rank_launch_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, STLT_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--mode", "train", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["value"] > 0
+    assert "all-reduce" in j["config"]["parallelism"] and "cpu_baseline" not in j

@@ -143,3 +143,16 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     pkg = importlib.import_module(PKG_NAME)
     assert int(ver) == 100 and int(ws) == pkg.ops.workspace_bytes(8, 32, 7, 768, 174) and int(sk) == 64 * 1024 * 1024
     assert int(rc) == -1 and "null" in out[1]  # argument error reported through the C-ABI, message available
+
+
+def test_trainer_fit_refuses_a_global_batch_that_does_not_divide_over_the_ranks():
+    """Equal shards are what makes the per-rank mean losses / 1/world gradient average equal the global-batch step; an
+    uneven (or empty) shard must be an error, not a silently different optimisation step or a hang in the all-reduce."""
+    import importlib
+    import pytest
+    import torch
+    T = importlib.import_module("revisiting-spatial-temporal-layouts_amd.train")
+    tr = T.Trainer(torch.nn.Linear(4, 2), "something", world=4, rank=1, fused_optimizer=False)
+    batch = {"categories": torch.zeros(6, 3, 2, dtype=torch.int64), "labels": torch.zeros(6, dtype=torch.int64)}
+    with pytest.raises(ValueError, match="does not divide"):
+        tr.fit([batch], "cpu")

@@ -447,3 +447,13 @@ def test_trainer_step_leaves_the_model_usable_by_a_plain_autograd_loop(pkg):
     F.cross_entropy(m(dev_batch)["stlt"], dev_batch["labels"]).backward()
     got = [q.grad is not None for k, q in m.named_parameters() if "prediction_head" in k]
     assert got and all(got)
+
+
+def test_fused_criterion_flags_an_out_of_range_label(pkg):
+    """torch raises on a class index outside [0, K); the fused criterion makes the loss (and that row's gradient) NaN instead
+    of training on a clamped label."""
+    x = torch.randn(5, 7, generator=torch.Generator().manual_seed(0)).to(DEV)
+    y = torch.tensor([0, 6, 7, 2, -1])
+    loss, dl = pkg.train.fused_criterion(x, y.to(DEV), "something")
+    assert torch.isnan(loss)
+    assert torch.isnan(dl[2]).all() and torch.isnan(dl[4]).all() and torch.isfinite(dl[[0, 1, 3]]).all()
