@@ -82,22 +82,29 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu):
         t = torch.tensor([elapsed], device="cpu" if one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank != 0:
-        return None
     ms_per_step = elapsed / args.steps * 1e3
+    # per-kernel timing leg: the steps hold collectives when world > 1, so every rank runs them (rank 0 alone reports)
+    k_ms, gflops = {}, 0.0
     try:
         pkg.ops.prof_take_gemm_flops()
-        pkg.ops.prof_enable(True)
-        for _ in range(args.steps):
-            tr.step(batch)
-        torch.cuda.synchronize(dev)
-        prof = pkg.ops.prof_collect()
-        gflops = pkg.ops.prof_take_gemm_flops() / args.steps
-        pkg.ops.prof_enable(False)
-        k_ms = {k: (ms / args.steps, int(n / args.steps)) for k, (ms, n) in prof.items()}
+        pkg.ops.prof_enable(rank == 0)
+        try:
+            for _ in range(args.steps):
+                tr.step(batch)
+            torch.cuda.synchronize(dev)
+            if rank == 0:
+                prof = pkg.ops.prof_collect()
+                gflops = pkg.ops.prof_take_gemm_flops() / args.steps
+                k_ms = {k: (ms / args.steps, int(n / args.steps)) for k, (ms, n) in prof.items()}
+        finally:
+            pkg.ops.prof_enable(False)
     except Exception as exc:  # the roofline leg must never cost the main line
+        if world > 1:
+            raise  # a rank that stops stepping would leave the others waiting in the all-reduce
         print(f"[bench] per-kernel timing failed: {type(exc).__name__}: {exc}", file=sys.stderr)
         k_ms, gflops = {}, 0.0
+    if rank != 0:
+        return None
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     gemm_tflops = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     out = {
@@ -158,6 +165,9 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu):
 
 
 def main():
+    if os.environ.get("STLT_BENCH_FAULT_DUMP"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["STLT_BENCH_FAULT_DUMP"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -294,10 +304,10 @@ def main():
             "roofline": {"kernel": "gemm_nt_kernel (f32 MFMA nn.Linear)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                          "traffic": traffic_gemm, "traffic_note": "avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), profiles/round2_traffic_pmc.json", "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
-            "roofline_attn_temporal": {"kernel": "attn_core_kernel (causal, L=T)", "bound": "hbm", "achieved": round(at_gbs, 1),
+            "roofline_attn_temporal": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=true> for T <= 64 (16-row tiles), attn_core_kernel beyond", "bound": "hbm", "achieved": round(at_gbs, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at_gbs / HBM_PEAK_GBS, 4),
-                                       "traffic": traffic_attn, "traffic_note": "bytes/launch of the temporal kernel (its own symbol, attn_core_kernel<false, false, true>), L2 memory-side, profiles/round2_traffic_pmc.json; algorithmic " + str(int(at_bytes)), "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
-            "roofline_attn_spatial": {"kernel": "attn_core_kernel (key padding, L=N)", "bound": "hbm", "achieved": round(as_gbs, 1),
+                                       "traffic": traffic_attn, "traffic_note": "bytes/launch of the temporal kernel (its own symbol: the CAUSAL=true instantiation), L2 memory-side, profiles/round2_traffic_pmc.json; algorithmic " + str(int(at_bytes)), "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
+            "roofline_attn_spatial": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=false> for N <= 64 (16-row tiles; frames packed per block for N <= 16), attn_core_kernel beyond", "bound": "hbm", "achieved": round(as_gbs, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(as_gbs / HBM_PEAK_GBS, 4),
                                       "traffic": traffic_attn_sp, "launches_per_step": as_n, "us_per_launch": round(as_ms / max(as_n, 1) * 1e3, 2)},
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},

@@ -364,7 +364,7 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
     return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles / tokens (32-bit index arithmetic)");
   StltProfScope ps(kid, s);
   // short self-attention on a packed buffer without dropout: the 16-row-tile kernel (attn16.hip)
-  if (Lq == Lk && Lq <= 48 && !dr.thr && k == q + H * dh && v == q + 2 * H * dh && ldq == 3 * H * dh && ldkv == ldq && !g_stlt_debug_buf) {
+  if (Lq == Lk && Lq <= 64 && !dr.thr && k == q + H * dh && v == q + 2 * H * dh && ldq == 3 * H * dh && ldkv == ldq && !g_stlt_debug_buf) {
     const int rc = launch_attn16(q, kpm, causal, S, Lq, H, ctx, attn_reverse_order(), s);
     if (rc != 0) return rc == 1 ? 0 : rc;
   }

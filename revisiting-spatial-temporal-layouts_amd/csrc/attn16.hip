@@ -1,27 +1,33 @@
-// K3, 16-row tiles: the attention core for self-attention over short sequences (L <= 48 tokens on a packed QKV buffer,
+// K3, 16-row tiles: the attention core for self-attention over short sequences (L <= 64 tokens on a packed QKV buffer,
 // no dropout) on v_mfma_f32_16x16x4_f32.  attn.hip's 32x32 tiles are exact for L = 32 / 64 and for 4 x 7-token frames, but
 // a 36-token sequence (cfg4: N = 36) costs them four (query tile, key tile) steps of which 68 % is padding, and a wave
-// needs 64 dependent 64-cycle MFMAs per (sequence, head).  Here an item is up to three 16-row blocks:
-//   FULL  (16 < L <= 48): one sequence = NB = ceil(L/16) blocks; every (query block, key block) pair, or the lower
+// needs 64 dependent 64-cycle MFMAs per (sequence, head).  Here an item is up to four 16-row blocks:
+//   FULL  (16 < L <= 64): one sequence = NB = ceil(L/16) blocks; every (query block, key block) pair, or the lower
 //         triangle when causal — cfg2 temporal (T = 32): 3 pairs instead of a 32x32 tile; cfg4 spatial (N = 36): 9 pairs of
-//         16x16 instead of 4 of 32x32;
+//         16x16 instead of 4 of 32x32; cfg4 temporal (T = 64): 10 pairs;
 //   DIAG  (L <= 16): P = floor(16/L) whole sequences per block, NB independent blocks per item, diagonal pairs only —
 //         cfg2 spatial (N = 7): 2 frames per block.
-// Same dataflow as attn.hip: S^T = K·Q^T with swapped operands (a query's scores sit in 4 lanes x 4 registers per key
-// block: row max / sum are in-register + two shuffles, and the probabilities are already the B operand of O^T += V^T·P^T),
-// Q and K fragments straight from global memory in operand shape, V by LDS-DMA into a swizzled tile, the next item's
-// loads issued as soon as Q·K^T has consumed the fragment registers.  All of an item's scores fit in registers (<= 36),
-// so the softmax is one pass (no running maximum).  The output leaves without an LDS transpose: lane (query, g) holds 4
-// consecutive channels per channel block = one 16-byte store.  Bit-for-bit it is a different summation order than
-// attn.hip (16-key blocks); both are tested against the same fp64 oracle.
+// Dataflow: S^T = K·Q^T with swapped operands (a query's scores sit in 4 lanes x 4 registers per key block: row max / sum
+// are in-register + two shuffles, and the probabilities are already the B operand of O^T += V^T·P^T), Q and K fragments
+// straight from global memory in operand shape, V by LDS-DMA into a swizzled tile.  A wave works through an item one
+// query block at a time — its Q·K^T blocks, one-pass softmax (all of a query's scores are in registers), P·V, store —
+// holding the K fragments of every block, one query block's Q fragments, NB score and 4 output accumulators: half the
+// registers and LDS of a schedule that computes every score block first (measured: 8 instead of 6 waves per CU at three
+// blocks, cfg4 spatial 524 -> 403 us).  The next query block's Q fragments are fetched while this one's softmax runs; the
+// next item's K / Q fragments as soon as the last Q·K^T has consumed the registers, its V tile as soon as the last P·V
+// has read the (single) V buffer.  The output leaves without an LDS transpose: lane (query, g) holds 4 consecutive
+// channels per channel block = one 16-byte store.
+// SPLIT (small grids): the unit of work is (item, query block) instead of item, so that a launch with fewer items than
+// wave slots spreads over NB times as many waves and each wave's dependent chain is one query block long; a unit loads
+// only the key / value blocks it uses.
+// Bit-for-bit it is a different summation order than attn.hip (16-key blocks); both are tested against the same fp64 oracle.
 #include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int DH16 = 64;
-// independent waves per workgroup: 4, or 2 with three blocks per item (24.8 KB of LDS per wave: 2 waves x 3 workgroups fit a CU)
-template <int NB> struct Waves16 { static constexpr int value = NB == 3 ? 2 : 4; };
+constexpr int WAVES16 = 4;  // independent waves per workgroup
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
@@ -36,62 +42,89 @@ struct Geo16 {
   float scale;
 };
 
-template <int NB, bool FULL, bool CAUSAL>
-__global__ __launch_bounds__(64 * Waves16<NB>::value) void attn16_kernel(const Geo16 geo) {
-  constexpr int WAVES16 = Waves16<NB>::value;
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT>
+__global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
+  static_assert(FULL || !SPLIT, "DIAG items are independent blocks already");
   constexpr int VROWS = NB * 16;
-  __shared__ __attribute__((aligned(16))) float smem_all[WAVES16 * (2 * VROWS * DH16 + VROWS)];
+  __shared__ __attribute__((aligned(16))) float smem_all[WAVES16 * (VROWS * DH16 + VROWS)];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* smem = smem_all + wave * (2 * VROWS * DH16 + VROWS);
-  int* kmeta = reinterpret_cast<int*>(smem + 2 * VROWS * DH16);
+  float* Vs = smem_all + wave * (VROWS * DH16 + VROWS);
+  int* kmeta = reinterpret_cast<int*>(Vs + VROWS * DH16);
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int H = geo.H, L = geo.L, d = H * DH16;
   const int64_t ld = 3 * (int64_t)d;
   const int stride = gridDim.x * WAVES16;
-  int item = blockIdx.x * WAVES16 + wave;
-  if (item >= geo.n_items) return;
+  const int n_units = SPLIT ? geo.n_items * NB : geo.n_items;
+  int unit = blockIdx.x * WAVES16 + wave;
+  if (unit >= n_units) return;
 
+  // does query block qb use key block kb
+  auto used = [&](int kb, int qb) __attribute__((always_inline)) { return FULL ? (!CAUSAL || kb <= qb) : kb == qb; };
   // token of block b, local row r of an item that starts at token t0; -1 = no such row
-  auto row_token = [&](int t0, int b, int r) {
+  auto row_token = [&](int t0, int b, int r) __attribute__((always_inline)) {
     const int local = FULL ? b * 16 + r : r;
     const int limit = FULL ? L : geo.P * L;
     const int tok = FULL ? t0 + local : t0 + b * geo.P * L + r;
     return (local < limit && tok < geo.n_tokens) ? tok : -1;
   };
-  auto item_geo = [&](int it, int& t0, int& head) {
-    const unsigned u = geo.reverse ? (unsigned)geo.n_items - 1u - (unsigned)it : (unsigned)it;
-    const unsigned grp = u / (unsigned)H;
-    head = (int)(u - grp * (unsigned)H);
+  // a valid token to read in place of an absent row of block b (such rows are masked / never stored)
+  auto spare_token = [&](int t0, int b) __attribute__((always_inline)) {
+    int last = FULL ? t0 + L - 1 : t0 + b * geo.P * L + geo.P * L - 1;
+    if (last > geo.n_tokens - 1) last = geo.n_tokens - 1;
+    return last < 0 ? 0 : last;
+  };
+  // unit -> first token of its item, head, and (SPLIT) its query block: the long blocks of a causal item go first
+  auto unit_geo = [&](int u, int& t0, int& head, int& qb0) __attribute__((always_inline)) {
+    unsigned it = (unsigned)u;
+    qb0 = 0;
+    if (SPLIT) {
+      it = (unsigned)u / (unsigned)NB;
+      qb0 = NB - 1 - (int)((unsigned)u - it * (unsigned)NB);
+    }
+    if (geo.reverse) it = (unsigned)geo.n_items - 1u - it;
+    const unsigned grp = it / (unsigned)H;
+    head = (int)(it - grp * (unsigned)H);
     t0 = (int)(grp * (unsigned)geo.rows_per_item);
   };
+  // row metadata, the same encoding for keys and queries: -1 = absent, else (sequence in block << 8) | position
+  auto row_meta = [&](int b) __attribute__((always_inline)) {
+    const int local = FULL ? b * 16 + li : li;
+    return ((FULL ? 0 : local / L) << 8) | (FULL ? local : local % L);
+  };
 
-  f32x4 qf[NB][4], kf[NB][4];
-  int pad[NB];  // key metadata of this lane's row in every block: -1 = masked / absent, else (sequence << 8) | position
-  auto load_item = [&](int it, int buf) {
-    int t0, head;
-    item_geo(it, t0, head);
-    const float* base = geo.qkv + head * DH16 + 4 * lg;
+  f32x4 kf[NB][4], qc[4];
+  int pad[NB];  // key metadata of this lane's row in every block (-1 also for padded keys)
+  auto load_k = [&](int u) __attribute__((always_inline)) {
+    int t0, head, qb0;
+    unit_geo(u, t0, head, qb0);
+    const float* base = geo.qkv + head * DH16 + 4 * lg + d;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      if (SPLIT && !used(b, qb0)) continue;
       const int tok = row_token(t0, b, li);
-      int last = FULL ? t0 + L - 1 : t0 + b * geo.P * L + geo.P * L - 1;
-      if (last > geo.n_tokens - 1) last = geo.n_tokens - 1;
-      if (last < 0) last = 0;
-      const int tk = tok >= 0 ? tok : last;  // rows past the end re-read a valid row; they are masked / never stored
+      const int tk = tok >= 0 ? tok : spare_token(t0, b);
       const float* row = base + (int64_t)tk * ld;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        qf[b][c] = *reinterpret_cast<const f32x4*>(row + 16 * c);
-        kf[b][c] = *reinterpret_cast<const f32x4*>(row + d + 16 * c);
-      }
-      const int local = FULL ? b * 16 + li : li;
-      pad[b] = (tok >= 0 && geo.kpm[tk] == 0) ? (((FULL ? 0 : local / L) << 8) | (FULL ? local : local % L)) : -1;
+      for (int c = 0; c < 4; ++c) kf[b][c] = *reinterpret_cast<const f32x4*>(row + 16 * c);
+      pad[b] = (tok >= 0 && geo.kpm[tk] == 0) ? row_meta(b) : -1;
     }
+  };
+  auto load_q = [&](int u, int b) __attribute__((always_inline)) {
+    int t0, head, qb0;
+    unit_geo(u, t0, head, qb0);
+    const int tok = row_token(t0, b, li);
+    const float* row = geo.qkv + head * DH16 + 4 * lg + (int64_t)(tok >= 0 ? tok : spare_token(t0, b)) * ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qc[c] = *reinterpret_cast<const f32x4*>(row + 16 * c);
+  };
+  auto load_v = [&](int u) __attribute__((always_inline)) {
+    int t0, head, qb0;
+    unit_geo(u, t0, head, qb0);
     // V rows of the item: 4 rows (1 KB) per LDS-DMA instruction, chunk slot q ^ (row & 15)
-    float* Vs = smem + buf * VROWS * DH16;
 #pragma unroll
     for (int i = 0; i < NB * 4; ++i) {
+      if (SPLIT && !used(i >> 2, qb0)) continue;
       const int row = 4 * i + (lane >> 4), slot = lane & 15;
       int tok = row_token(t0, row >> 4, row & 15);
       if (tok < 0) tok = t0 < geo.n_tokens ? t0 : geo.n_tokens - 1;
@@ -100,60 +133,61 @@ __global__ __launch_bounds__(64 * Waves16<NB>::value) void attn16_kernel(const G
     }
   };
 
-  int buf = 0;
-  load_item(item, 0);
+  {
+    int t0, head, qb0;
+    unit_geo(unit, t0, head, qb0);
+    load_k(unit);
+    load_q(unit, qb0);
+    load_v(unit);
+  }
   for (;;) {
-    int t0, head;
-    item_geo(item, t0, head);
-    float* Vs = smem + buf * VROWS * DH16;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this item's fragments and V tile have landed (wave-local)
+    int t0, head, qb0;
+    unit_geo(unit, t0, head, qb0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this unit's fragments and V tile have landed (wave-local)
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-      if (lane < 16) kmeta[b * 16 + lane] = pad[b];
+      if (lane < 16 && (!SPLIT || used(b, qb0))) kmeta[b * 16 + lane] = pad[b];
+    const int n_unit = unit + stride;
+    const bool have_next = n_unit < n_units;
 
-    // ---- S^T blocks: st[qb][kb][r] = score of key kb*16 + 4*lg + r against query qb*16 + li
-    f32x4 st[NB][NB];
-#pragma unroll
-    for (int qb = 0; qb < NB; ++qb)
+    // one query block: qb is a constant of the unrolled loop below, or the unit's block under SPLIT
+    auto pass = [&](const int qb, const bool last) __attribute__((always_inline)) {
+      // ---- S^T blocks: st[kb][r] = score of key kb*16 + 4*lg + r against query qb*16 + li
+      f32x4 st[NB];
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
-        const bool use = FULL ? (!CAUSAL || kb <= qb) : kb == qb;
-        st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (use) {
+        st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (used(kb, qb)) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kb][c][e], qf[qb][c][e], st[qb][kb], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) st[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kb][c][e], qc[c][e], st[kb], 0, 0, 0);
         }
       }
-    // the fragment registers are dead: put the next item's loads in flight under the softmax / P·V / stores
-    const int n_item = item + stride;
-    const bool have_next = n_item < geo.n_items;
-    int my_q[NB];  // this lane's query metadata per block (same encoding as the keys'), taken before the registers are reloaded
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int local = FULL ? b * 16 + li : li;
-      my_q[b] = row_token(t0, b, li) >= 0 ? (((FULL ? 0 : local / L) << 8) | (FULL ? local : local % L)) : -1;
-    }
-    if (have_next) load_item(n_item, buf ^ 1);
-
-    // ---- mask + softmax (all of a query's scores are in registers: 4 per key block, over the 4 lanes lg = 0..3)
-    float inv[NB];
-#pragma unroll
-    for (int qb = 0; qb < NB; ++qb) {
-      const int q_seq = my_q[qb] >> 8, q_pos = my_q[qb] & 0xff;
+      // the Q registers are dead (after the last block the K registers too): next loads go under the softmax / P·V
+      if (!last) {
+        load_q(unit, qb + 1);
+      } else if (have_next) {
+        int nt0, nhead, nqb0;
+        unit_geo(n_unit, nt0, nhead, nqb0);
+        load_k(n_unit);
+        load_q(n_unit, nqb0);
+      }
+      // ---- mask + softmax (a query's scores: 4 per key block, over the 4 lanes lg = 0..3)
+      const int tok = row_token(t0, qb, li);
+      const int mq = tok >= 0 ? row_meta(qb) : -1;
+      const int q_seq = mq >> 8, q_pos = mq & 0xff;
       float m = -1e30f;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
-        const bool use = FULL ? (!CAUSAL || kb <= qb) : kb == qb;
-        if (!use) continue;
+        if (!used(kb, qb)) continue;
         const int4 km = *reinterpret_cast<const int4*>(kmeta + kb * 16 + 4 * lg);
         const int kmv[4] = {km.x, km.y, km.z, km.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool ok = (kmv[r] >= 0) & ((kmv[r] >> 8) == q_seq) & (!CAUSAL || (kmv[r] & 0xff) <= q_pos);
-          st[qb][kb][r] = ok ? st[qb][kb][r] * geo.scale : -1e30f;
-          m = fmaxf(m, st[qb][kb][r]);
+          st[kb][r] = ok ? st[kb][r] * geo.scale : -1e30f;
+          m = fmaxf(m, st[kb][r]);
         }
       }
       m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -161,73 +195,85 @@ __global__ __launch_bounds__(64 * Waves16<NB>::value) void attn16_kernel(const G
       float sum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
-        const bool use = FULL ? (!CAUSAL || kb <= qb) : kb == qb;
-        if (!use) continue;
+        if (!used(kb, qb)) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = st[qb][kb][r] > -1e29f ? __expf(st[qb][kb][r] - m) : 0.f;
-          st[qb][kb][r] = p;
+          const float p = st[kb][r] > -1e29f ? __expf(st[kb][r] - m) : 0.f;
+          st[kb][r] = p;
           sum += p;
         }
       }
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
-      inv[qb] = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
-    }
-
-    // ---- O^T[channel][query] += V^T·P^T: MFMA step (kb, r) sums keys kb*16 + 4g + r over g; one V value per lane and
-    // step feeds every query block that uses the key block
-    f32x4 o[NB][4];
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
+      // ---- O^T[channel][query] += V^T·P^T: MFMA step (kb, r) sums keys kb*16 + 4g + r over g
+      f32x4 o[4];
 #pragma unroll
-    for (int qb = 0; qb < NB; ++qb)
+      for (int cb = 0; cb < 4; ++cb) o[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) o[qb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < NB; ++kb) {
+        if (!used(kb, qb)) continue;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
+        for (int r = 0; r < 4; ++r) {
+          const int j = kb * 16 + 4 * lg + r;  // key row inside the item's V tile
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kb * 16 + 4 * lg + r;  // key row inside the item's V tile
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          const float v = Vs[j * DH16 + (((cb * 4 + (li >> 2)) ^ (j & 15)) * 4) + (li & 3)];
-#pragma unroll
-          for (int qb = 0; qb < NB; ++qb) {
-            const bool use = FULL ? (!CAUSAL || kb <= qb) : kb == qb;
-            if (use) o[qb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, st[qb][kb][r], o[qb][cb], 0, 0, 0);
+          for (int cb = 0; cb < 4; ++cb) {
+            const float v = Vs[j * DH16 + (((cb * 4 + (li >> 2)) ^ (j & 15)) * 4) + (li & 3)];
+            o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, st[kb][r], o[cb], 0, 0, 0);
           }
         }
       }
-
-    // ---- stores: lane (query li, lg) holds channels cb*16 + 4*lg .. +3 of its query
-#pragma unroll
-    for (int qb = 0; qb < NB; ++qb) {
-      const int tok = row_token(t0, qb, li);
+      if (last && have_next) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the unit's last V reads have returned: the tile can be refilled
+        load_v(n_unit);
+      }
+      // ---- store: lane (query li, lg) holds channels cb*16 + 4*lg .. +3 of its query
       if (tok >= 0) {
         float* dst = geo.ctx + (int64_t)tok * d + head * DH16 + 4 * lg;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(dst + 16 * cb) = o[qb][cb] * inv[qb];
+        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(dst + 16 * cb) = o[cb] * inv;
       }
+    };
+    if (SPLIT) {
+      pass(qb0, true);
+    } else {
+#pragma unroll
+      for (int qb = 0; qb < NB; ++qb) pass(qb, qb == NB - 1);
     }
     if (!have_next) break;
-    item = n_item;
-    buf ^= 1;
+    unit = n_unit;
   }
 }
 
-template <int NB, bool FULL, bool CAUSAL>
-int launch16(const Geo16& g, hipStream_t s) {
-  constexpr int WAVES16 = Waves16<NB>::value;
+// wave slots of the device for one instantiation (workgroups per CU x CUs x waves per workgroup)
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT>
+int64_t wg_capacity16() {
   static StltPerDeviceInt occ;
   int& wg_per_cu = occ.ref();
   if (wg_per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn16_kernel<NB, FULL, CAUSAL>, 64 * WAVES16, 0) != hipSuccess || wg_per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn16_kernel<NB, FULL, CAUSAL, SPLIT>, 64 * WAVES16, 0) != hipSuccess || wg_per_cu <= 0)
       wg_per_cu = 1;
   }
-  int64_t n_wg = ((int64_t)g.n_items + WAVES16 - 1) / WAVES16;
-  const int64_t cap = (int64_t)wg_per_cu * stlt_device_cus();
+  return (int64_t)wg_per_cu * stlt_device_cus();
+}
+
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT>
+int launch16_as(const Geo16& g, hipStream_t s) {
+  const int64_t n_units = SPLIT ? (int64_t)g.n_items * NB : g.n_items;
+  int64_t n_wg = (n_units + WAVES16 - 1) / WAVES16;
+  const int64_t cap = wg_capacity16<NB, FULL, CAUSAL, SPLIT>();
   if (n_wg > cap) n_wg = cap;
-  hipLaunchKernelGGL((attn16_kernel<NB, FULL, CAUSAL>), dim3((unsigned)n_wg), dim3(64 * WAVES16), 0, s, g);
+  hipLaunchKernelGGL((attn16_kernel<NB, FULL, CAUSAL, SPLIT>), dim3((unsigned)n_wg), dim3(64 * WAVES16), 0, s, g);
   return stlt_check_launch("attn16_kernel");
+}
+
+// FULL launches with fewer items than `split_below` x the device's wave slots are cut into (item, query block) units
+template <int NB, bool CAUSAL>
+int launch16_full(const Geo16& g, hipStream_t s) {
+  static const double split_below = [] { const char* e = getenv("STLT_ATTN16_SPLIT_BELOW"); return e ? atof(e) : 0.5; }();
+  const int64_t slots = wg_capacity16<NB, true, CAUSAL, false>() * WAVES16;
+  if ((double)g.n_items < split_below * (double)slots && (int64_t)g.n_items * NB <= 0x7fffffffLL) return launch16_as<NB, true, CAUSAL, true>(g, s);
+  return launch16_as<NB, true, CAUSAL, false>(g, s);
 }
 
 }  // namespace
@@ -235,7 +281,7 @@ int launch16(const Geo16& g, hipStream_t s) {
 // Returns 1 when the launch was taken, 0 when the shape is not this kernel's (the caller then uses attn.hip), < 0 / hip error on failure.
 int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s) {
   static const int enabled = [] { const char* e = getenv("STLT_ATTN16"); return e ? atoi(e) : 1; }();
-  if (!enabled || L < 1 || L > 48) return 0;
+  if (!enabled || L < 1 || L > 64) return 0;
   const int64_t n_tokens = S * L;
   if (n_tokens > 0x7fffffffLL || H > 65535) return 0;
   Geo16 g;
@@ -252,15 +298,16 @@ int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, i
     const int64_t items = ((n_tokens + g.rows_per_item - 1) / g.rows_per_item) * H;
     if (items > 0x7fffffffLL) return 0;
     g.n_items = (int)items;
-    rc = launch16<NB, false, false>(g, s);
+    rc = launch16_as<NB, false, false, false>(g, s);
   } else {
     g.P = 1;
     g.rows_per_item = (int)L;
     const int64_t items = S * H;
     if (items > 0x7fffffffLL) return 0;
     g.n_items = (int)items;
-    if (L <= 32) rc = causal ? launch16<2, true, true>(g, s) : launch16<2, true, false>(g, s);
-    else rc = causal ? launch16<3, true, true>(g, s) : launch16<3, true, false>(g, s);
+    if (L <= 32) rc = causal ? launch16_full<2, true>(g, s) : launch16_full<2, false>(g, s);
+    else if (L <= 48) rc = causal ? launch16_full<3, true>(g, s) : launch16_full<3, false>(g, s);
+    else rc = causal ? launch16_full<4, true>(g, s) : launch16_full<4, false>(g, s);
   }
   return rc == 0 ? 1 : rc;
 }

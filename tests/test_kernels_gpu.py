@@ -429,9 +429,12 @@ def test_linear_relu_autograd(pkg):
         assert (got.cpu().double() - r).abs().max().item() / max(r.abs().max().item(), 1e-6) <= 2e-5
 
 
-@pytest.mark.parametrize("S,L,causal", [(37, 7, False), (1, 7, False), (53, 36, False), (5, 32, True), (101, 4, False), (29, 48, True), (64, 16, False)])
+@pytest.mark.parametrize("S,L,causal", [(37, 7, False), (1, 7, False), (53, 36, False), (5, 32, True), (101, 4, False), (29, 48, True), (64, 16, False),
+                                        (29, 64, True), (31, 57, False), (300, 36, False), (300, 32, True), (200, 64, True), (200, 50, False),
+                                        (3000, 7, False)])
 def test_attn_core_short_sequences_many_items_and_masked_rows(pkg, S, L, causal):
-    """The 16-row-tile kernel (L <= 48): sequence counts that leave the last item partly filled, sequences whose keys are
+    """The 16-row-tile kernel (L <= 64): few items (the launch is cut into (item, query block) units) and many (whole
+    items per wave, several per wave at the largest counts); sequence counts that leave the last item partly filled, sequences whose keys are
     all padded (zeros out), every head count parity; against the fp64 oracle."""
     H = 12
     d = 64 * H

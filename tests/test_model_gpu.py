@@ -111,16 +111,16 @@ def test_matches_oracle_on_fresh_seed_with_scores_absent_and_present(pkg):
             assert (got - ref).abs().max().item() <= TOL
 
 
-def test_full_size_properties_cfg2(pkg):
-    """BASELINE-size batch (cfg2, B=64): size-independent properties, no oracle needed."""
-    name = "cfg2"
+@pytest.mark.parametrize("name", ["cfg2", "cfg4"])
+def test_full_size_properties(pkg, name):
+    """BASELINE-size batches (cfg2 and cfg4 at B=64): size-independent properties, no oracle needed."""
     c = pkg.synth.CONFIGS[name]
     m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
     sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234)
     m.load_state_dict(sd)
     m = m.train(False).to(DEV)
     B = 64
-    batch = _to(pkg.synth.make_batch(B, c["T"], c["N"], seed=3))
+    batch = _to(pkg.synth.make_batch(B, c["T"], c["N"], dataset=c["dataset"], seed=3))
     with torch.no_grad():
         full = m(batch)["stlt"]
         assert torch.isfinite(full).all()
@@ -145,6 +145,9 @@ def test_full_size_properties_cfg2(pkg):
         ext["frame_types"] = torch.zeros(B, T + 3, dtype=torch.int64, device=DEV)
         ext["frame_types"][:, :T] = batch["frame_types"]
         ext["lengths"] = batch["lengths"]
+        if "scores" in batch:
+            ext["scores"] = torch.zeros(B, T + 3, N + 2, device=DEV)
+            ext["scores"][:, :T, :N] = batch["scores"]
         ext["src_key_padding_mask_boxes"] = ext["categories"] == 0
         ext["src_key_padding_mask_frames"] = ext["frame_types"] == 0
         assert (m(ext)["stlt"] - full).abs().max().item() <= 2e-5

@@ -40,8 +40,9 @@ def main():
     for B in args.batches:
         run(B, 32, 12, True, args.iters)        # cfg2 temporal
         run(B * 32, 7, 12, False, args.iters)   # cfg2 spatial
-    run(64, 64, 12, True, args.iters)           # cfg4 temporal
-    run(64 * 64, 36, 12, False, args.iters)     # cfg4 spatial
+    for B in (16, 64, 256):
+        run(B, 64, 12, True, args.iters)        # cfg4 temporal
+        run(B * 64, 36, 12, False, args.iters)  # cfg4 spatial
 
 
 if __name__ == "__main__":

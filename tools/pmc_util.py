@@ -15,6 +15,9 @@ def family(name):
     m = re.search(r"attn_core_kernel<(?:true|false), (true|false), (true|false)>", name)
     if m:  # <STAMP, VARLEN, CAUSAL>
         return "attn_core_kernel/" + ("ragged-" if m.group(1) == "true" else "") + ("temporal" if m.group(2) == "true" else "spatial")
+    m = re.search(r"attn16_kernel<(\d), (true|false), (true|false)", name)
+    if m:  # <NB, FULL, CAUSAL, SPLIT>: 16-row tiles, the kernel of the L <= 64 passes (temporal = causal)
+        return "attn16_kernel/" + ("temporal" if m.group(3) == "true" else "spatial")
     m = re.search(r"(gemm_nt_kernel<\d|gemm_fixup_kernel|[a-z_0-9]+_kernel)", name)
     return m.group(1) if m else name[:40]
 
@@ -60,7 +63,7 @@ def main():
                           "SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -- python3 bench.py --steps 2 --warmup 1 "
                           "--no-cpu-baseline --no-skip-padding  [cfg2, 1024 clips]", "kernels": res}, open(out, "w"), indent=1)
     for k in sorted(res):
-        if "gemm_nt" in k or "attn_core" in k:
+        if "gemm_nt" in k or "attn_core" in k or "attn16" in k:
             print(k, res[k])
 
 
