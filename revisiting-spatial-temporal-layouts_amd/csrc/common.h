@@ -85,6 +85,8 @@ int launch_embed(const int64_t* categories, const float* boxes, const float* sco
                  const int* src_index = nullptr);
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, int act, hipStream_t s);
+int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y,
+                      int64_t ldy, int64_t M, int64_t N, int64_t K, hipStream_t s);
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
                 int64_t K, int n_split, int act, hipStream_t s);

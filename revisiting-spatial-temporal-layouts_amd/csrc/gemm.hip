@@ -498,35 +498,54 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int g = 0; g < 8; ++g) *reinterpret_cast<f32x4*>(P + t_row(a) * BN + t_col4(g)) = group(a, g);
+      } else if (vec_ok) {
+        // whole tile, 16-byte aligned rows: straight-line code, 16 stores of 16 bytes per lane
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int m = m0 + t_row(a);
+          float* yrow = Yt + (int64_t)m * ldy + n0;
+          const float* rrow = ADD ? R + (int64_t)m * ldr + n0 : nullptr;
+          // add-source (residual / residual gradient): the 8 pieces of this row pair are requested before its first store —
+          // left inside the store loop, every load waits out its own latency behind the previous store (possible aliasing);
+          // all 16 at once spill 24-44 of the 168 registers
+          constexpr int RB = 8;
+          f32x4 rv[ADD ? RB : 1];
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            if (ADD && g % RB == 0) {
+#pragma unroll
+              for (int h = 0; h < RB; ++h) rv[ADD ? h : 0] = *reinterpret_cast<const f32x4*>(rrow + t_col4(g + h));
+            }
+            f32x4 val = group(a, g);
+            if (ADD) val += rv[ADD ? g % RB : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (ACT == STLT_ACT_GELU) val[j] = gelu_epilogue(val[j]);
+              if (ACT == STLT_ACT_RELU) val[j] = fmaxf(val[j], 0.f);
+            }
+            if (STLT_GEMM_ABLATE & 16) asm volatile("" :: "v"(val)); else
+            *reinterpret_cast<f32x4*>(yrow + t_col4(g)) = val;
+          }
+        }
       } else {
+        // ragged tile or unaligned rows: guarded scalars
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const int m = m0 + t_row(a);
 #pragma unroll
           for (int g = 0; g < 8; ++g) {
             const int n = n0 + t_col4(g);
-            f32x4 val = group(a, g);
+            const f32x4 val = group(a, g);
             float* yp = Yt + (int64_t)m * ldy + n;
-            const float* rp = ADD ? R + (int64_t)m * ldr + n : nullptr;  // add-source (residual gradient)
-            if (vec_ok) {
-              if (ADD) val += *reinterpret_cast<const f32x4*>(rp);
+            const float* rp = ADD ? R + (int64_t)m * ldr + n : nullptr;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (ACT == STLT_ACT_GELU) val[j] = gelu_epilogue(val[j]);
-                if (ACT == STLT_ACT_RELU) val[j] = fmaxf(val[j], 0.f);
-              }
-              if (STLT_GEMM_ABLATE & 16) asm volatile("" :: "v"(val)); else
-              *reinterpret_cast<f32x4*>(yp) = val;
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                float x = val[j];
-                if (m < M && n + j < N) {
-                  if (ADD) x += rp[j];
-                  if (ACT == STLT_ACT_GELU) x = gelu_epilogue(x);
-                  if (ACT == STLT_ACT_RELU) x = fmaxf(x, 0.f);
-                  yp[j] = x;
-                }
+            for (int j = 0; j < 4; ++j) {
+              float x = val[j];
+              if (m < M && n + j < N) {
+                if (ADD) x += rp[j];
+                if (ACT == STLT_ACT_GELU) x = gelu_epilogue(x);
+                if (ACT == STLT_ACT_RELU) x = fmaxf(x, 0.f);
+                yp[j] = x;
               }
             }
           }
@@ -652,6 +671,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   if (transA && !transB) return stlt_set_error(STLT_EINVAL, "gemm: the (transA, !transB) layout is not built");
   if (n_split > 1 && (bias || act != STLT_ACT_NONE || r)) return stlt_set_error(STLT_EINVAL, "gemm: a split product takes no bias / activation / add-source");
   if ((transA || transB) && (act != STLT_ACT_NONE || bias)) return stlt_set_error(STLT_EINVAL, "gemm: bias/activation only with the forward (NT) layout");
+  if (r && act != STLT_ACT_NONE) return stlt_set_error(STLT_EINVAL, "gemm: an add-source excludes an activation");
   if (M == 0) return 0;
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   if (tiles_m * tiles_n * n_split > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "gemm: too many tiles");
@@ -679,7 +699,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 #define LAUNCH_SK(ACTV, TAV, TBV, ADDV) do { if (ws_sk) LAUNCH_SK1(ACTV, TAV, TBV, ADDV, true, dim3(GEMM_THREADS_WS)); else LAUNCH_SK1(ACTV, TAV, TBV, ADDV, false, block); } while (0)
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
       else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
-      else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
+      else if (r) LAUNCH_SK(STLT_ACT_NONE, false, false, true);  // y = x·Wᵀ + b + r (the residual of a post-norm layer)
       else if (act == STLT_ACT_GELU) LAUNCH_SK(STLT_ACT_GELU, false, false, false);
       else if (act == STLT_ACT_RELU) LAUNCH_SK(STLT_ACT_RELU, false, false, false);
       else LAUNCH_SK(STLT_ACT_NONE, false, false, false);
@@ -703,7 +723,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 #define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws) LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
-  else if (r) return stlt_set_error(STLT_EINVAL, "gemm: add-source is only built for the backward layouts");
+  else if (r) LAUNCH(STLT_ACT_NONE, false, false, false, true);  // y = x·Wᵀ + b + r
   else if (g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true, false, false, false);  // diagnostic build path only
   else if (act == STLT_ACT_GELU) LAUNCH(STLT_ACT_GELU, false, false, false, false);
   else if (act == STLT_ACT_RELU) LAUNCH(STLT_ACT_RELU, false, false, false, false);
@@ -742,4 +762,11 @@ int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* 
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, int act, hipStream_t s) {
   return launch_gemm(0, 0, x, ldx, w, K, bias, nullptr, 0, y, ldy, 0, M, N, K, 1, act, s);
+}
+
+// y = (x·Wᵀ + b) + r: the residual add of a post-norm layer in the product's epilogue (same rounding sequence as
+// storing the product and adding r in the LayerNorm pass: the accumulators start from b, r is added last)
+int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y,
+                      int64_t ldy, int64_t M, int64_t N, int64_t K, hipStream_t s) {
+  return launch_gemm(0, 0, x, ldx, w, K, bias, r, ldr, y, ldy, 0, M, N, K, 1, STLT_ACT_NONE, s);
 }

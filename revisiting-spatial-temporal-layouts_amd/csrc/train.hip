@@ -404,9 +404,14 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   TRY(launch_ln_bwd(sc.hA, d, t.z1, d, nullptr, 0, p->head_ln_w, p->ln_eps, B, d, sc.hB, d, W(g->head_ln_w), W(g->head_ln_b),
                     sc.red, s));                                                                    // hB = dz1
   TRY(launch_gelu_bwd(sc.hB, t.u0, sc.hB, B * d, s));                                               // hB = du0
-  if (g->fc1_w) TRY(launch_small_gemm(sc.hB, 1, d, t.h0, d, 1, W(g->fc1_w), d, d, d, B, 1, s));     // (d,d) += du0ᵀ·h0
+  // the two d x d products of fc1 go to the MFMA kernel (it contracts over multiples of 32 clips; the strided kernel takes the rest)
+  if (g->fc1_w) {                                                                                   // (d,d) += du0ᵀ·h0
+    const int64_t Bf = B / 32 * 32;
+    if (Bf > 0) TRY(launch_gemm(1, 1, sc.hB, d, t.h0, d, nullptr, W(g->fc1_w), d, W(g->fc1_w), d, 0, d, d, Bf, 1, STLT_ACT_NONE, s));
+    if (B > Bf) TRY(launch_small_gemm(sc.hB + Bf * d, 1, d, t.h0 + Bf * d, d, 1, W(g->fc1_w), d, d, d, B - Bf, 1, s));
+  }
   if (g->fc1_b) TRY(launch_colsum_acc(sc.hB, d, B, d, W(g->fc1_b), sc.red, s));
-  TRY(launch_small_gemm(sc.hB, d, 1, p->fc1_w, d, 1, sc.hA, d, B, d, d, 0, s));                     // hA = dh0
+  TRY(launch_gemm(0, 1, sc.hB, d, p->fc1_w, d, nullptr, nullptr, 0, sc.hA, d, 0, B, d, d, 1, STLT_ACT_NONE, s));  // hA = dh0
   // ---- temporal transformer
   int64_t l_tp = p->n_temporal - 1;
   if (tp_tail) {

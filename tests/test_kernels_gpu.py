@@ -229,6 +229,21 @@ def test_gemm_nn_stream_k_with_add_source(pkg, M, N, K):
     assert (got_r.double() - (ref + r.double())).abs().max().item() <= 3e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 3072), (2048, 768, 768), (300, 200, 96), (57, 768, 768), (14336, 768, 768)])
+@pytest.mark.parametrize("lend", [False, True])
+def test_gemm_nt_forward_layout_with_add_source(pkg, M, N, K, lend):
+    """y = x·Wᵀ + r (the residual add of a post-norm layer in the product's epilogue), whole tiles / ragged edges,
+    with and without stream-K."""
+    x, w, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(M, N, seed=3)
+    ref = x.double() @ w.double().t() + r.double()
+    if lend:
+        with pkg.ops.gemm_scratch():
+            got = pkg.ops.gemm(x.to(DEV), w.to(DEV), add=r.to(DEV)).cpu()
+    else:
+        got = pkg.ops.gemm(x.to(DEV), w.to(DEV), add=r.to(DEV)).cpu()
+    assert (got.double() - ref).abs().max().item() <= 3e-5
+
+
 def test_gemm_tn_stream_k(pkg):
     M, N, K = 768, 768, 2048  # 18 tiles: far fewer than CUs
     a, b = _rand(K, M, seed=4), _rand(K, N, seed=5)
