@@ -365,8 +365,9 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
   StltProfScope ps(kid, s);
   // short self-attention on a packed buffer without dropout: the 16-row-tile kernel (attn16.hip)
   if (Lq == Lk && Lq <= 64 && !dr.thr && k == q + H * dh && v == q + 2 * H * dh && ldq == 3 * H * dh && ldkv == ldq && !g_stlt_debug_buf) {
-    const int rc = launch_attn16(q, kpm, causal, S, Lq, H, ctx, attn_reverse_order(), s);
-    if (rc != 0) return rc == 1 ? 0 : rc;
+    bool taken = false;
+    const int rc = launch_attn16(q, kpm, causal, S, Lq, H, ctx, attn_reverse_order(), s, &taken);
+    if (taken || rc != 0) return rc;
   }
   const int64_t n_items = groups * g.ntq * H;
   g.n_items = n_items;

@@ -278,8 +278,11 @@ int launch16_full(const Geo16& g, hipStream_t s) {
 
 }  // namespace
 
-// Returns 1 when the launch was taken, 0 when the shape is not this kernel's (the caller then uses attn.hip), < 0 / hip error on failure.
-int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s) {
+// *taken = true when the launch was made (return value: 0 or the error), false when the shape is not this kernel's (the
+// caller then uses attn.hip).
+int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s,
+                  bool* taken) {
+  *taken = false;
   static const int enabled = [] { const char* e = getenv("STLT_ATTN16"); return e ? atoi(e) : 1; }();
   if (!enabled || L < 1 || L > 64) return 0;
   const int64_t n_tokens = S * L;
@@ -309,5 +312,6 @@ int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, i
     else if (L <= 48) rc = causal ? launch16_full<3, true>(g, s) : launch16_full<3, false>(g, s);
     else rc = causal ? launch16_full<4, true>(g, s) : launch16_full<4, false>(g, s);
   }
-  return rc == 0 ? 1 : rc;
+  *taken = true;
+  return rc;
 }

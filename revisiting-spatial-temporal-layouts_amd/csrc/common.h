@@ -109,7 +109,11 @@ void stlt_gemm_set_scratch_impl(void* p, size_t bytes);
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
-int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s);  // attn16.hip: 1 = taken, 0 = not this kernel's shape
+int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s,
+                  bool* taken);  // attn16.hip; *taken = false: not this kernel's shape
+int launch_attn_bwd16(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* dqkv,
+                      StltDrop dr, uint32_t site, float* scratch, int want_colsum, int* chunks_out, hipStream_t s,
+                      bool* taken);  // attn_bwd16.hip; *taken = false: not this kernel's shape
 int launch_attn_general(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm,
                         int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx, int kid,
                         hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);

@@ -25,7 +25,20 @@ def _oracle_grads(sd, batch, H, labels, dtype=torch.float64):
 @pytest.mark.parametrize("skip_padding", [False, True])
 @pytest.mark.parametrize("name,B,with_scores", [("cfg1", 3, False), ("cfg1", 5, True), ("cfg2", 2, False), ("cfg4", 2, True)])
 def test_gradients_match_oracle_autograd(pkg, name, B, with_scores, skip_padding):
-    c = pkg.synth.CONFIGS[name]
+    _check_gradients(pkg, name, B, with_scores, skip_padding)
+
+
+@pytest.mark.parametrize("T,N,B", [(20, 9, 3), (29, 16, 2), (32, 5, 3), (24, 3, 3), (17, 2, 4), (32, 7, 5)])
+def test_gradients_match_oracle_autograd_other_layouts(pkg, T, N, B):
+    """Frame / object counts around the block sizes of the MFMA attention backward (two 16-row blocks per item: one
+    sequence of 17-32 frames, or floor(16/N) frames per block; last item partly filled), cfg1's widths."""
+    _check_gradients(pkg, "cfg1", B, False, False, T=T, N=N)
+
+
+def _check_gradients(pkg, name, B, with_scores, skip_padding, T=None, N=None):
+    c = dict(pkg.synth.CONFIGS[name])
+    if T is not None:
+        c["T"], c["N"] = T, N
     H = c["num_attention_heads"]
     m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
     sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=31, gain=1.5)
