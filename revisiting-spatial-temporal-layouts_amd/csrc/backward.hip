@@ -614,11 +614,8 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
                                             ldb, w, eps, M, (int)d, ds, ldds, scratch, dr, site_b2,
                                             (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy, drop_rows));
   if (int e = stlt_check_launch("ln_bwd_kernel")) return e;
-  // partial rows are interleaved [block][dw|db|colsum][d]: strided reductions
-  if (g_w) { if (int e = launch_reduce_slabs(scratch, 3 * d, (int)blocks, g_w, d, 1, s)) return e; }
-  if (g_b) { if (int e = launch_reduce_slabs(scratch + d, 3 * d, (int)blocks, g_b, d, 1, s)) return e; }
-  if (g_colsum) { if (int e = launch_reduce_slabs(scratch + 2 * d, 3 * d, (int)blocks, g_colsum, d, 1, s)) return e; }
-  return 0;
+  // partial rows are interleaved [block][dw|db|colsum][d]: one strided reduction for the three destinations
+  return launch_reduce_slabs3(scratch, 3 * d, (int)blocks, g_w, g_b, g_colsum, d, 1, s);
 }
 
 // g[n] += sum_m x[m][n]   (scratch >= 64*N floats)

@@ -107,6 +107,8 @@ class StltGemmScratch {
 };
 void stlt_gemm_set_scratch_impl(void* p, size_t bytes);
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
+int launch_reduce_slabs3(const float* slabs, int64_t stride, int n_slabs, float* dst0, float* dst1, float* dst2, int64_t n, int accumulate,
+                         hipStream_t s);  // three destinations of n columns each, side by side in the slabs
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s,

@@ -652,6 +652,31 @@ __global__ __launch_bounds__(256) void reduce_tall_kernel(const float* __restric
   }
 }
 
+// The same reduction for up to three destinations at once: column j of the slabs belongs to destination j / n (LayerNorm
+// backward leaves [dw | db | column sums] per partial row): one launch instead of three, same summation order.
+__global__ __launch_bounds__(256) void reduce_tall3_kernel(const float* __restrict__ slabs, int64_t stride, int n_slabs,
+                                                           float* __restrict__ dst0, float* __restrict__ dst1,
+                                                           float* __restrict__ dst2, int64_t n, int accumulate) {
+  __shared__ float part[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t j = (int64_t)blockIdx.x * 16 + col;  // n is a multiple of 16 here, so a block never straddles destinations
+  const int which = (int)(j / n);
+  float* dst = which == 0 ? dst0 : which == 1 ? dst1 : dst2;
+  const bool live = j < 3 * n && dst != nullptr;
+  float acc = 0.f;
+  if (live)
+    for (int s = sl; s < n_slabs; s += 16) acc += slabs[s * stride + j];
+  part[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && live) {
+    const int64_t c = j - (int64_t)which * n;
+    float t = accumulate ? dst[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][col];
+    dst[c] = t;
+  }
+}
+
 }  // namespace
 
 static int n_cu() { return stlt_device_cus(); }
@@ -757,6 +782,21 @@ int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* 
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, stride, n_slabs, dst, n, accumulate);
   return stlt_check_launch("reduce_slabs_kernel");
+}
+
+// dst_k[i] (+)= sum_s slabs[s*stride + k*n + i] for the non-null destinations k = 0..2, i < n: one launch
+int launch_reduce_slabs3(const float* slabs, int64_t stride, int n_slabs, float* dst0, float* dst1, float* dst2, int64_t n, int accumulate,
+                         hipStream_t s) {
+  if (!slabs || n_slabs < 1) return stlt_set_error(STLT_EINVAL, "reduce_slabs: bad arguments");
+  if (n == 0 || (!dst0 && !dst1 && !dst2)) return 0;
+  if (n % 16 != 0 || n > 16384) {  // shapes the fused kernel does not take: one launch per destination
+    float* dsts[3] = {dst0, dst1, dst2};
+    for (int k = 0; k < 3; ++k)
+      if (dsts[k]) { if (int e = launch_reduce_slabs(slabs + k * n, stride, n_slabs, dsts[k], n, accumulate, s)) return e; }
+    return 0;
+  }
+  hipLaunchKernelGGL(reduce_tall3_kernel, dim3((unsigned)(3 * n / 16)), dim3(256), 0, s, slabs, stride, n_slabs, dst0, dst1, dst2, n, accumulate);
+  return stlt_check_launch("reduce_tall3_kernel");
 }
 
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
