@@ -220,6 +220,12 @@ size_t stlt_caf_workspace_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int6
 int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const float* appearance_features, void* workspace,
                      size_t workspace_bytes, float* logits_caf, float* logits_stlt, float* logits_resnet3d,
                      float* logits_ensemble, stlt_stream_t stream);
+/* The same with STLT_FLAG_SKIP_PADDING accepted in `flags`: the layout branch runs on the real tokens / frames only (the
+ * collater's masks, as for stlt_forward); padded frames' rows of the (B,T,d) layout state are zero — downstream they are
+ * only masked keys (models.py:403-431) — so the logits are those of the padded schedule to rounding. */
+int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, const float* appearance_features, void* workspace,
+                           size_t workspace_bytes, int flags, float* logits_caf, float* logits_stlt, float* logits_resnet3d,
+                           float* logits_ensemble, stlt_stream_t stream);
 
 /* ---- training step (reference src/train.py:119-135: forward, loss.backward(); optimiser step further below) ----
  * stlt_train_forward runs every layer on every row — except that the last layer of each tower runs its out-proj /

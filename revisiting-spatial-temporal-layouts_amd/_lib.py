@@ -102,6 +102,7 @@ SIGNATURES = {
     "stlt_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
     "stlt_caf_workspace_bytes": (C.c_size_t, [C.c_int64] * 7),
     "stlt_caf_forward": (C.c_int, [C.c_void_p, C.POINTER(Inputs), _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp]),
+    "stlt_caf_forward_flags": (C.c_int, [C.c_void_p, C.POINTER(Inputs), _vp, _vp, C.c_size_t, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "stlt_train_tape_bytes": (C.c_size_t, [C.c_int64] * 6),
     "stlt_train_scratch_bytes": (C.c_size_t, [C.c_int64] * 5),
     "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),

@@ -398,7 +398,11 @@ static int encoder_tail_rows(const stlt_layer_params& lp, int64_t d, const float
 
 // Stlt.forward up to the rows the head reads, computed on the real tokens / frames only (STLT_FLAG_SKIP_PADDING).
 // Synchronises the stream once, to read the two row counts the launches are sized by.
-static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* workspace, const WsLayout& w, float* h0, hipStream_t s) {
+// out_btd != null (the fusion models' layout branch): every temporal layer runs on all real frames and the result is
+// scattered into the (B,T,d) tensor, padded frames zero — those rows are only ever masked keys or queries whose outputs
+// nobody reads (models.py:403-431, 470), so the logits are the padded schedule's; h0 is not produced.
+static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* workspace, const WsLayout& w, float* h0, float* out_btd,
+                          hipStream_t s) {
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
   char* base = (char*)workspace;
   float* x = (float*)(base + w.x);
@@ -439,8 +443,10 @@ static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* wor
   TRY(launch_frames_embed(cls, d, in->frame_types, p->pos_emb, p->type_emb, p->frames_ln_w, p->frames_ln_b, p->ln_eps, B, T,
                           d, tbuf, s, nullptr, StltDrop{0u, 1.0f, 0ull}, ix.f_orig, Mf));
   // temporal transformer: segments = clips, causal
-  for (int64_t l = 0; l + 1 < p->n_temporal; ++l)
+  const int64_t tp_full = out_btd ? p->n_temporal : p->n_temporal - 1;
+  for (int64_t l = 0; l < tp_full; ++l)
     TRY(encoder_layer_ragged(p->temporal[l], d, H, tbuf, Mf, ix.f_seg_start, ix.f_seg_end, 1, STLT_K_ATTN_TEMPORAL, qkv, ctx, tmp, x, hh, tbuf, s));
+  if (out_btd) return launch_scatter_rows(tbuf, ix.f_orig, Mf, d, out_btd, B * T, s);
   if (p->n_temporal > 0) {
     const stlt_layer_params& lp = p->temporal[p->n_temporal - 1];
     TRY(launch_linear(tbuf, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, Mf, 3 * d, d, STLT_ACT_NONE, s));
@@ -456,6 +462,14 @@ static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* wor
 int backbone_impl_public(const stlt_params* p, const stlt_inputs* in, void* workspace, size_t workspace_bytes, int flags,
                          float* out_btd, hipStream_t s) {
   TRY(check_params(p, in, false));
+  if (flags & STLT_FLAG_SKIP_PADDING) {
+    const WsLayout w = ws_layout(in->B, in->T, in->N, p->d, p->n_classes < 0 ? 0 : p->n_classes);
+    if (!workspace || workspace_bytes < w.total)
+      return stlt_set_error(STLT_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.total);
+    if (!out_btd) return stlt_set_error(STLT_EINVAL, "skip-padding backbone: out_btd is null");
+    StltGemmScratch gemm_scratch((char*)workspace + w.sk, STLT_GEMM_SCRATCH_BYTES);
+    return forward_ragged(p, in, workspace, w, nullptr, out_btd, s);
+  }
   return backbone_impl(p, in, workspace, workspace_bytes, flags, out_btd, nullptr, s);
 }
 size_t stlt_workspace_bytes_public(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_classes) {
@@ -488,7 +502,7 @@ int stlt_forward(const stlt_params* p, const stlt_inputs* in, void* workspace, s
   float* h2 = h1 + (size_t)B * d;
   const bool last_only = (flags & STLT_FLAG_LAST_ROW_ONLY_TEMPORAL) && !out_btd && p->n_temporal > 0 && in->T > 1;
   if ((flags & STLT_FLAG_SKIP_PADDING) && !out_btd) {  // padded rows are never computed, so there is no (B,T,d) output to hand back
-    TRY(forward_ragged(p, in, workspace, w, h0, s));
+    TRY(forward_ragged(p, in, workspace, w, h0, nullptr, s));
   } else if (last_only) {  // the caller does not want the (B,T,d) backbone output: produce only the rows the head reads
     TRY(backbone_impl(p, in, workspace, workspace_bytes, flags, bb_out, h0, s));
   } else {

@@ -129,6 +129,12 @@ extern "C" size_t stlt_caf_workspace_bytes(int64_t B, int64_t T, int64_t N, int6
 extern "C" int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const float* feats, void* workspace,
                                 size_t workspace_bytes, float* logits_caf, float* logits_stlt, float* logits_resnet3d,
                                 float* logits_ensemble, stlt_stream_t stream) {
+  return stlt_caf_forward_flags(p, in, feats, workspace, workspace_bytes, 0, logits_caf, logits_stlt, logits_resnet3d, logits_ensemble, stream);
+}
+
+extern "C" int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, const float* feats, void* workspace,
+                                      size_t workspace_bytes, int flags, float* logits_caf, float* logits_stlt,
+                                      float* logits_resnet3d, float* logits_ensemble, stlt_stream_t stream) {
   if (!p || !in || !feats || !workspace || !logits_caf) return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: null argument");
   hipStream_t s = (hipStream_t)stream;
   const stlt_params& lp = p->layout;
@@ -149,8 +155,10 @@ extern "C" int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in,
   if (hipError_t e = hipMemsetAsync(base + w.zero, 0, (size_t)B * (T > S + 1 ? T : S + 1), s); e != hipSuccess)
     return stlt_set_error((int)e, "stlt_caf_forward: memset: %s", hipGetErrorString(e));
 
-  // ---- layout branch: full (B,T,d) backbone output (models.py:451)
-  TRY(backbone_impl_public(&lp, in, base + w.bb, stlt_workspace_bytes_public(B, T, N, d, K), STLT_FLAG_CLS_ONLY_LAST_SPATIAL, Lh, s));
+  // ---- layout branch: full (B,T,d) backbone output (models.py:451); STLT_FLAG_SKIP_PADDING computes it on the real
+  // tokens / frames only and leaves the padded frames' rows zero (they are masked keys everywhere downstream)
+  TRY(backbone_impl_public(&lp, in, base + w.bb, stlt_workspace_bytes_public(B, T, N, d, K),
+                           STLT_FLAG_CLS_ONLY_LAST_SPATIAL | (flags & STLT_FLAG_SKIP_PADDING), Lh, s));
   // ---- appearance branch from the feature map (models.py:253-271)
   hipLaunchKernelGGL(feat_transpose_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((S + 31) / 32), (unsigned)B), dim3(256), 0, s, feats,
                      (int)C, (int)S, F(w.ft));

@@ -226,8 +226,10 @@ class CrossAttentionFusionBackbone(nn.Module):
         outs = [torch.empty(B, K, device=device, dtype=torch.float32) for _ in range(4 if layout_head is not None else 1)]
         ptrs = [o.data_ptr() for o in outs] + [None] * (4 - len(outs))
         with torch.cuda.device(device):
-            L.check(lib.stlt_caf_forward(C.byref(p), C.byref(inp), feats.data_ptr(), ws.data_ptr(), ws.numel(), ptrs[0], ptrs[1],
-                                         ptrs[2], ptrs[3], torch.cuda.current_stream().cuda_stream), "stlt_caf_forward")
+            # layout_branch.skip_padding (as on a stand-alone StltBackbone): the layout branch on the real tokens / frames only
+            flags = L.FLAG_SKIP_PADDING if self.layout_branch.skip_padding else 0
+            L.check(lib.stlt_caf_forward_flags(C.byref(p), C.byref(inp), feats.data_ptr(), ws.data_ptr(), ws.numel(), flags, ptrs[0],
+                                               ptrs[1], ptrs[2], ptrs[3], torch.cuda.current_stream().cuda_stream), "stlt_caf_forward")
         return outs
 
 

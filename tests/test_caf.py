@@ -45,14 +45,26 @@ def test_caf_state_dict_keys_are_the_reference_non_r3d_keys(pkg, model_name):
     assert all(list(sd[k].shape) == meta["keys"][k] for k in sd)
 
 
+def _set_skip_padding(pkg, m, on):
+    """The fusion models take the flag from their layout branch (a StltBackbone), like a stand-alone backbone."""
+    n = 0
+    for mod in m.modules():
+        if isinstance(mod, pkg.StltBackbone):
+            mod.skip_padding = on
+            n += 1
+    assert n == 1
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("skip_padding", [False, True])
 @pytest.mark.parametrize("model_name", ["caf", "cacnf", "lcf"])
-def test_caf_gpu_matches_reference(pkg, model_name):
+def test_caf_gpu_matches_reference(pkg, model_name, skip_padding):
     z, meta, sd, batch, c = _case(pkg.synth, model_name)
     cls = pkg.models_factory[model_name]
     m = cls(pkg.MultimodalModelConfig(**dict(pkg.synth.model_kwargs(NAME), **EXTRA)))
     m.load_state_dict(sd, strict=True)
     m.train(False).to("cuda")
+    _set_skip_padding(pkg, m, skip_padding)  # layout branch on the real tokens / frames only: same logits
     with torch.no_grad():
         out = m({k: v.to("cuda") for k, v in batch.items()})
     assert tuple(out) == m.logit_names or set(out) == set(m.logit_names)
@@ -76,8 +88,12 @@ def test_caf_gpu_full_width_matches_oracle(pkg):
     with torch.no_grad():
         out = m({k: v.to("cuda") for k, v in batch.items()})
         ref = CO.cacnf_forward(sd, batch, c["num_attention_heads"])
+        _set_skip_padding(pkg, m, True)
+        out_sp = m({k: v.to("cuda") for k, v in batch.items()})
     for k in ref:
         assert (out[k].cpu() - ref[k]).abs().max().item() <= 1e-4, k
+        assert (out_sp[k].cpu() - ref[k]).abs().max().item() <= 1e-4, k
+        assert (out_sp[k] - out[k]).abs().max().item() <= 2e-5, k
 
 
 @pytest.mark.gpu
