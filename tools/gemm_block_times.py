@@ -27,9 +27,11 @@ fl = 2.0 * M * N * K
 print(f"in-kernel clock {clk:.3f} GHz ; kernel {fl / (en.max() * 1e-6) / 1e12:.1f} TFLOP/s by its own span = {fl / (en.max() * 1e-6) / 1e12 / (clk / 2.4 * 157.3):.3f} of the MFMA rate at that clock")
 print(f"workgroups={len(t)} tiles/wg min {t[:,3].min()} max {t[:,3].max()}  kernel span {en.max():.1f} us")
 print(f"start: max {st.max():.1f} us ; end: min {en.min():.1f} median {en.median():.1f} max {en.max():.1f} us ; mean idle tail {(en.max()-en).mean():.1f} us")
+wg_clk = (ck[:, 1] - ck[:, 0]) / ((t[:, 1] - t[:, 0]).double() / 100.0) / 1e3  # GHz per workgroup
 for xcc in sorted(set(t[:, 2].tolist())):
     m = t[:, 2] == xcc
-    print(f"  xcc {xcc}: wgs {int(m.sum()):4d} end min {en[m].min():8.1f} med {en[m].median():8.1f} max {en[m].max():8.1f}")
+    print(f"  xcc {xcc}: wgs {int(m.sum()):4d} end min {en[m].min():8.1f} med {en[m].median():8.1f} max {en[m].max():8.1f}   shader clock {wg_clk[m].median():.3f} GHz"
+          f"   blockIdx&7 = {sorted(set((torch.nonzero(m).flatten() & 7).tolist()))}")
 import numpy as np
 e = en.numpy()
 hist, edges = np.histogram(e, bins=12)
