@@ -103,6 +103,13 @@ __device__ __forceinline__ float gelu_epilogue(float x) {
 #endif
 }
 
+// Stream-K launches on a full grid of 8 x Gx workgroups with at least one round of whole tiles to spare run as a hybrid:
+// `dp_rounds` rounds of whole tiles in the XCD-grouped order (no partial tiles, the L2-friendly order), then only the
+// remaining tiles — positions [dp_rounds*G, n_tiles) of the same order — as k-step ranges.  XCD x owns the tail steps
+// [P[x], P[x+1]), cut into ranges of S[x] steps for its workgroups in turn (per-XCD lengths: room for clock-weighted
+// ranges; equal today).  dp_rounds = 0: the plain stream-K assignment (G equal ranges over every tile).
+struct SkPlan { int dp_rounds; int P[9]; int S[8]; };
+
 template <int ACT, bool STAMP, bool TA, bool TB, bool ADD, bool SK, bool WS>
 __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ W, int64_t ldw,
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
                                                                   int64_t slab_stride, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, int n_split,
                                                                   float* __restrict__ partials,
-                                                                  unsigned long long* __restrict__ dbg) {
+                                                                  unsigned long long* __restrict__ dbg, const SkPlan plan) {
   constexpr int prio = STLT_GEMM_PRIO_MODE;
   constexpr int NBIAS = 2;  // bias strips, by tile parity
   __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + NBIAS * BN];  // operand stages + bias strips
@@ -146,7 +153,24 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   const int g_xcd = blockIdx.x & 7, g_local = blockIdx.x >> 3, g_gx = G >> 3;
   const int g_rounds = (n_tiles + G - 1) / G;
   int my_tiles, sk_first = 0, sk_kt0 = 0, sk_tail = 0;
-  if (SK) {
+  const bool hy = SK && plan.dp_rounds > 0;  // hybrid: whole-tile rounds, then a stream-K tail
+  const int hy_R = hy ? plan.dp_rounds : 0;
+  int hy_steps = 0;
+  if (hy) {
+    const int e = plan.P[g_xcd + 1];
+    const int s0 = plan.P[g_xcd] + g_local * plan.S[g_xcd];
+    const int s1 = s0 + plan.S[g_xcd] < e ? s0 + plan.S[g_xcd] : e;
+    int sk_tiles = 0;
+    if (s0 < s1) {
+      sk_first = s0 / nk;
+      sk_kt0 = s0 - sk_first * nk;
+      const int last = (s1 - 1) / nk;
+      sk_tiles = last - sk_first + 1;
+      sk_tail = s1 - last * nk;
+      hy_steps = s1 - s0;
+    }
+    my_tiles = hy_R + sk_tiles;
+  } else if (SK) {
     const int total = n_tiles * nk;
     const int S = (total + G - 1) / G;
     const int s0 = v * S;
@@ -174,16 +198,21 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
     dbg[4 * blockIdx.x + 3] = my_tiles;
     dbg[4 * (size_t)gridDim.x + (size_t)gridDim.x * GEMM_WAVES * 6 + 1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime();  // shader clock, behind the stamp / trace regions
   }
-  const int total_steps = SK ? (my_tiles - 1) * nk + sk_tail - sk_kt0 : my_tiles * nk;
+  const int total_steps = hy ? hy_R * nk + hy_steps : SK ? (my_tiles - 1) * nk + sk_tail - sk_kt0 : my_tiles * nk;
   // does this workgroup compute every k-step of its it-th tile?  (otherwise the segment is a partial: no bias, raw store)
   auto seg_complete = [&](int it) {
     if (!SK) return true;
-    return (it > 0 || sk_kt0 == 0) && (it < my_tiles - 1 || sk_tail == nk);
+    if (it < hy_R) return true;
+    return (it > hy_R || sk_kt0 == 0) && (it < my_tiles - 1 || sk_tail == nk);
   };
+  // first k-step of the it-th tile: only the first stream-K segment may begin inside a tile
+  auto kt_begin = [&](int it) { return (SK && it == hy_R) ? sk_kt0 : 0; };
 
   auto tile_origin = [&](int it, int& m0, int& n0, int& split) {
-    if (grouped) {
-      const int p = (g_xcd * g_rounds + it) * g_gx + g_local;
+    if (grouped || hy) {
+      // hybrid: the whole-tile rounds take positions [0, R*G) XCD by XCD, the tail tiles follow in the same order
+      const int p = hy ? (it < hy_R ? (g_xcd * hy_R + it) * g_gx + g_local : hy_R * G + sk_first + (it - hy_R))
+                       : (g_xcd * g_rounds + it) * g_gx + g_local;
       const int band = p / (GROUP_M * tiles_n), w = p - band * (GROUP_M * tiles_n);
       const int rows = tiles_m - band * GROUP_M < GROUP_M ? tiles_m - band * GROUP_M : GROUP_M;
       const int tn_g = w / rows;
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   };
   if (WS && wave >= GEMM_WAVES) {
     // ---- loader waves: the whole DMA stream of the workgroup, two k-steps ahead of the MFMA waves, same barriers
-    int l_it = 0, l_kt = SK ? sk_kt0 : 0, l_stage = 0;
+    int l_it = 0, l_kt = kt_begin(0), l_stage = 0;
     bool l_fresh = true;  // row pointers not yet set for the tile the stream is in (first step, possibly mid-tile)
     auto l_step = [&]() {
       if ((STLT_GEMM_ABLATE & 32) ? l_fresh : (l_kt == 0 || l_fresh)) { dma_set_tile(l_it); l_fresh = false; }
@@ -340,7 +369,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         issue_dma_part(1, src_kt, l_stage, u);
         issue_dma_part(2, src_kt, l_stage, u);
       }
-      if (++l_kt == nk) { l_kt = 0; ++l_it; }
+      if (++l_kt == nk) { ++l_it; l_kt = kt_begin(l_it); if (!(STLT_GEMM_ABLATE & 32)) l_fresh = true; }
       if (++l_stage == NSTAGE) l_stage = 0;
     };
     dma_bias(0);
@@ -352,7 +381,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    int w_it = 0, w_kt = SK ? sk_kt0 : 0;  // position of the MFMA waves (the bias strip follows their tile changes)
+    int w_it = 0, w_kt = kt_begin(0);  // position of the MFMA waves (the bias strip follows their tile changes)
     for (int step = 0; step < total_steps; ++step) {
       if (w_kt == nk - 1 && w_it + 1 < my_tiles) dma_bias(w_it + 1);
       if (!(STLT_GEMM_ABLATE & 1) && step + 2 < total_steps) {
@@ -362,7 +391,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      if (++w_kt == nk) { w_kt = 0; ++w_it; }
+      if (++w_kt == nk) { ++w_it; w_kt = kt_begin(w_it); }
     }
     return;
   }
@@ -429,7 +458,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   init_acc(0, SK && !seg_complete(0));
   Frags fa = read_frags(0, 0), fb;  // ping-pong fragment registers: 4 chunk reads per step, so fa is "current" at every step start
 
-  int c_it = 0, c_kt = SK ? sk_kt0 : 0;  // MFMA stream position
+  int c_it = 0, c_kt = kt_begin(0);  // MFMA stream position
   int stage = 0;
   unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
 #define GSTAMP(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); t_acc[k] += t_now - t_prev; t_prev = t_now; __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -493,7 +522,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         return v;
       };
       if (partial) {  // raw accumulators into this workgroup's head / tail slot (a whole BMxBN image, no guards)
-        float* P = partials + (size_t)(2 * v + (c_it == 0 ? 0 : 1)) * (BM * BN);
+        float* P = partials + (size_t)(2 * v + (c_it == hy_R ? 0 : 1)) * (BM * BN);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -552,8 +581,8 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         }
       }
       if (c_it + 1 < my_tiles) init_acc(c_it + 1, SK && !seg_complete(c_it + 1));
-      c_kt = 0;
       ++c_it;
+      c_kt = kt_begin(c_it);
       GSTAMP(5);  // epilogue
     }
   }
@@ -577,13 +606,39 @@ template <int ACT>
 __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict__ partials, int S, int nk,
                                                          const float* __restrict__ bias, const float* __restrict__ R,
                                                          int64_t ldr, float* __restrict__ Y, int64_t ldy, int M, int N,
-                                                         int tiles_n) {
+                                                         int tiles_m, int tiles_n, int G, const SkPlan plan) {
   const int t = blockIdx.x / FIXUP_CHUNKS, chunk = blockIdx.x - t * FIXUP_CHUNKS;  // a workgroup sums BM/FIXUP_CHUNKS rows of a tile
-  const int lo = t * nk, hi = lo + nk;
-  const int v_first = lo / S, v_last = (hi - 1) / S;
+  const int lo = t * nk, hi = lo + nk;  // hybrid: t counts the tail tiles, steps are tail steps
+  const bool hy = plan.dp_rounds > 0;
+  const int gx = G >> 3;
+  // workgroup (in range order) that owns k-step s, and the first step of workgroup v's range
+  auto wg_of = [&](int s) {
+    if (!hy) return s / S;
+    int x = 0;
+    while (x < 7 && s >= plan.P[x + 1]) ++x;
+    return x * gx + (s - plan.P[x]) / plan.S[x];
+  };
+  auto start_of = [&](int v) {
+    if (!hy) return v * S;
+    const int x = v / gx;
+    return plan.P[x] + (v - x * gx) * plan.S[x];
+  };
+  const int v_first = wg_of(lo), v_last = wg_of(hi - 1);
   if (v_first == v_last) return;
-  const int tm = t / tiles_n;
-  const int m0 = tm * BM, n0 = (t - tm * tiles_n) * BN;
+  int m0, n0;
+  if (hy) {  // position of the tail tile in the band-major order of the main kernel
+    constexpr int GROUP_M = 4;
+    const int p = plan.dp_rounds * G + t;
+    const int band = p / (GROUP_M * tiles_n), w = p - band * (GROUP_M * tiles_n);
+    const int rows = tiles_m - band * GROUP_M < GROUP_M ? tiles_m - band * GROUP_M : GROUP_M;
+    const int tn_g = w / rows;
+    m0 = (band * GROUP_M + (w - tn_g * rows)) * BM;
+    n0 = tn_g * BN;
+  } else {
+    const int tm = t / tiles_n;
+    m0 = tm * BM;
+    n0 = (t - tm * tiles_n) * BN;
+  }
   const int c4 = (threadIdx.x & 31) * 4;
   float bv[4];
 #pragma unroll
@@ -594,7 +649,7 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict
     if (m >= M) break;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int v = v_first; v <= v_last; ++v) {
-      const size_t slot = (size_t)(2 * v + (v * S >= lo ? 0 : 1));
+      const size_t slot = (size_t)(2 * v + (start_of(v) >= lo ? 0 : 1));
       acc += *reinterpret_cast<const f32x4*>(partials + slot * (BM * BN) + rr * BN + c4);
     }
 #pragma unroll
@@ -720,7 +775,24 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
       dim3 grid((unsigned)G);
       float* P = t_gemm_scratch;
       static const bool ws_sk = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
-#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr)
+      // hybrid: whole-tile rounds in the grouped order + a stream-K tail (loader-wave build, full grid of 8 x Gx workgroups,
+      // the tail at least 4 k-steps per workgroup: the last whole round joins it otherwise).  STLT_GEMM_HYBRID=0: plain stream-K.
+      static const bool hybrid_on = [] { const char* e = getenv("STLT_GEMM_HYBRID"); return e ? atoi(e) != 0 : true; }();
+      SkPlan plan{};
+      int64_t fix_tiles = n_tiles;
+      if (hybrid_on && ws_sk && (G & 7) == 0 && G == n_cu() && n_tiles > G) {
+        int64_t R = n_tiles / G, tail = n_tiles - R * G;
+        if (tail * nk < 4 * G) { R -= 1; tail += G; }
+        if (R >= 1 && tail > 0) {
+          const int64_t tail_steps = tail * nk, gx = G >> 3;
+          const int64_t Sx = (tail_steps + G - 1) / G;  // equal ranges (per-XCD lengths are the hook for clock-weighted ones)
+          plan.dp_rounds = (int)R;
+          for (int x = 0; x <= 8; ++x) { const int64_t v = x * gx * Sx; plan.P[x] = (int)(v < tail_steps ? v : tail_steps); }
+          for (int x = 0; x < 8; ++x) plan.S[x] = (int)Sx;
+          fix_tiles = tail;
+        }
+      }
+#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan)
 #define LAUNCH_SK(ACTV, TAV, TBV, ADDV) do { if (ws_sk) LAUNCH_SK1(ACTV, TAV, TBV, ADDV, true, dim3(GEMM_THREADS_WS)); else LAUNCH_SK1(ACTV, TAV, TBV, ADDV, false, block); } while (0)
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
       else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
@@ -731,8 +803,8 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 #undef LAUNCH_SK
 #undef LAUNCH_SK1
       if (int e = stlt_check_launch("gemm_nt_kernel(stream-k)")) return e;
-      dim3 fgrid((unsigned)(n_tiles * FIXUP_CHUNKS)), fblock(256);
-#define FIX(ACTV) hipLaunchKernelGGL((gemm_fixup_kernel<ACTV>), fgrid, fblock, 0, s, P, S, (int)nk, bias, r, ldr, c, ldc, (int)M, (int)N, (int)tiles_n)
+      dim3 fgrid((unsigned)(fix_tiles * FIXUP_CHUNKS)), fblock(256);
+#define FIX(ACTV) hipLaunchKernelGGL((gemm_fixup_kernel<ACTV>), fgrid, fblock, 0, s, P, S, (int)nk, bias, r, ldr, c, ldc, (int)M, (int)N, (int)tiles_m, (int)tiles_n, (int)G, plan)
       if (act == STLT_ACT_GELU) FIX(STLT_ACT_GELU);
       else if (act == STLT_ACT_RELU) FIX(STLT_ACT_RELU);
       else FIX(STLT_ACT_NONE);
@@ -744,7 +816,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   // wave-specialised build (4 DMA-only waves beside the 8 MFMA waves) unless STLT_GEMM_WS=0 (A/B measurements)
   static const bool ws = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
   const dim3 block_ws(GEMM_THREADS_WS);
-#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf)
+#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf, SkPlan{})
 #define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws) LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }

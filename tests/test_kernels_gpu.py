@@ -197,7 +197,10 @@ def test_linear_relu(pkg):
 # the fix-up kernel.  Shapes: fewer tiles than CUs, a ragged last round (1.3 rounds), ranges shorter than a tile
 # (many partials per tile), ragged M/N edges, and a launch small enough that the grid shrinks below the CU count.
 SK_SHAPES = [(2048, 768, 768), (2048, 768, 3072), (2048, 2304, 768), (14336, 768, 768), (64, 768, 768), (1000, 174, 256),
-             (300, 130, 96), (5000, 3072, 64), (1, 64, 32)]
+             (300, 130, 96), (5000, 3072, 64), (1, 64, 32),
+             # more tiles than CUs: whole-tile rounds + a stream-K tail (1 round + 80 tiles; 5 rounds + 64; ragged edges; a
+             # tail too short on its own, so the last whole round joins it)
+             (14336, 3072, 768), (14336, 768, 3072), (14000, 776, 768), (16640, 1024, 64)]
 
 
 @pytest.mark.parametrize("M,N,K", SK_SHAPES)
@@ -218,7 +221,7 @@ def test_linear_stream_k(pkg, M, N, K, act):
     assert (y - plain).abs().max().item() <= 1e-5  # same products, different association across the k-range cuts
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 768, 3072), (2048, 3072, 768), (300, 200, 96), (57, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 3072), (2048, 3072, 768), (300, 200, 96), (57, 3072, 768), (14336, 768, 3072), (14336, 3072, 768)])
 def test_gemm_nn_stream_k_with_add_source(pkg, M, N, K):
     a, b, r = _rand(M, K, seed=1), _rand(K, N, seed=2, scale=1 / math.sqrt(K)), _rand(M, N, seed=3)
     ref = a.double() @ b.double()
