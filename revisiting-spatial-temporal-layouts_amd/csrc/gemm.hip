@@ -649,6 +649,7 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict
     if (m >= M) break;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int v = v_first; v <= v_last; ++v) {
+      if (hy && start_of(v) >= plan.P[v / gx + 1]) continue;  // the last workgroups of an XCD may have no range
       const size_t slot = (size_t)(2 * v + (start_of(v) >= lo ? 0 : 1));
       acc += *reinterpret_cast<const f32x4*>(partials + slot * (BM * BN) + rr * BN + c4);
     }
@@ -736,6 +737,75 @@ __global__ __launch_bounds__(256) void reduce_tall3_kernel(const float* __restri
 
 static int n_cu() { return stlt_device_cus(); }
 
+// Relative XCD speeds for the hybrid launch's tail ranges: STLT_GEMM_XCD_W="w0,...,w7" (experiments) — empty: equal.
+static const double* xcd_weights() {
+  static double w[8];
+  static const bool have = [] {
+    const char* e = getenv("STLT_GEMM_XCD_W");
+    if (!e) return false;
+    int n = 0;
+    for (const char* p = e; *p && n < 8;) {
+      char* end = nullptr;
+      const double v = strtod(p, &end);
+      if (end == p) break;
+      w[n++] = v;
+      p = *end == ',' ? end + 1 : end;
+    }
+    if (n != 8) return false;
+    for (int i = 0; i < 8; ++i) if (!(w[i] > 0.5 && w[i] < 2.0)) return false;
+    return true;
+  }();
+  return have ? w : nullptr;
+}
+
+// Hybrid plan for n_tiles tiles of nk k-steps on G = 8*gx workgroups: R whole-tile rounds, then the remaining tiles as
+// k-step ranges; with XCD weights the ranges are sized so that every XCD finishes its rounds + range at the same time.
+// Returns false when the shape leaves no room (the caller keeps the plain assignment).
+static bool make_sk_plan(int64_t n_tiles, int64_t nk, int64_t G, const double* w, bool force_tail_round, SkPlan& plan, int64_t& tail_tiles) {
+  if ((G & 7) != 0 || n_tiles <= G) return false;
+  const int64_t gx = G >> 3;
+  int64_t R = n_tiles / G, tail = n_tiles - R * G;
+  if (tail * nk < 4 * G || (force_tail_round && tail == 0)) { R -= 1; tail += G; }
+  const int64_t total = n_tiles * nk;
+  double want[8], sum = 0.0;
+  for (;;) {  // weighted: move whole rounds into the tail until the slowest XCD's share of it is not negative
+    if (R < 1 || tail <= 0) return false;
+    bool ok = true;
+    sum = 0.0;
+    for (int x = 0; x < 8; ++x) {
+      double sx = (double)(tail * nk) / 8.0;  // tail steps of XCD x (all of its workgroups)
+      if (w) {
+        double sw = 0.0;
+        for (int i = 0; i < 8; ++i) sw += w[i];
+        sx = w[x] * (double)total / sw - (double)(R * nk * gx);  // its share of everything, minus its whole-tile rounds
+        if (sx < 0.25 * (double)(nk * gx)) ok = false;
+      }
+      want[x] = sx;
+      sum += sx;
+    }
+    if (ok) break;
+    R -= 1;
+    tail += G;
+  }
+  const int64_t tail_steps = tail * nk;
+  if (!(sum > 0.0)) return false;
+  plan.dp_rounds = (int)R;
+  plan.P[0] = 0;
+  double cum = 0.0;
+  for (int x = 0; x < 8; ++x) {
+    cum += want[x];
+    int64_t p = x == 7 ? tail_steps : (int64_t)((double)tail_steps * (cum / sum) + 0.5);
+    if (p < plan.P[x]) p = plan.P[x];
+    if (p > tail_steps) p = tail_steps;
+    plan.P[x + 1] = (int)p;
+    const int64_t len = p - plan.P[x];
+    plan.S[x] = (int)((len + gx - 1) / gx);
+    if (plan.S[x] < 1) plan.S[x] = 1;
+  }
+  tail_tiles = tail;
+  return true;
+}
+
 // C (M,N) = opA(A)·opB(B) [+ bias | + R], contraction length K (multiple of 32).  n_split > 1: C is a slab buffer.
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
@@ -767,7 +837,14 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   const int64_t rounds = (n_tiles + n_cu() - 1) / n_cu();
   const double fill = (double)n_tiles / (double)(rounds * n_cu());
   static const double sk_fill = [] { const char* e = getenv("STLT_GEMM_SK_FILL"); return e ? atof(e) : 0.9; }();  // A/B knob
-  if (n_split == 1 && t_gemm_scratch && fill < sk_fill && n_tiles * nk < 0x7fffffffLL && !g_stlt_debug_buf) {
+  // with XCD weights, well-filled launches of at least four rounds get a weighted tail too (if a plan exists)
+  bool weighted = false;
+  if (xcd_weights() && n_split == 1 && t_gemm_scratch && fill >= sk_fill && n_tiles >= 4 * (int64_t)n_cu() && n_tiles * nk < 0x7fffffffLL) {
+    SkPlan probe{};
+    int64_t tail = 0;
+    weighted = make_sk_plan(n_tiles, nk, n_cu() < STLT_GEMM_SK_MAX_WG ? n_cu() : STLT_GEMM_SK_MAX_WG, xcd_weights(), true, probe, tail);
+  }
+  if (n_split == 1 && t_gemm_scratch && (fill < sk_fill || weighted) && n_tiles * nk < 0x7fffffffLL && !g_stlt_debug_buf) {
     int64_t G = n_cu() < STLT_GEMM_SK_MAX_WG ? n_cu() : STLT_GEMM_SK_MAX_WG;
     if (n_tiles * nk < 4 * G) G = (n_tiles * nk + 3) / 4;  // at least ~4 k-steps per workgroup
     if (t_gemm_scratch_bytes >= (size_t)(2 * G) * BM * BN * sizeof(float)) {
@@ -780,17 +857,10 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
       static const bool hybrid_on = [] { const char* e = getenv("STLT_GEMM_HYBRID"); return e ? atoi(e) != 0 : true; }();
       SkPlan plan{};
       int64_t fix_tiles = n_tiles;
-      if (hybrid_on && ws_sk && (G & 7) == 0 && G == n_cu() && n_tiles > G) {
-        int64_t R = n_tiles / G, tail = n_tiles - R * G;
-        if (tail * nk < 4 * G) { R -= 1; tail += G; }
-        if (R >= 1 && tail > 0) {
-          const int64_t tail_steps = tail * nk, gx = G >> 3;
-          const int64_t Sx = (tail_steps + G - 1) / G;  // equal ranges (per-XCD lengths are the hook for clock-weighted ones)
-          plan.dp_rounds = (int)R;
-          for (int x = 0; x <= 8; ++x) { const int64_t v = x * gx * Sx; plan.P[x] = (int)(v < tail_steps ? v : tail_steps); }
-          for (int x = 0; x < 8; ++x) plan.S[x] = (int)Sx;
-          fix_tiles = tail;
-        }
+      if (hybrid_on && ws_sk && G == n_cu()) {
+        int64_t tail = 0;
+        if (make_sk_plan(n_tiles, nk, G, xcd_weights(), weighted, plan, tail)) fix_tiles = tail;
+        else plan = SkPlan{};
       }
 #define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan)
 #define LAUNCH_SK(ACTV, TAV, TBV, ADDV) do { if (ws_sk) LAUNCH_SK1(ACTV, TAV, TBV, ADDV, true, dim3(GEMM_THREADS_WS)); else LAUNCH_SK1(ACTV, TAV, TBV, ADDV, false, block); } while (0)
