@@ -222,7 +222,8 @@ int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const floa
                      float* logits_ensemble, stlt_stream_t stream);
 /* The same with STLT_FLAG_SKIP_PADDING accepted in `flags`: the layout branch runs on the real tokens / frames only (the
  * collater's masks, as for stlt_forward); padded frames' rows of the (B,T,d) layout state are zero — downstream they are
- * only masked keys (models.py:403-431) — so the logits are those of the padded schedule to rounding. */
+ * only masked keys (models.py:403-431) — so the logits are those of the padded schedule to rounding.  Like stlt_forward
+ * with that flag it synchronises the stream once (two row counts are read back to size the launches). */
 int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, const float* appearance_features, void* workspace,
                            size_t workspace_bytes, int flags, float* logits_caf, float* logits_stlt, float* logits_resnet3d,
                            float* logits_ensemble, stlt_stream_t stream);
