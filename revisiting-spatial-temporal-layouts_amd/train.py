@@ -22,21 +22,34 @@ from . import dist as D
 
 
 def add_weight_decay(model: torch.nn.Module, weight_decay: float) -> List[dict]:
-    decay, no_decay = [], []
-    for name, param in model.named_parameters():
-        if not param.requires_grad:
-            continue  # frozen weights
-        (no_decay if (param.dim() == 1 or name.endswith(".bias")) else decay).append(param)
-    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+    """The optimizer's two parameter groups (contract of train_inference_utils.py:37-54): group 0, no decay, holds the
+    trainable vectors — biases, LayerNorm scales, anything one-dimensional; group 1 holds the trainable matrices."""
+    groups = ([], [])
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            is_matrix = p.dim() > 1 and not name.endswith(".bias")
+            groups[int(is_matrix)].append(p)
+    return [dict(params=groups[0], weight_decay=0.0), dict(params=groups[1], weight_decay=weight_decay)]
+
+
+class _WarmupThenLinearDecay:
+    """Learning-rate factor of the reference's schedule (train_inference_utils.py:20-34): 0 -> 1 over the warm-up steps,
+    then a straight line down to 0 at the last training step, never negative."""
+
+    def __init__(self, warmup_steps: int, total_steps: int):
+        self.warmup = max(1, int(warmup_steps))
+        self.ramp_steps = int(warmup_steps)
+        self.total = int(total_steps)
+        self.decay_span = max(1, self.total - self.ramp_steps)
+
+    def __call__(self, step: int) -> float:
+        if step < self.ramp_steps:
+            return step / self.warmup
+        return max(0.0, (self.total - step) / self.decay_span)
 
 
 def linear_schedule_with_warmup(optimizer, num_warmup_steps: int, num_training_steps: int):
-    def lr_lambda(step: int) -> float:
-        if step < num_warmup_steps:
-            return float(step) / float(max(1, num_warmup_steps))
-        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
-
-    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, _WarmupThenLinearDecay(num_warmup_steps, num_training_steps))
 
 
 def criterion(logits: Dict[str, torch.Tensor], labels: torch.Tensor, dataset_name: str = "something") -> torch.Tensor:
