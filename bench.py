@@ -48,6 +48,108 @@ def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only):
     return f
 
 
+def _build_model(pkg, torch, dev, config, dropout=None, train=False):
+    kw = pkg.synth.model_kwargs(config)
+    if dropout is not None:
+        kw["hidden_dropout_prob"] = dropout
+    model = pkg.Stlt(pkg.StltModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    model.load_state_dict(sd)
+    model.train(train)
+    model.to(dev)
+    return model, sd
+
+
+def _attn_rooflines(k_ms, B, T, N, d):
+    """HBM rooflines of the two attention-core passes from the library's per-launch events (SURVEY 8d byte counts)."""
+    out = {}
+    for key, nbytes in (("attn_temporal", B * (16.0 * T * d + T)), ("attn_spatial", B * (16.0 * T * N * d + T * N))):
+        ms, n = k_ms.get(key, (0.0, 0))
+        gbs = nbytes / (ms / max(n, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[key] = {"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "us_per_launch": round(ms / max(n, 1) * 1e3, 2), "launches_per_step": n}
+    return out
+
+
+def side_forward_leg(pkg, torch, dev, config, B, steps, warmup):
+    """A bounded forward measurement of another workload (cfg4, or cfg2 at the reference's default batch) for the default
+    line's sub-objects: wall-clock ms per step, clips/s, and the GEMM / attention rooflines from the library's events."""
+    c = pkg.synth.CONFIGS[config]
+    model, _ = _build_model(pkg, torch, dev, config)
+    T, N, d = c["T"], c["N"], c["hidden_size"]
+    batch = {k: v.to(dev) for k, v in pkg.synth.make_batch(B, T, N, dataset=c["dataset"], seed=2000).items()}
+
+    def step():
+        with torch.no_grad():
+            return model(batch)["stlt"]
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    pkg.ops.prof_take_gemm_flops()
+    pkg.ops.prof_enable(True)
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        prof = pkg.ops.prof_collect()
+        gflops = pkg.ops.prof_take_gemm_flops() / steps
+    finally:
+        pkg.ops.prof_enable(False)
+    k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
+    gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
+    tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    at = _attn_rooflines(k_ms, B, T, N, d)
+    return {"workload": f"{config}: STLT forward, T={T}, N={N}, d={d}, {c['num_classes']} classes", "per_gpu_batch": B, "steps": steps, "warmup": warmup,
+            "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                         "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
+            "roofline_attn_temporal": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **at["attn_temporal"]),
+            "roofline_attn_spatial": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **at["attn_spatial"])}
+
+
+def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
+    """BASELINE config 3 on one GPU for the default line's `train_step` sub-object: the same step `--mode train` times."""
+    c = pkg.synth.CONFIGS[config]
+    model, _ = _build_model(pkg, torch, dev, config, dropout=0.1, train=True)
+    tr = pkg.train.Trainer(model, "something" if c["dataset"] == "something" else "action_genome", learning_rate=5e-5, weight_decay=1e-3, clip_val=5.0,
+                           warmup_steps=2, total_steps=100000)
+    cpu_batch = pkg.synth.make_batch(B, c["T"], c["N"], dataset=c["dataset"], seed=1000)
+    cpu_batch["labels"] = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(0))
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+    for _ in range(warmup):
+        tr.step(batch)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = tr.step(batch)
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    pkg.ops.prof_take_gemm_flops()
+    pkg.ops.prof_enable(True)
+    try:
+        for _ in range(steps):
+            tr.step(batch)
+        torch.cuda.synchronize(dev)
+        prof = pkg.ops.prof_collect()
+        gflops = pkg.ops.prof_take_gemm_flops() / steps
+    finally:
+        pkg.ops.prof_enable(False)
+    k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
+    gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
+    tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return {"workload": f"{config}: STLT optimisation step (forward with tape, loss, reverse sweep, clip 5.0, AdamW), dropout 0.1", "per_gpu_batch": B,
+            "steps": steps, "warmup": warmup, "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4),
+            "roofline": {"kernel": "gemm_nt_kernel, forward + dX + dW products", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4),
+                         "flops_per_step": gflops},
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()}, "loss": float(res["loss"]), "grad_norm": float(res["grad_norm"])}
+
+
 def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu):
     """--mode train: one optimisation step of the reference's train() loop (src/train.py:119-135) per step."""
     c = pkg.synth.CONFIGS[args.config]
@@ -178,6 +280,8 @@ def main():
                                                            "number of 256-tile rounds), 64 for --mode train (the reference's batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-skip-padding", action="store_true", help="do not time the opt-in skip-padding variant after the main measurement (profiling runs)")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the bounded sub-measurements of the default line (train_step, cfg4, small_batch)")
+    ap.add_argument("--side-legs", action="store_true", help="run the sub-measurements at any --batch (they ride on the default cfg2 / 1024-clip line only otherwise)")
     ap.add_argument("--no-cls-only", action="store_true", help="dense schedule: run the last spatial / last temporal layer on every token")
     args = ap.parse_args()
     if args.batch is None:
@@ -334,6 +438,17 @@ def main():
                                        "logit_max_abs_diff_vs_padded": float((sk_logits - logits).abs().max())}
             except Exception as exc:  # the secondary legs must never cost the main line
                 out["skip_padding"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and not args.no_side_legs and args.config == "cfg2" and (B == 1024 or args.side_legs):
+            # BASELINE configs 3 / 4 and the reference's default batch on the same clock as the headline line (bounded: a few
+            # seconds each); `value` above is untouched.  Each leg frees its buffers before the next one starts.
+            for key, fn in (("train_step", lambda: side_train_leg(pkg, torch, dev, "cfg2", 64, 10, 3)),
+                            ("cfg4", lambda: side_forward_leg(pkg, torch, dev, "cfg4", 64, 10, 3)),
+                            ("small_batch", lambda: side_forward_leg(pkg, torch, dev, "cfg2", 64, 20, 5))):
+                try:
+                    out[key] = fn()
+                except Exception as exc:  # the secondary legs must never cost the main line
+                    out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 from oracle import stlt_oracle as O

@@ -238,8 +238,9 @@ int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, cons
  * buffer of that parameter or NULL to skip it (frozen / unused parameters; models.py:172-174).  `scratch` must be
  * zero-filled once by the caller as well.  Embedding rows at padding_idx 0 receive no gradient (models.py:22,91).
  * Dropout (nn.Dropout after both embedding LayerNorms; attention probabilities, dropout1, FFN dropout and dropout2 of
- * every encoder layer — SURVEY.md App. B) is a counter-based mask: element idx of site s is kept iff the high 32 bits of
- * splitmix64(idx + seed*0x9E3779B97F4A7C15 + s*0xD1B54A32D192ED03) are >= p*2^32, kept values are scaled by 1/(1-p).
+ * every encoder layer — SURVEY.md App. B) is a counter-based mask: with key = splitmix64-finaliser(seed*0x9E3779B97F4A7C15
+ * + s*0xD1B54A32D192ED03), element idx of site s is kept iff the keyed 32-bit mixer of csrc/common.h (stlt_keep_k: two
+ * multiply-xorshift rounds over idx + key_lo, key_hi folded in between) is >= p*2^32; kept values are scaled by 1/(1-p).
  * The backward recomputes the masks from (p, seed): pass the same values to both calls.  p = 0 disables it.
  * Attention backward supports sequences of up to 256 tokens (the position table). */
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);

@@ -36,19 +36,32 @@ _LAYER_KEYS = (
 
 # ---- train-mode dropout: the build's counter-based masks restated (include/stlt_hip.h, "training step") -------------
 # The reference uses nn.Dropout at six sites; its Philox stream cannot be reproduced, so the mask
-# DEFINITION is the build's own: keep iff high32(mix(idx + seed*G1 + site*G2)) >= p*2^32 with the splitmix64 finaliser.
+# DEFINITION is the build's own (csrc/common.h: stlt_keep): key = splitmix64-finaliser(seed*G1 + site*G2); keep iff
+# mix32(idx; key) >= p*2^32 with a keyed two-round 32-bit multiply-xorshift (cheap enough for a GEMM epilogue).
 _M64 = (1 << 64) - 1
+_M32 = (1 << 32) - 1
+
+
+def dropout_key(seed: int, site: int) -> int:
+    z = (seed * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
 
 
 def dropout_keep(p: float, seed: int, site: int, idx: "np.ndarray"):
     import numpy as np
+    key = dropout_key(seed, site)
+    k0, k1 = np.uint32(key & _M32), np.uint32(key >> 32)
+    idx = idx.astype(np.uint64)
     with np.errstate(over="ignore"):
-        z = idx.astype(np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & _M64) + np.uint64((site * 0xD1B54A32D192ED03) & _M64)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
+        x = (idx & np.uint64(_M32)).astype(np.uint32) + k0 + (idx >> np.uint64(32)).astype(np.uint32) * np.uint32(0x9E3779B9)
+        x = (x ^ (x >> np.uint32(16))) * np.uint32(0x7FEB352D)
+        x = x ^ k1
+        x = (x ^ (x >> np.uint32(15))) * np.uint32(0x846CA68B)
+        x = x ^ (x >> np.uint32(16))
     thr = min(int(p * 4294967296.0), 4294967295)
-    return (z >> np.uint64(32)) >= np.uint64(thr)
+    return x >= np.uint32(thr)
 
 
 class Dropout:

@@ -52,21 +52,35 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// Counter-based dropout: keep element `idx` of site `site` iff splitmix64(seed, site, idx) >= thr (thr = p * 2^32).
+// Counter-based dropout: keep element `idx` of site `site` iff mix32(idx; key(seed, site)) >= thr (thr = p * 2^32).
 // No mask is stored: the backward recomputes it.  Sites per encoder layer g (0.. spatial, then temporal):
 // 8g+0 attention probabilities, 8g+1 after out-proj, 8g+2 FFN hidden, 8g+3 after linear2; 0xE0 / 0xE1 = embedding outputs.
+// key = splitmix64 finaliser of seed*G1 + site*G2 (wave-uniform: scalar ALU); the per-element mixer is a keyed
+// two-round 32-bit multiply-xorshift (round-3 change: the 64-bit splitmix per element cost ~180 VALU cycles, which is
+// exposed once the mask is applied inside a GEMM epilogue; this one is ~55).  oracle/stlt_oracle.py restates it.
 struct StltDrop { uint32_t thr; float scale; uint64_t seed; };  // thr == 0: dropout off
-__device__ __forceinline__ bool stlt_keep(const StltDrop& dr, uint32_t site, uint64_t idx) {
-  uint64_t z = idx + dr.seed * 0x9E3779B97F4A7C15ull + (uint64_t)site * 0xD1B54A32D192ED03ull;
+__device__ __forceinline__ uint64_t stlt_drop_key(const StltDrop& dr, uint32_t site) {
+  uint64_t z = dr.seed * 0x9E3779B97F4A7C15ull + (uint64_t)site * 0xD1B54A32D192ED03ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32) >= dr.thr;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool stlt_keep_k(uint32_t thr, uint64_t key, uint64_t idx) {
+  uint32_t x = (uint32_t)idx + (uint32_t)key + (uint32_t)(idx >> 32) * 0x9E3779B9u;
+  x = (x ^ (x >> 16)) * 0x7FEB352Du;
+  x ^= (uint32_t)(key >> 32);
+  x = (x ^ (x >> 15)) * 0x846CA68Bu;
+  x ^= x >> 16;
+  return x >= thr;
+}
+__device__ __forceinline__ bool stlt_keep(const StltDrop& dr, uint32_t site, uint64_t idx) {
+  return stlt_keep_k(dr.thr, stlt_drop_key(dr, site), idx);
 }
 __device__ __forceinline__ f32x4 stlt_drop4(const StltDrop& dr, uint32_t site, uint64_t idx0, f32x4 v) {
+  const uint64_t key = stlt_drop_key(dr, site);
   f32x4 o;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) o[k] = stlt_keep(dr, site, idx0 + k) ? v[k] * dr.scale : 0.f;
+  for (int k = 0; k < 4; ++k) o[k] = stlt_keep_k(dr.thr, key, idx0 + k) ? v[k] * dr.scale : 0.f;
   return o;
 }
 inline StltDrop stlt_drop_make(float p, uint64_t seed) {
@@ -106,6 +120,20 @@ class StltGemmScratch {
   size_t prev_bytes_;
 };
 void stlt_gemm_set_scratch_impl(void* p, size_t bytes);
+// Grouped launch: several independent products of the same operand layout walked by ONE persistent stream-K launch (one
+// fix-up instead of one per product; a workgroup's range may run from one product's tiles into the next one's).  Used for
+// the weight gradients of an encoder layer: C_p (M_p, N_p) += A_pᵀ·B_p with A_p (Kc_p, M_p), B_p (Kc_p, N_p) row-major.
+constexpr int STLT_GEMM_GROUP_MAX = 32;
+struct StltGemmProblem { const float* a; const float* b; const float* r; float* c; int lda, ldb, ldr, ldc; int M, N, nk, tiles_n; };
+struct StltGemmGroup {
+  int n, pad;
+  int tile_base[STLT_GEMM_GROUP_MAX + 1];  // first tile of problem p in the launch's tile order (problem-major, then M, N fastest)
+  int step_base[STLT_GEMM_GROUP_MAX + 1];  // first k-step of problem p in the launch's flattened k-step space
+  StltGemmProblem p[STLT_GEMM_GROUP_MAX];
+};
+struct StltWeightGradItem { const float* dy; int64_t n_out; const float* x; int64_t k_in; int64_t rows; float* g_w; };  // g_w (n_out,k_in) += dy[:rows]ᵀ·x[:rows]
+int launch_weight_grad_group(const StltWeightGradItem* items, int n_items, hipStream_t s);  // needs lent stream-K scratch (StltGemmScratch); rows % 32 == 0
+bool stlt_gemm_has_scratch();
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
 int launch_reduce_slabs3(const float* slabs, int64_t stride, int n_slabs, float* dst0, float* dst1, float* dst2, int64_t n, int accumulate,
                          hipStream_t s);  // three destinations of n columns each, side by side in the slabs

@@ -110,7 +110,10 @@ __device__ __forceinline__ float gelu_epilogue(float x) {
 // ranges; equal today).  dp_rounds = 0: the plain stream-K assignment (G equal ranges over every tile).
 struct SkPlan { int dp_rounds; int P[9]; int S[8]; };
 
-template <int ACT, bool STAMP, bool TA, bool TB, bool ADD, bool SK, bool WS>
+// GROUP (with SK and WS): the launch walks the tiles of several products (StltGemmGroup, by value in the kernel arguments:
+// a wave reads the fields of the product its current tile belongs to with scalar loads); X / W / R / Y / M / N / K of the
+// single-product form are unused.  Plain stream-K assignment over the concatenated k-step space.
+template <int ACT, bool STAMP, bool TA, bool TB, bool ADD, bool SK, bool WS, bool GROUP = false>
 __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) void gemm_nt_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ W, int64_t ldw,
                                                                   const float* __restrict__ bias,
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
                                                                   int64_t slab_stride, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, int n_split,
                                                                   float* __restrict__ partials,
-                                                                  unsigned long long* __restrict__ dbg, const SkPlan plan) {
+                                                                  unsigned long long* __restrict__ dbg, const SkPlan plan,
+                                                                  const StltGemmGroup grp) {
+  static_assert(!GROUP || (SK && WS), "grouped launches are stream-K launches of the loader-wave build");
   constexpr int prio = STLT_GEMM_PRIO_MODE;
   constexpr int NBIAS = 2;  // bias strips, by tile parity
   __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + NBIAS * BN];  // operand stages + bias strips
@@ -130,8 +135,8 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64x64
   const int lr = lane & 31, lh = lane >> 5;
   const int nk_total = K / BK;
-  const int nk = nk_total / n_split;          // k-steps per work item (launcher guarantees divisibility)
-  const int n_tiles = tiles_m * tiles_n * n_split;  // work items: (output tile, contraction split), split fastest
+  int nk = GROUP ? 1 : nk_total / n_split;    // k-steps per work item (launcher guarantees divisibility); GROUP: of the wave's current tile
+  const int n_tiles = GROUP ? grp.tile_base[grp.n] : tiles_m * tiles_n * n_split;  // work items: (output tile, contraction split), split fastest
 
   // XCD-contiguous tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so virtual id
   // v = (b%8)*(G/8) + b/8 gives each XCD a contiguous run of tiles (N fastest: they share the X panel).
@@ -156,6 +161,26 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   const bool hy = SK && plan.dp_rounds > 0;  // hybrid: whole-tile rounds, then a stream-K tail
   const int hy_R = hy ? plan.dp_rounds : 0;
   int hy_steps = 0;
+  int g_p0 = 0, g_first = 0, g_nk_last = 1, g_total = 0;  // GROUP: product of the first tile, first global tile, nk of the last tile, steps
+  if constexpr (GROUP) {
+    const int total = grp.step_base[grp.n];
+    const int S = (total + G - 1) / G;
+    const int s0 = v * S;
+    if (s0 >= total) return;
+    const int s1 = s0 + S < total ? s0 + S : total;
+    while (grp.step_base[g_p0 + 1] <= s0) ++g_p0;
+    const int nk0 = grp.p[g_p0].nk;
+    const int lt0 = (s0 - grp.step_base[g_p0]) / nk0;
+    sk_kt0 = s0 - grp.step_base[g_p0] - lt0 * nk0;
+    g_first = grp.tile_base[g_p0] + lt0;
+    int p1 = g_p0;
+    while (grp.step_base[p1 + 1] <= s1 - 1) ++p1;
+    g_nk_last = grp.p[p1].nk;
+    const int lt1 = (s1 - 1 - grp.step_base[p1]) / g_nk_last;
+    my_tiles = grp.tile_base[p1] + lt1 - g_first + 1;
+    sk_tail = s1 - (grp.step_base[p1] + lt1 * g_nk_last);  // end offset inside the last tile (== its nk when the range ends on a tile boundary)
+    g_total = s1 - s0;
+  } else
   if (hy) {
     const int e = plan.P[g_xcd + 1];
     const int s0 = plan.P[g_xcd] + g_local * plan.S[g_xcd];
@@ -198,17 +223,34 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
     dbg[4 * blockIdx.x + 3] = my_tiles;
     dbg[4 * (size_t)gridDim.x + (size_t)gridDim.x * GEMM_WAVES * 6 + 1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime();  // shader clock, behind the stamp / trace regions
   }
-  const int total_steps = hy ? hy_R * nk + hy_steps : SK ? (my_tiles - 1) * nk + sk_tail - sk_kt0 : my_tiles * nk;
+  const int total_steps = GROUP ? g_total : hy ? hy_R * nk + hy_steps : SK ? (my_tiles - 1) * nk + sk_tail - sk_kt0 : my_tiles * nk;
   // does this workgroup compute every k-step of its it-th tile?  (otherwise the segment is a partial: no bias, raw store)
   auto seg_complete = [&](int it) {
     if (!SK) return true;
     if (it < hy_R) return true;
-    return (it > hy_R || sk_kt0 == 0) && (it < my_tiles - 1 || sk_tail == nk);
+    return (it > hy_R || sk_kt0 == 0) && (it < my_tiles - 1 || sk_tail == (GROUP ? g_nk_last : nk));
+  };
+  // GROUP: product and local tile of the workgroup's it-th tile (a range covers a few tiles: the scan is short)
+  auto group_tile = [&](int it, int& pi, int& lt) {
+    const int gt = g_first + it;
+    pi = g_p0;
+    while (grp.tile_base[pi + 1] <= gt) ++pi;
+    lt = gt - grp.tile_base[pi];
   };
   // first k-step of the it-th tile: only the first stream-K segment may begin inside a tile
   auto kt_begin = [&](int it) { return (SK && it == hy_R) ? sk_kt0 : 0; };
 
   auto tile_origin = [&](int it, int& m0, int& n0, int& split) {
+    if constexpr (GROUP) {
+      int pi, lt;
+      group_tile(it, pi, lt);
+      const int tn_all = grp.p[pi].tiles_n;
+      const int tm = lt / tn_all;
+      split = 0;
+      m0 = tm * BM;
+      n0 = (lt - tm * tn_all) * BN;
+      return;
+    }
     if (grouped || hy) {
       // hybrid: the whole-tile rounds take positions [0, R*G) XCD by XCD, the tail tiles follow in the same order
       const int p = hy ? (it < hy_R ? (g_xcd * hy_R + it) * g_gx + g_local : hy_R * G + sk_first + (it - hy_R))
@@ -239,12 +281,19 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   const float* pa[NV][4];
   const float* pb[NV][2];
   const int vw0 = WS ? 2 * (wave - GEMM_WAVES) : wave;  // first "virtual wave" whose DMA share this wave issues (WS: loaders only)
-  const int64_t a_kstep = TA ? (int64_t)BK * ldx : BK;
-  const int64_t b_kstep = TB ? (int64_t)BK * ldw : BK;
+  int64_t a_kstep = TA ? (int64_t)BK * ldx : BK;
+  int64_t b_kstep = TB ? (int64_t)BK * ldw : BK;
   auto dma_set_tile = [&](int it) {
     int m0, n0, split;
     tile_origin(it, m0, n0, split);
-    const int64_t kbase = (int64_t)split * nk * BK;  // first contraction index of this split
+    if constexpr (GROUP) {  // this tile's product (loader waves only: they own nk / the k strides of the DMA stream)
+      int pi, lt;
+      group_tile(it, pi, lt);
+      X = grp.p[pi].a; ldx = grp.p[pi].lda; W = grp.p[pi].b; ldw = grp.p[pi].ldb; M = grp.p[pi].M; N = grp.p[pi].N; nk = grp.p[pi].nk;
+      a_kstep = TA ? (int64_t)BK * ldx : BK;
+      b_kstep = TB ? (int64_t)BK * ldw : BK;
+    }
+    const int64_t kbase = GROUP ? 0 : (int64_t)split * nk * BK;  // first contraction index of this split
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int vw = vw0 + u;
@@ -383,7 +432,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
     __builtin_amdgcn_s_barrier();
     int w_it = 0, w_kt = kt_begin(0);  // position of the MFMA waves (the bias strip follows their tile changes)
     for (int step = 0; step < total_steps; ++step) {
-      if (w_kt == nk - 1 && w_it + 1 < my_tiles) dma_bias(w_it + 1);
+      if (!GROUP && w_kt == nk - 1 && w_it + 1 < my_tiles) dma_bias(w_it + 1);
       if (!(STLT_GEMM_ABLATE & 1) && step + 2 < total_steps) {
         l_step();
         if (!(STLT_GEMM_ABLATE & 8)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // step+1 landed; only step+2's 12 instructions may stay in flight
@@ -391,7 +440,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      if (++w_kt == nk) { ++w_it; w_kt = kt_begin(w_it); }
+      if (!GROUP && ++w_kt == nk) { ++w_it; w_kt = kt_begin(w_it); }
     }
     return;
   }
@@ -459,6 +508,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   Frags fa = read_frags(0, 0), fb;  // ping-pong fragment registers: 4 chunk reads per step, so fa is "current" at every step start
 
   int c_it = 0, c_kt = kt_begin(0);  // MFMA stream position
+  if constexpr (GROUP) nk = grp.p[g_p0].nk;  // k-steps of the MFMA stream's current tile
   int stage = 0;
   unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
 #define GSTAMP(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); t_acc[k] += t_now - t_prev; t_prev = t_now; __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -504,6 +554,11 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
       // k-steps are in flight; the barrier of this last k-step published the next tile's bias strip).
       int m0, n0, split;
       tile_origin(c_it, m0, n0, split);
+      if constexpr (GROUP) {  // the output side of this tile's product
+        int pi, lt;
+        group_tile(c_it, pi, lt);
+        Y = grp.p[pi].c; ldy = grp.p[pi].ldc; R = grp.p[pi].r; ldr = grp.p[pi].ldr; M = grp.p[pi].M; N = grp.p[pi].N;
+      }
       float* Yt = Y + (int64_t)split * slab_stride;
       const bool partial = SK && !seg_complete(c_it);
       // 16-byte stores need 16-byte aligned rows (wave-uniform test); otherwise, and on ragged tiles, guarded scalars
@@ -583,6 +638,9 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
       if (c_it + 1 < my_tiles) init_acc(c_it + 1, SK && !seg_complete(c_it + 1));
       ++c_it;
       c_kt = kt_begin(c_it);
+      if constexpr (GROUP) {
+        if (c_it < my_tiles) { int pi, lt; group_tile(c_it, pi, lt); nk = grp.p[pi].nk; }
+      }
       GSTAMP(5);  // epilogue
     }
   }
@@ -661,6 +719,47 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict
         if (R) val += R[(int64_t)m * ldr + n];
         if (ACT == STLT_ACT_GELU) val = gelu_epilogue(val);
         if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
+        Y[(int64_t)m * ldy + n] = val;
+      }
+    }
+  }
+}
+
+// Fix-up of a grouped stream-K launch (S k-steps per workgroup over the group's flattened k-step space): tile t of the
+// launch order belongs to product p = the last one with tile_base[p] <= t; its segments are summed in workgroup order and
+// added to the product's add-source (the weight gradient being accumulated).
+__global__ __launch_bounds__(256) void gemm_fixup_group_kernel(const float* __restrict__ partials, int S, const StltGemmGroup grp) {
+  const int t = blockIdx.x / FIXUP_CHUNKS, chunk = blockIdx.x - t * FIXUP_CHUNKS;
+  int pi = 0;
+  while (grp.tile_base[pi + 1] <= t) ++pi;
+  const int lt = t - grp.tile_base[pi];
+  const int nk = grp.p[pi].nk;
+  const int lo = grp.step_base[pi] + lt * nk, hi = lo + nk;
+  const int v_first = lo / S, v_last = (hi - 1) / S;
+  if (v_first == v_last) return;  // one workgroup computed the whole tile and stored it
+  const int tn_all = grp.p[pi].tiles_n;
+  const int tm = lt / tn_all;
+  const int m0 = tm * BM, n0 = (lt - tm * tn_all) * BN;
+  const int M = grp.p[pi].M, N = grp.p[pi].N;
+  const float* __restrict__ R = grp.p[pi].r;
+  float* __restrict__ Y = grp.p[pi].c;
+  const int64_t ldr = grp.p[pi].ldr, ldy = grp.p[pi].ldc;
+  const int c4 = (threadIdx.x & 31) * 4;
+  const int r_end = (chunk + 1) * (BM / FIXUP_CHUNKS);
+  for (int rr = chunk * (BM / FIXUP_CHUNKS) + (threadIdx.x >> 5); rr < r_end; rr += 8) {
+    const int m = m0 + rr;
+    if (m >= M) break;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int v = v_first; v <= v_last; ++v) {
+      const size_t slot = (size_t)(2 * v + (v * S >= lo ? 0 : 1));
+      acc += *reinterpret_cast<const f32x4*>(partials + slot * (BM * BN) + rr * BN + c4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + c4 + e;
+      if (n < N) {
+        float val = acc[e];
+        if (R) val += R[(int64_t)m * ldr + n];
         Y[(int64_t)m * ldy + n] = val;
       }
     }
@@ -862,7 +961,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
         if (make_sk_plan(n_tiles, nk, G, xcd_weights(), weighted, plan, tail)) fix_tiles = tail;
         else plan = SkPlan{};
       }
-#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan)
+#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan, StltGemmGroup{})
 #define LAUNCH_SK(ACTV, TAV, TBV, ADDV) do { if (ws_sk) LAUNCH_SK1(ACTV, TAV, TBV, ADDV, true, dim3(GEMM_THREADS_WS)); else LAUNCH_SK1(ACTV, TAV, TBV, ADDV, false, block); } while (0)
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
       else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
@@ -886,7 +985,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   // wave-specialised build (4 DMA-only waves beside the 8 MFMA waves) unless STLT_GEMM_WS=0 (A/B measurements)
   static const bool ws = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
   const dim3 block_ws(GEMM_THREADS_WS);
-#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf, SkPlan{})
+#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf, SkPlan{}, StltGemmGroup{})
 #define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws) LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
@@ -898,6 +997,54 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 #undef LAUNCH
 #undef LAUNCH1
   return stlt_check_launch("gemm_nt_kernel");
+}
+
+bool stlt_gemm_has_scratch() { return t_gemm_scratch != nullptr && t_gemm_scratch_bytes >= STLT_GEMM_SCRATCH_BYTES; }
+
+// g_w_i (n_out_i, k_in_i) += dy_i[:rows_i]ᵀ · x_i[:rows_i] for every item, as ONE stream-K launch + one fix-up: every CU gets
+// an equal share of the group's k-steps, a workgroup's range may cross from one product into the next.  Deterministic
+// (fixed summation order), like the per-product launches it replaces.
+int launch_weight_grad_group(const StltWeightGradItem* items, int n_items, hipStream_t s) {
+  if (!items || n_items < 1 || n_items > STLT_GEMM_GROUP_MAX) return stlt_set_error(STLT_EINVAL, "weight_grad_group: 1..%d items", STLT_GEMM_GROUP_MAX);
+  if (!stlt_gemm_has_scratch()) return stlt_set_error(STLT_EWORKSPACE, "weight_grad_group: no stream-K scratch lent (StltGemmScratch)");
+  StltGemmGroup grp{};
+  int64_t tiles = 0, steps = 0;
+  double flops = 0.0;
+  int n = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const StltWeightGradItem& it = items[i];
+    if (!it.g_w || it.rows == 0) continue;
+    if (!it.dy || !it.x || it.n_out <= 0 || it.k_in <= 0 || it.rows < 0 || it.rows % BK != 0 || it.n_out % 4 != 0 || it.k_in % 4 != 0)
+      return stlt_set_error(STLT_EINVAL, "weight_grad_group: item %d: rows=%lld must be a multiple of %d, n_out=%lld / k_in=%lld multiples of 4", i,
+                            (long long)it.rows, BK, (long long)it.n_out, (long long)it.k_in);
+    if (it.n_out > 0x7fffff00LL || it.k_in > 0x7fffff00LL || it.rows > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "weight_grad_group: item too large");
+    const int64_t tm = (it.n_out + BM - 1) / BM, tn = (it.k_in + BN - 1) / BN;
+    StltGemmProblem& q = grp.p[n];
+    q.a = it.dy; q.lda = (int)it.n_out; q.b = it.x; q.ldb = (int)it.k_in; q.r = it.g_w; q.ldr = (int)it.k_in; q.c = it.g_w; q.ldc = (int)it.k_in;
+    q.M = (int)it.n_out; q.N = (int)it.k_in; q.nk = (int)(it.rows / BK); q.tiles_n = (int)tn;
+    grp.tile_base[n] = (int)tiles;
+    grp.step_base[n] = (int)steps;
+    tiles += tm * tn;
+    steps += tm * tn * (it.rows / BK);
+    if (tiles > 0x3fffffffLL || steps > 0x3fffffffLL) return stlt_set_error(STLT_EINVAL, "weight_grad_group: too many k-steps");
+    flops += 2.0 * (double)it.n_out * (double)it.k_in * (double)it.rows;
+    ++n;
+  }
+  if (n == 0) return 0;
+  grp.n = n;
+  for (int i = n; i <= STLT_GEMM_GROUP_MAX; ++i) { grp.tile_base[i] = (int)tiles; grp.step_base[i] = (int)steps; }  // sentinels: scans stop at the end
+  int64_t G = n_cu() < STLT_GEMM_SK_MAX_WG ? n_cu() : STLT_GEMM_SK_MAX_WG;
+  if (steps < 4 * G) G = (steps + 3) / 4;
+  const int S = (int)((steps + G - 1) / G);
+  StltProfScope ps(STLT_K_GEMM, s);
+  stlt_prof_add_flops(flops);
+  float* P = t_gemm_scratch;
+  hipLaunchKernelGGL((gemm_nt_kernel<STLT_ACT_NONE, false, true, true, true, true, true, true>), dim3((unsigned)G), dim3(GEMM_THREADS_WS), 0, s,
+                     (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, (int64_t)0,
+                     (float*)nullptr, (int64_t)0, (int64_t)0, 0, 0, BK, 0, 0, 1, P, (unsigned long long*)nullptr, SkPlan{}, grp);
+  if (int e = stlt_check_launch("gemm_nt_kernel(grouped stream-k)")) return e;
+  hipLaunchKernelGGL(gemm_fixup_group_kernel, dim3((unsigned)(tiles * FIXUP_CHUNKS)), dim3(256), 0, s, P, S, grp);
+  return stlt_check_launch("gemm_fixup_group_kernel");
 }
 
 StltGemmScratch::StltGemmScratch(void* p, size_t bytes) : prev_(t_gemm_scratch), prev_bytes_(t_gemm_scratch_bytes) {

@@ -9,6 +9,7 @@
 //   | per temporal layer: same 8 buffers on BT rows | x_tp_out | head: h0, u0, z1, z2 (B rows)
 //   layer math:  qkv = x·Winᵀ+b ; ctx = attn(qkv) ; a = ctx·Woᵀ+bo ; x1 = LN1(x+a) ; u = x1·W1ᵀ+b1 ; h = gelu(u) ;
 //                f = h·W2ᵀ+b2 ; y = LN2(x1+f)   (y is the next layer's x)
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -58,8 +59,8 @@ static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, 
 // backward scratch: gradient buffers for the spatial phase (tok rows) and, separately, the temporal phase (BT
 // rows) so that each one's row padding stays zero; split-K slabs; reduction scratch.
 struct Scratch {
-  float *sA, *sB, *sC, *sD, *sQKV, *sH;  // spatial: (tokp,d) x4, (tokp,3d), (tokp,4d)
-  float *tA, *tB, *tC, *tD, *tQKV, *tH;  // temporal
+  float *sA, *sB, *sC, *sD, *sE, *sQKV, *sH;  // spatial: (tokp,d) x5, (tokp,3d), (tokp,4d)
+  float *tA, *tB, *tC, *tD, *tE, *tQKV, *tH;  // temporal
   float *hA, *hB;                   // head: (bp,d) x2
   float* slabs;
   float* red;
@@ -75,8 +76,8 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   const int64_t tokp = up32(B * T * N), btp = up32(B * T), bp = up32(B);
   size_t off = 0;
   auto take = [&](int64_t floats) { float* p = (float*)(base + off); off = align256(off + (size_t)floats * sizeof(float)); return p; };
-  s.sA = take(tokp * d); s.sB = take(tokp * d); s.sC = take(tokp * d); s.sD = take(tokp * d); s.sQKV = take(tokp * 3 * d); s.sH = take(tokp * 4 * d);
-  s.tA = take(btp * d); s.tB = take(btp * d); s.tC = take(btp * d); s.tD = take(btp * d); s.tQKV = take(btp * 3 * d); s.tH = take(btp * 4 * d);
+  s.sA = take(tokp * d); s.sB = take(tokp * d); s.sC = take(tokp * d); s.sD = take(tokp * d); s.sE = take(tokp * d); s.sQKV = take(tokp * 3 * d); s.sH = take(tokp * 4 * d);
+  s.tA = take(btp * d); s.tB = take(btp * d); s.tC = take(btp * d); s.tD = take(btp * d); s.tE = take(btp * d); s.tQKV = take(btp * 3 * d); s.tH = take(btp * 4 * d);
   s.hA = take(bp * d); s.hB = take(bp * d);
   s.slab_floats = (size_t)MAX_SPLIT * 4 * d * d;
   s.slabs = take((int64_t)s.slab_floats);
@@ -113,42 +114,57 @@ static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k
   return launch_reduce_slabs(sc.slabs, n_out * k_in, split, g_w, n_out * k_in, 1, s);
 }
 
+// The weight gradients of a layer as ONE grouped stream-K launch (gemm.hip: launch_weight_grad_group) when stream-K
+// scratch is lent, else product by product.  Every CU gets an equal share of the four products' k-steps: one pipeline
+// fill, at most two partial tiles per workgroup and one fix-up for the layer instead of four of each.
+static int weight_grad_all(const StltWeightGradItem* items, int n, const Scratch& sc, hipStream_t s) {
+  static const bool grouped = [] { const char* e = getenv("STLT_GEMM_GROUP_DW"); return e ? atoi(e) != 0 : true; }();  // A/B knob
+  if (grouped && sc.sk && stlt_gemm_has_scratch()) return launch_weight_grad_group(items, n, s);
+  for (int i = 0; i < n; ++i) TRY(weight_grad(items[i].dy, items[i].n_out, items[i].x, items[i].k_in, items[i].rows, items[i].g_w, sc, s));
+  return 0;
+}
+
 // backward of one encoder layer.  dy: gradient wrt the layer output (M,d) in bufA; on return bufA holds the gradient
-// wrt the layer input.  bufB / bufC / bufD (M,d), bufQ (M,3d), bufH (M,4d) are scratch with zero row padding.
-// With dropout on, bufD receives the gradient wrt the un-dropped branch output (ds * mask / (1-p)) while bufB keeps
-// the residual-path gradient.
+// wrt the layer input.  bufB / bufC / bufD / bufE (M,d), bufQ (M,3d), bufH (M,4d) are scratch with zero row padding.
+// The four output gradients of the layer's Linears (df, du, da, dqkv) stay alive until the end of the layer, where their
+// weight gradients run as one grouped launch: df in bufD (dropout on: the gradient wrt the un-dropped branch output,
+// ds * mask / (1-p)) or bufB (dropout off: the residual-path gradient is the branch gradient), du in bufH, da in bufE,
+// dqkv in bufQ.
 static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
                           int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, float* bufA, float* bufB,
-                          float* bufC, float* bufD, float* bufQ, float* bufH, const Scratch& sc, StltDrop dr, uint32_t site0,
+                          float* bufC, float* bufD, float* bufE, float* bufQ, float* bufH, const Scratch& sc, StltDrop dr, uint32_t site0,
                           hipStream_t s, const AttnBwdRagged* rg = nullptr) {
   auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
-  float* br = dr.thr ? bufD : bufB;  // branch gradient (after the dropout mask)
+  float* df = dr.thr ? bufD : bufB;   // gradient wrt f (after the dropout mask)
+  float* ds1 = dr.thr ? bufB : bufE;  // residual-path gradient behind norm1 (bufB's ds2 is dead by then when dropout is on)
+  float* da = bufE;                   // gradient wrt a
   // y = LN2(x1 + drop(f))
   TRY(launch_ln_bwd(bufA, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm2_w),
                     G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0,
-                    G(&stlt_layer_params::lin2_b)));                                               // bufB = ds2, br = df; lin2_b += colsum(df)
+                    G(&stlt_layer_params::lin2_b)));                                               // bufB = ds2, df; lin2_b += colsum(df)
   // f = h·W2ᵀ + b2
-  TRY(weight_grad(br, d, t.h, 4 * d, Mp, G(&stlt_layer_params::lin2_w), sc, s));
-  TRY(launch_gemm(0, 1, br, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, M, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
+  TRY(launch_gemm(0, 1, df, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, M, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
   // h = drop(gelu(u))
   if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_gelu_bwd_colsum(bufH, t.u, bufH, M, 4 * d, gb, sc.red, s, dr, site0 + 2));  // bufH = du; lin1_b += colsum(du)
   else TRY(launch_gelu_bwd(bufH, t.u, bufH, M * 4 * d, s, dr, site0 + 2));
   // u = x1·W1ᵀ + b1
-  TRY(weight_grad(bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w), sc, s));
   TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, M, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x + drop(a))
-  TRY(launch_ln_bwd(bufC, d, t.x, d, t.a, d, lp.norm1_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm1_w),
-                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufD, 0,
-                    G(&stlt_layer_params::out_proj_b)));                                           // bufB = ds1, br = da; out_proj_b += colsum(da)
+  TRY(launch_ln_bwd(bufC, d, t.x, d, t.a, d, lp.norm1_w, 1e-5f, M, d, ds1, d, G(&stlt_layer_params::norm1_w),
+                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufE, 0,
+                    G(&stlt_layer_params::out_proj_b)));                                           // ds1, da; out_proj_b += colsum(da)
   // a = ctx·Woᵀ + bo
-  TRY(weight_grad(br, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w), sc, s));
-  TRY(launch_gemm(0, 1, br, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
+  TRY(launch_gemm(0, 1, da, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
   // ctx = attention(qkv) with dropout on the probabilities
   TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv; in_proj_b += colsum(dqkv)
   // qkv = x·Winᵀ + bin
-  TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
-  TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, bufB, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
-  return 0;
+  TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, ds1, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
+  // the four weight gradients (off the dX chain): one grouped launch
+  const StltWeightGradItem items[4] = {{df, d, t.h, 4 * d, Mp, G(&stlt_layer_params::lin2_w)},
+                                       {bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w)},
+                                       {da, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w)},
+                                       {bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w)}};
+  return weight_grad_all(items, 4, sc, s);
 }
 
 static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
@@ -203,37 +219,42 @@ static int zero_rows(float* buf, int64_t width, int64_t r0, int64_t r1, hipStrea
 // zeroed between n and its round-up to 32 first (those rows belong to other layers' data in the shared buffers).
 static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
                                int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, const int* rows, int64_t n,
-                               const float* dy, float* bufA, float* bufB, float* bufC, float* bufD, float* bufQ, float* bufH,
+                               const float* dy, float* bufA, float* bufB, float* bufC, float* bufD, float* bufE, float* bufQ, float* bufH,
                                const Scratch& sc, StltDrop dr, uint32_t site0, hipStream_t s, const AttnBwdRagged* rg) {
   auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
   const int64_t np = up32(n);
-  float* br = dr.thr ? bufD : bufB;
+  float* df = dr.thr ? bufD : bufB;
+  float* ds1 = dr.thr ? bufB : bufE;
+  float* da = bufE;
   TRY(zero_rows(bufB, d, n, np, s));
   TRY(zero_rows(bufD, d, n, np, s));
+  TRY(zero_rows(bufE, d, n, np, s));
   TRY(zero_rows(bufH, 4 * d, n, np, s));
   // y = LN2(x1 + drop(f))
   TRY(launch_ln_bwd(dy, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, n, d, bufB, d, G(&stlt_layer_params::norm2_w),
                     G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0, G(&stlt_layer_params::lin2_b), rows));
-  TRY(weight_grad(br, d, t.h, 4 * d, np, G(&stlt_layer_params::lin2_w), sc, s));
-  TRY(launch_gemm(0, 1, br, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, n, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
+  TRY(launch_gemm(0, 1, df, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, n, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
   if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_gelu_bwd_colsum(bufH, t.u, bufH, n, 4 * d, gb, sc.red, s, dr, site0 + 2, rows));
   else TRY(launch_gelu_bwd(bufH, t.u, bufH, n * 4 * d, s, dr, site0 + 2, rows, 4 * d));
-  TRY(weight_grad(bufH, 4 * d, t.x1, d, np, G(&stlt_layer_params::lin1_w), sc, s));
   TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, n, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x[rows] + drop(a)), a = ctx[rows]·Woᵀ + bo: gather the two inputs again (bufQ is free until the attention backward)
   float* g_x = bufQ;
   float* g_ctx = bufQ + np * d;
   TRY(launch_gather_rows(t.x, d, rows, n, d, g_x, s));
   TRY(launch_gather_rows(t.ctx, d, rows, n, d, g_ctx, s));
-  TRY(launch_ln_bwd(bufC, d, g_x, d, t.a, d, lp.norm1_w, 1e-5f, n, d, bufB, d, G(&stlt_layer_params::norm1_w),
-                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufD, 0, G(&stlt_layer_params::out_proj_b), rows));  // bufB = ds1, br = da
-  TRY(weight_grad(br, d, g_ctx, d, np, G(&stlt_layer_params::out_proj_w), sc, s));
-  TRY(launch_gemm(0, 1, br, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, n, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx of the picked rows
+  TRY(launch_ln_bwd(bufC, d, g_x, d, t.a, d, lp.norm1_w, 1e-5f, n, d, ds1, d, G(&stlt_layer_params::norm1_w),
+                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufE, 0, G(&stlt_layer_params::out_proj_b), rows));  // ds1, da
+  TRY(launch_gemm(0, 1, da, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, n, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx of the picked rows
+  // the weight gradients of the three Linears that ran on the picked rows: one grouped launch, before bufH / bufQ are reused
+  const StltWeightGradItem items[3] = {{df, d, t.h, 4 * d, np, G(&stlt_layer_params::lin2_w)},
+                                       {bufH, 4 * d, t.x1, d, np, G(&stlt_layer_params::lin1_w)},
+                                       {da, d, g_ctx, d, np, G(&stlt_layer_params::out_proj_w)}};
+  TRY(weight_grad_all(items, 3, sc, s));
   // the other rows' attention outputs were never read: their dctx is zero
   TRY(launch_scatter_rows(bufC, rows, n, d, bufH, M, s));                                           // bufH (as M x d) = dctx
   TRY(launch_attn_bwd(t.qkv, bufH, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv
   TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
-  TRY(launch_scatter_rows(bufB, rows, n, d, bufC, M, s));                                           // residual path: ds1 on the picked rows only
+  TRY(launch_scatter_rows(ds1, rows, n, d, bufC, M, s));                                            // residual path: ds1 on the picked rows only
   TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, bufC, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
   // the 4d-wide view of bufH lost its zero rows past M to the dctx image only below M*d floats: nothing to restore
   return 0;
@@ -386,12 +407,12 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // can round to the same byte count), so the rows the weight-gradient products read beyond the row count are
   // cleared every step: at most 31 rows per buffer.
   if (do_lower) {
-    for (float* b : {sc.sB, sc.sD}) TRY(zero_rows(b, d, tok, tokp, s));
+    for (float* b : {sc.sB, sc.sD, sc.sE}) TRY(zero_rows(b, d, tok, tokp, s));
     TRY(zero_rows(sc.sQKV, 3 * d, tok, tokp, s));
     TRY(zero_rows(sc.sH, 4 * d, tok, tokp, s));
   }
   if (do_upper) {
-    for (float* b : {sc.tB, sc.tD}) TRY(zero_rows(b, d, BT, btp, s));
+    for (float* b : {sc.tB, sc.tD, sc.tE}) TRY(zero_rows(b, d, BT, btp, s));
     TRY(zero_rows(sc.tQKV, 3 * d, BT, btp, s));
     TRY(zero_rows(sc.tH, 4 * d, BT, btp, s));
   }
@@ -416,7 +437,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   int64_t l_tp = p->n_temporal - 1;
   if (tp_tail) {
     TRY(layer_backward_tail(p->temporal[l_tp], g->temporal ? &g->temporal[l_tp] : nullptr, t.tp[l_tp], d, H, BT, btp, B, T, in->kpm_frames, 1,
-                            ix.last_row, B, sc.hA, sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr,
+                            ix.last_row, B, sc.hA, sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr,
                             (uint32_t)(8 * (p->n_spatial + l_tp + 1)), s, ragged ? &rg_tp : nullptr));
     --l_tp;
   } else {
@@ -424,7 +445,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   }
   for (int64_t l = l_tp; l >= 0; --l)
     TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
-                       sc.tA, sc.tB, sc.tC, sc.tD, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s,
+                       sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s,
                        ragged ? &rg_tp : nullptr));
   }  // upper half: sc.tA now holds the gradient wrt the temporal tower's input
   if (!do_lower) return 0;
@@ -438,7 +459,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   int64_t l_sp = p->n_spatial - 1;
   if (sp_tail) {
     TRY(layer_backward_tail(p->spatial[l_sp], g->spatial ? &g->spatial[l_sp] : nullptr, t.sp[l_sp], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
-                            ix.f_cls_row, BT, sc.tB, sc.sA, sc.sB, sc.sC, sc.sD, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l_sp + 1)), s,
+                            ix.f_cls_row, BT, sc.tB, sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l_sp + 1)), s,
                             ragged ? &rg_sp : nullptr));
     --l_sp;
   } else if (ragged) {
@@ -446,7 +467,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   }
   for (int64_t l = l_sp; l >= 0; --l)
     TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
-                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr));
+                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr));
   // ---- category / box / score embeddings (models.py:29-39)
   TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sB, d, W(g->emb_ln_w), W(g->emb_ln_b),
                     sc.red, s, dr, 0, nullptr, STLT_SITE_EMBED));

@@ -33,6 +33,19 @@ def test_single_process_line():
     assert j["skip_padding"]["value"] > j["value"] and j["logit_max_abs_diff"] <= 1e-4
 
 
+def test_side_legs_ride_on_the_default_line():
+    """train_step / cfg4 / small_batch sub-objects (BASELINE configs 3, 4 and the reference's default batch) next to `value`."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "64", "--side-legs", "--no-cpu-baseline",
+                        "--no-skip-padding"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    for key in ("train_step", "cfg4", "small_batch"):
+        assert "error" not in j[key], j[key]
+        assert j[key]["value"] > 0 and j[key]["per_gpu_batch"] == 64 and 0 < j[key]["roofline"]["frac"] < 1, j[key]
+    assert j["train_step"]["loss"] == j["train_step"]["loss"] and j["train_step"]["grad_norm"] > 0
+    assert j["cfg4"]["roofline_attn_spatial"]["frac"] > 0 and j["small_batch"]["roofline_attn_temporal"]["frac"] > 0
+
+
 def test_two_rank_launch_line():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
