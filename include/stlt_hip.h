@@ -77,6 +77,14 @@ int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* 
  * the launch on its stream.  Pass NULL to withdraw.  The whole-path entry points lend a slice of their workspace. */
 size_t stlt_gemm_scratch_bytes(void);
 int stlt_gemm_set_scratch(void* scratch, size_t bytes);
+/* Weight gradients of several nn.Linear modules in ONE launch (what autograd computes product by product for
+ * `loss.backward()`, src/train.py:125-127): g_w_i (n_out_i, k_in_i) += dy_i[:rows_i]^T · x_i[:rows_i] for every item.
+ * dy_i (rows_i, n_out_i) and x_i (rows_i, k_in_i) row-major; rows_i a multiple of 32 (rows beyond the logical count
+ * must be zero in dy or x); n_out_i, k_in_i multiples of 4; 1..32 items; items with g_w == NULL are skipped.  Needs lent
+ * stream-K scratch (stlt_gemm_set_scratch).  One persistent stream-K launch over the concatenated k-step space of the
+ * items + one fix-up: deterministic (fixed summation order). */
+typedef struct { const float* dy; int64_t n_out; const float* x; int64_t k_in; int64_t rows; float* g_w; } stlt_wgrad_item;
+int stlt_weight_grad_group(const stlt_wgrad_item* items, int n_items, stlt_stream_t stream);
 /* dst[i] = (accumulate ? dst[i] : 0) + sum_s slabs[s*stride + i], i < n */
 int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate,
                       stlt_stream_t stream);

@@ -27,6 +27,10 @@ class OptChunk(C.Structure):
     _fields_ = [("param", C.c_void_p), ("flat_offset", C.c_int64), ("n", C.c_int32), ("weight_decay", C.c_float)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("n_out", C.c_int64), ("x", C.c_void_p), ("k_in", C.c_int64), ("rows", C.c_int64), ("g_w", C.c_void_p)]
+
+
 class LayerParams(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
@@ -83,6 +87,7 @@ SIGNATURES = {
                                   C.c_int, _vp]),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
+    "stlt_weight_grad_group": (C.c_int, [_vp, C.c_int, _vp]),
     "stlt_gemm_scratch_bytes": (C.c_size_t, []),
     "stlt_gemm_set_scratch": (C.c_int, [_vp, C.c_size_t]),
     "stlt_reduce_slabs": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int, _vp]),

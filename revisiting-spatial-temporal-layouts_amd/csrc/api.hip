@@ -148,6 +148,11 @@ int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* 
                      STLT_ACT_NONE, (hipStream_t)stream);
 }
 
+int stlt_weight_grad_group(const stlt_wgrad_item* items, int n_items, stlt_stream_t stream) {
+  static_assert(sizeof(stlt_wgrad_item) == sizeof(StltWeightGradItem), "the C-ABI item is the internal item");
+  return launch_weight_grad_group(reinterpret_cast<const StltWeightGradItem*>(items), n_items, (hipStream_t)stream);
+}
+
 size_t stlt_gemm_scratch_bytes(void) { return STLT_GEMM_SCRATCH_BYTES; }
 
 int stlt_gemm_set_scratch(void* scratch, size_t bytes) {

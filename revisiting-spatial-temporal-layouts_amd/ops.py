@@ -128,6 +128,20 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return c
 
 
+def weight_grad_group(items):
+    """g_w += dy[:rows]ᵀ @ x[:rows] for every (dy, x, g_w[, rows]) of `items`, as one grouped stream-K launch (needs
+    `gemm_scratch()`); rows defaults to dy.shape[0] and must be a multiple of 32."""
+    lib = L.load()
+    arr = (L.WgradItem * len(items))()
+    for i, it in enumerate(items):
+        dy, x, g = it[0], it[1], it[2]
+        rows = it[3] if len(it) > 3 else dy.shape[0]
+        _chk(dy, torch.float32, "dy"); _chk(x, torch.float32, "x"); _chk(g, torch.float32, "g_w")
+        assert tuple(g.shape) == (dy.shape[1], x.shape[1]) and x.shape[0] >= rows and dy.shape[0] >= rows
+        arr[i] = L.WgradItem(_p(dy), dy.shape[1], _p(x), x.shape[1], rows, _p(g))
+    L.check(lib.stlt_weight_grad_group(arr, len(items), _stream()), "stlt_weight_grad_group")
+
+
 def attn_core(qkv: torch.Tensor, kpm: torch.Tensor, causal: bool, num_heads: int):
     """K3 — qkv (S,L,3d) packed [q;k;v], kpm (S,L) bool/uint8 (True = key masked). -> ctx (S,L,d)"""
     lib = L.load()

@@ -432,6 +432,39 @@ def test_dropout_op_mask_scale_and_backward(pkg):
     assert pkg.ops.dropout(x, 0.3, False) is x and pkg.ops.dropout(x, 0.0, True) is x
 
 
+@pytest.mark.parametrize("shapes", [
+    [(64, 96, 64)],                                                   # one small product: a handful of k-steps per workgroup
+    [(2048, 768, 3072), (2048, 3072, 768), (2048, 768, 768), (2048, 2304, 768)],      # an encoder layer's four products (64 clips, temporal)
+    [(64, 768, 3072), (64, 3072, 768), (64, 768, 768)],               # a tail layer: few rows
+    [(416, 132, 260), (32, 300, 36), (1024, 4, 4), (96, 256, 128), (4096, 260, 516)],  # ragged tiles, different contraction lengths
+    [(14336, 768, 768), (14336, 2304, 768)],                          # long contractions: ranges inside one tile
+])
+def test_weight_grad_group_matches_per_product_sums(pkg, shapes):
+    """stlt_weight_grad_group: every g_w += dyᵀ·x of the group in one stream-K launch equals the fp64 products, accumulates
+    into what g_w held, is bitwise reproducible, and leaves a NULL item alone."""
+    gen = torch.Generator().manual_seed(len(shapes))
+    items, refs = [], []
+    for i, (rows, n_out, k_in) in enumerate(shapes):
+        dy = (torch.rand(rows, n_out, generator=gen) * 2 - 1)
+        x = (torch.rand(rows, k_in, generator=gen) * 2 - 1)
+        g0 = torch.rand(n_out, k_in, generator=gen)
+        refs.append(g0.double() + dy.double().t() @ x.double())
+        items.append((dy.to(DEV), x.to(DEV), g0))
+    outs = []
+    for rep in range(2):
+        run = [(dy, x, g0.clone().to(DEV)) for dy, x, g0 in items]
+        with pkg.ops.gemm_scratch(DEV):
+            pkg.ops.weight_grad_group(run)
+        torch.cuda.synchronize()
+        outs.append([g.cpu() for _, _, g in run])
+    for (rows, n_out, k_in), got, again, ref in zip(shapes, outs[0], outs[1], refs):
+        tol = 3e-6 * max(1.0, rows ** 0.5)
+        assert (got.double() - ref).abs().max().item() <= tol * 8, (rows, n_out, k_in, (got.double() - ref).abs().max().item())
+        assert torch.equal(got, again)
+    with pytest.raises(pkg._lib.StltHipError):  # no scratch lent: the grouped launch has nowhere to put its partial tiles
+        pkg.ops.weight_grad_group([(items[0][0], items[0][1], items[0][2].clone().to(DEV))])
+
+
 def test_linear_relu_autograd(pkg):
     """LinearFn with the ReLU in the product's epilogue: forward and all three gradients against torch (fp64)."""
     M, N, K = 300, 96, 64
