@@ -32,8 +32,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X f32-input MFMA dense peak (MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak
 
 
-def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only):
-    """FLOPs the GEMM launches of one forward actually execute (2*M*N*K summed over launches)."""
+def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only, fused_mhsa=False):
+    """FLOPs the GEMM launches of one forward actually execute (2*M*N*K summed over launches).  With the fused MHSA kernel
+    the temporal in-projections (6 d^2 per frame and layer) belong to that kernel, not to the GEMM launches."""
     tok, bt = B * T * N, B * T
     per_row = 24.0 * d * d  # qkv 6d^2 + out 2d^2 + ffn 16d^2
     full_sp = n_sp - 1 if (cls_only and N > 1 and n_sp > 0) else n_sp
@@ -45,6 +46,8 @@ def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only):
     else:
         f += n_tp * bt * per_row
     f += B * (2.0 * d * d + 2.0 * d * classes)
+    if fused_mhsa:
+        f -= n_tp * bt * 6.0 * d * d
     return f
 
 
@@ -376,9 +379,29 @@ def main():
         for name in ("gemm", "attn_temporal", "attn_spatial"):
             k_ms.setdefault(name, (0.0, 0))
         gemm_ms, gemm_n = k_ms["gemm"]
+        fused = bool(pkg._lib.load().stlt_fused_mhsa_active(T, d, c["num_attention_heads"])) and k_ms.get("mhsa_fused", (0.0, 0))[1] > 0
         gflops = gemm_flops_per_step(B, T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"],
-                                     not args.no_cls_only)
+                                     not args.no_cls_only, fused)
         gemm_tflops = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        attn_temporal_note = ""
+        if fused and k_ms["attn_temporal"][1] == 0:
+            # The forward runs the temporal in-projection + attention core as one MFMA-bound kernel (roofline_mhsa_fused below).
+            # The attention core alone is still reported against HBM: the same kernel the two-launch path runs, timed
+            # here on a packed-QKV buffer of this batch (library events, stand-alone launches).
+            try:
+                qkv = torch.rand(B, T, 3 * d, device=dev) * 2 - 1
+                pkg.ops.prof_enable(True)
+                for _ in range(20):
+                    pkg.ops.attn_core(qkv, batch["src_key_padding_mask_frames"], True, c["num_attention_heads"])
+                torch.cuda.synchronize(dev)
+                ms, n = pkg.ops.prof_collect()["attn_temporal"]
+                pkg.ops.prof_enable(False)
+                k_ms["attn_temporal"] = (ms / n * c["num_temporal_layers"], c["num_temporal_layers"]) if n else (0.0, 0)
+                attn_temporal_note = "stand-alone launches on a packed-QKV buffer of this batch (the forward itself runs the fused kernel); "
+                del qkv
+            except Exception as exc:
+                pkg.ops.prof_enable(False)
+                print(f"[bench] stand-alone attention timing failed: {type(exc).__name__}: {exc}", file=sys.stderr)
         at_ms, at_n = k_ms["attn_temporal"]
         at_bytes = B * (16.0 * T * d + T)  # per launch: read packed QKV, write ctx, kpm byte
         at_gbs = at_bytes / (at_ms / max(at_n, 1) * 1e-3) / 1e9 if at_ms > 0 else 0.0
@@ -410,12 +433,20 @@ def main():
                          "traffic": traffic_gemm, "traffic_note": "avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), profiles/round2_traffic_pmc.json", "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
             "roofline_attn_temporal": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=true> for T <= 64 (16-row tiles), attn_core_kernel beyond", "bound": "hbm", "achieved": round(at_gbs, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at_gbs / HBM_PEAK_GBS, 4),
-                                       "traffic": traffic_attn, "traffic_note": "bytes/launch of the temporal kernel (its own symbol: the CAUSAL=true instantiation), L2 memory-side, profiles/round2_traffic_pmc.json; algorithmic " + str(int(at_bytes)), "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
+                                       "traffic": traffic_attn, "traffic_note": attn_temporal_note + "bytes/launch of the temporal kernel (its own symbol: the CAUSAL=true instantiation), L2 memory-side, profiles/round2_traffic_pmc.json; algorithmic " + str(int(at_bytes)), "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
             "roofline_attn_spatial": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=false> for N <= 64 (16-row tiles; frames packed per block for N <= 16), attn_core_kernel beyond", "bound": "hbm", "achieved": round(as_gbs, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(as_gbs / HBM_PEAK_GBS, 4),
                                       "traffic": traffic_attn_sp, "launches_per_step": as_n, "us_per_launch": round(as_ms / max(as_n, 1) * 1e3, 2)},
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
         }
+        if fused:
+            mf_ms, mf_n = k_ms["mhsa_fused"]
+            mf_fl = B * T * 6.0 * d * d + B * c["num_attention_heads"] * 4.0 * T * T * 64  # in-projection + QK^T and PV of every clip and head, per launch
+            mf_tf = mf_fl * mf_n / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+            out["roofline_mhsa_fused"] = {"kernel": "mhsa_fused_kernel (temporal in-projection + causal softmax(QK^T)V in one launch, packed QKV never in HBM)",
+                                          "bound": "mfma", "achieved": round(mf_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": round(mf_tf / MFMA_F32_PEAK_TFLOPS, 4), "launches_per_step": mf_n, "us_per_launch": round(mf_ms / max(mf_n, 1) * 1e3, 2),
+                                          "algorithmic_bytes_per_launch": int(B * T * d * 8 + 4 * (3 * d * d + 3 * d) + B * T)}
         if world == 1 and not args.no_skip_padding:
             try:
                 # Same workload with STLT_FLAG_SKIP_PADDING (opt-in: only the real tokens / frames of the padded batch are

@@ -97,6 +97,16 @@ int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* ds
 int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal,
                        int64_t S, int64_t L, int64_t H, int64_t dh, float* ctx, stlt_stream_t stream);
 
+/* Fused multi-head self-attention of the temporal tower (the north star's "fused MHSA"): the in-projection of
+ * nn.MultiheadAttention (models.py:118-124: in_proj_weight (3d,d) rows [q;k;v], in_proj_bias) and the causal attention core
+ * (mask of utils/model_utils.py:4-7 + src_key_padding_mask_frames, models.py:142-150) in ONE kernel: x (S*L, d) -> ctx (S*L, d),
+ * the packed QKV tensor never goes to memory.  Only L == 32 frames per clip and 64-channel heads (d == 64*H); other shapes
+ * return STLT_EINVAL (callers use stlt_linear_fwd + stlt_attn_core_fwd).  Same result as that pair to fp32 rounding. */
+int stlt_mhsa_fused_fwd(const float* x, const float* in_proj_w, const float* in_proj_b, const uint8_t* kpm, int64_t S, int64_t L,
+                        int64_t H, int64_t d, float* ctx, stlt_stream_t stream);
+/* 1 when stlt_forward / stlt_backbone_forward run their temporal layers through the fused kernel for this shape
+ * (32 frames, 64-channel heads; STLT_FUSED_MHSA=0 in the environment switches back to the two launches). */
+int stlt_fused_mhsa_active(int64_t T, int64_t d, int64_t H);
 /* Cross-attention core (CrossAttentionLayer of CAF/CACNF, models.py:362-382; also self-attention on unpacked buffers):
  * queries q (S*Lq rows, stride ldq floats) attend to keys k / values v (S*Lk rows, stride ldkv).  kpm: (S*Lk) bytes over
  * the KEY tokens (pass zeros for no padding mask).  ctx: (S*Lq, H*dh).  causal requires Lq == Lk. */
@@ -366,7 +376,8 @@ int stlt_eval_average_precision(const float* scores, const float* truths, int64_
 #define STLT_K_EMBED_BWD 10    /* embedding / frames-embedding backward */
 #define STLT_K_OPTIM 11        /* criterion, gradient norm, AdamW */
 #define STLT_K_MISC 12         /* row gathers / scatters, column sums, ragged index, the head's small products */
-#define STLT_K_COUNT 13
+#define STLT_K_MHSA_FUSED 13    /* fused in-projection + causal attention core (stlt_mhsa_fused_fwd) */
+#define STLT_K_COUNT 14
 int stlt_prof_enable(int on);                       /* 1: record events around each launch (serialises nothing, adds events) */
 int stlt_prof_collect(double* ms_out, int64_t* launches_out);
 /* FLOPs (2*M*N*K summed over the launches) of the matrix-core products enqueued on the current device while timing was on,

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstlt_hip.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 SOURCES = ["api.hip", "rowwise.hip", "gemm.hip", "attn.hip", "backward.hip", "train.hip", "collate.hip", "caf.hip", "ragged.hip",
-           "optim.hip", "bwd_api.hip", "evalk.hip", "attn16.hip", "attn_bwd16.hip"]
+           "optim.hip", "bwd_api.hip", "evalk.hip", "attn16.hip", "attn_bwd16.hip", "mhsa.hip"]
 BASE_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
 
@@ -35,7 +35,10 @@ def _headers():
 
 
 def _sources():
-    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    missing = [s for s in SOURCES if not os.path.exists(os.path.join(CSRC, s))]
+    if missing:
+        raise RuntimeError(f"HIP sources missing from {CSRC}: {missing}")
+    return list(SOURCES)
 
 
 def needs_build() -> bool:
@@ -61,11 +64,11 @@ def _compile_one(src_name: str, flags, verbose: bool) -> str:
     obj = os.path.join(OBJ, f"{os.path.splitext(src_name)[0]}.{tag}.o")
     if not os.path.exists(obj):
         os.makedirs(OBJ, exist_ok=True)
-        cmd = [_hipcc(), *BASE_FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, *flags, "-c", src, "-o", obj + ".tmp"]
+        cmd = [_hipcc(), *BASE_FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, *flags, "-c", src, "-o", obj + f".{os.getpid()}.tmp"]
         if verbose:
             print("[stlt build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        os.replace(obj + ".tmp", obj)
+        os.replace(obj + f".{os.getpid()}.tmp", obj)
         stem = os.path.splitext(src_name)[0] + "."
         mine = sorted((f for f in os.listdir(OBJ) if f.startswith(stem) and f.endswith(".o")), key=lambda f: os.path.getmtime(os.path.join(OBJ, f)))
         for f in mine[:-6]:  # keep the cache small: the six newest objects per source
@@ -74,11 +77,11 @@ def _compile_one(src_name: str, flags, verbose: bool) -> str:
 
 
 def _link(objs, out: str, verbose: bool) -> str:
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", out + ".tmp"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", out + f".{os.getpid()}.tmp"]
     if verbose:
         print("[stlt build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(out + ".tmp", out)
+    os.replace(out + f".{os.getpid()}.tmp", out)
     return out
 
 

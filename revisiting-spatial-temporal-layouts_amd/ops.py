@@ -142,6 +142,17 @@ def weight_grad_group(items):
     L.check(lib.stlt_weight_grad_group(arr, len(items), _stream()), "stlt_weight_grad_group")
 
 
+def mhsa_fused(x: torch.Tensor, in_proj_w: torch.Tensor, in_proj_b: torch.Tensor, kpm: torch.Tensor, num_heads: int):
+    """Fused in-projection + causal attention core (temporal tower): x (S,32,d), kpm (S,32) -> ctx (S,32,d)."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"); _chk(in_proj_w, torch.float32, "in_proj_w"); _chk(in_proj_b, torch.float32, "in_proj_b")
+    kpm = _mask_u8(kpm, "kpm")
+    S, Lq, d = x.shape
+    ctx = torch.empty_like(x)
+    L.check(lib.stlt_mhsa_fused_fwd(_p(x), _p(in_proj_w), _p(in_proj_b), _p(kpm), S, Lq, num_heads, d, _p(ctx), _stream()), "stlt_mhsa_fused_fwd")
+    return ctx
+
+
 def attn_core(qkv: torch.Tensor, kpm: torch.Tensor, causal: bool, num_heads: int):
     """K3 — qkv (S,L,3d) packed [q;k;v], kpm (S,L) bool/uint8 (True = key masked). -> ctx (S,L,d)"""
     lib = L.load()

@@ -501,3 +501,32 @@ def test_attn_core_short_sequences_many_items_and_masked_rows(pkg, S, L, causal)
         ref[2] = 0.0
     assert torch.isfinite(got).all()
     assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("S,H", [(1, 12), (4, 12), (5, 12), (64, 12), (257, 12), (1030, 12), (9, 4), (130, 2)])
+def test_mhsa_fused_matches_projection_plus_attention_core(pkg, S, H):
+    """stlt_mhsa_fused_fwd: in-projection + causal attention of 32-frame clips in one kernel, against the
+    fp64 oracle and against the two-launch path (stlt_linear_fwd + stlt_attn_core_fwd); ragged last clip group, a fully
+    padded clip (zeros out), padded frames; other shapes are refused."""
+    d, L = 64 * H, 32
+    x = _rand(S, L, d, seed=S, scale=1.5)
+    w = _rand(3 * d, d, seed=S + 1, scale=2.0 / math.sqrt(d))
+    b = _rand(3 * d, seed=S + 2, scale=0.5)
+    kpm = torch.rand(S, L, generator=torch.Generator().manual_seed(S)) < 0.3
+    kpm[:, 0] = False
+    if S > 3:
+        kpm[2, :] = True  # a fully padded clip
+    xd, wd, bd, kd = x.to(DEV), w.to(DEV), b.to(DEV), kpm.to(DEV)
+    got = pkg.ops.mhsa_fused(xd, wd, bd, kd, H)
+    again = pkg.ops.mhsa_fused(xd, wd, bd, kd, H)
+    qkv = pkg.ops.linear(xd.view(S * L, d), wd, bd).view(S, L, 3 * d)
+    two = pkg.ops.attn_core(qkv, kd, True, H)
+    ref = _attn_ref((x.double().view(S * L, d) @ w.double().t() + b.double()).view(S, L, 3 * d), kpm, True, H)
+    if S > 3:
+        assert got[2].abs().max().item() == 0.0
+        ref[2] = 0.0
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    assert (got.cpu().double() - ref).abs().max().item() <= 3e-5
+    assert (got - two).abs().max().item() <= 2e-5
+    with pytest.raises(pkg._lib.StltHipError):
+        pkg.ops.mhsa_fused(xd[:, :16].contiguous(), wd, bd, kd[:, :16].contiguous(), H)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Row N1 A/B (GPU box only): in-projection + causal attention of a temporal layer as two launches (stlt_linear_fwd +
+stlt_attn_core_fwd: packed QKV through HBM) against the fused kernel (stlt_mhsa_fused_fwd), per clip count.
+
+    python tools/bench_mhsa.py [--clips 64 256 1024] [--iters 50]
+"""
+import argparse, importlib, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("revisiting-spatial-temporal-layouts_amd")
+
+
+def timed(fn, iters):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clips", type=int, nargs="+", default=[64, 256, 1024])
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--only", choices=("both", "two", "fused"), default="both")
+    a = ap.parse_args()
+    dev, H, d, L = "cuda", 12, 768, 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    w = (torch.rand(3 * d, d, device=dev, generator=g) * 2 - 1) / d ** 0.5
+    b = torch.rand(3 * d, device=dev, generator=g) - 0.5
+    for S in a.clips:
+        x = torch.rand(S, L, d, device=dev, generator=g) * 2 - 1
+        kpm = torch.rand(S, L, device=dev, generator=g) < 0.25
+        kpm[:, 0] = False
+        qkv = torch.empty(S * L, 3 * d, device=dev)
+        row = {"clips": S}
+        with pkg.ops.gemm_scratch(dev):
+            if a.only in ("both", "two"):
+                def two():
+                    pkg.ops.linear(x.view(S * L, d), w, b, out=qkv)
+                    return pkg.ops.attn_core(qkv.view(S, L, 3 * d), kpm, True, H)
+                row["two_launch_us"] = round(timed(two, a.iters), 1)
+                row["qkv_only_us"] = round(timed(lambda: pkg.ops.linear(x.view(S * L, d), w, b, out=qkv), a.iters), 1)
+            if a.only in ("both", "fused"):
+                row["fused_us"] = round(timed(lambda: pkg.ops.mhsa_fused(x, w, b, kpm, H), a.iters), 1)
+            if a.only == "both":
+                row["max_abs_diff"] = float((two() - pkg.ops.mhsa_fused(x, w, b, kpm, H)).abs().max())
+        fl = 2.0 * S * L * 3 * d * d
+        for k in ("two_launch_us", "qkv_only_us", "fused_us"):
+            if k in row:
+                row[k.replace("_us", "_tflops")] = round(fl / row[k] / 1e6, 1)
+        print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
