@@ -51,6 +51,58 @@ def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only, fused_mhsa=Fa
     return f
 
 
+def pin_to_gpu_numa_node(local_rank):
+    """Best effort, before anything touches the GPU: bind this rank's host threads to the NUMA node its GPU hangs off (KFD
+    topology -> render node -> sysfs numa_node).  Returns what was done, for the JSON line; never raises."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(l.split() for l in open(os.path.join(base, n, "properties")) if len(l.split()) == 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props.get("drm_render_minor", "-1")))
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            order = [int(x) for x in vis.split(",") if x.strip().isdigit()]
+            gpus = [gpus[i] for i in order if i < len(gpus)]
+        minor = gpus[local_rank]
+        node = int(open(f"/sys/class/drm/renderD{minor}/device/numa_node").read())
+        if node < 0:
+            return {"numa_node": node, "pinned": False}
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "pinned": bool(cpus), "cpus": len(cpus)}
+    except Exception as exc:  # unknown topology layout: run unpinned
+        return {"pinned": False, "why": f"{type(exc).__name__}: {exc}"}
+
+
+def rank_report(torch, dist, world, one_gpu, dev, my_ms, pin):
+    """What makes the first multi-GPU run readable: world size as torch.distributed sees it, the RCCL version, every rank's own
+    ms per step (the line's value uses the slowest) and where each rank's host threads were pinned."""
+    rep = {"world_size": dist.get_world_size() if dist is not None else 1, "backend": dist.get_backend() if dist is not None else None}
+    try:
+        rep["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        rep["rccl_version"] = None
+    if dist is not None:
+        t = torch.tensor([my_ms], device="cpu" if one_gpu else dev, dtype=torch.float64)
+        all_ms = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_ms, t)
+        rep["ms_per_step_by_rank"] = [round(float(x.item()), 4) for x in all_ms]
+        pins = [None] * world
+        dist.all_gather_object(pins, pin)
+        rep["numa_pin_by_rank"] = pins
+    else:
+        rep["ms_per_step_by_rank"] = [round(my_ms, 4)]
+        rep["numa_pin_by_rank"] = [pin]
+    return rep
+
+
 def _build_model(pkg, torch, dev, config, dropout=None, train=False):
     kw = pkg.synth.model_kwargs(config)
     if dropout is not None:
@@ -153,7 +205,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()}, "loss": float(res["loss"]), "grad_norm": float(res["grad_norm"])}
 
 
-def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu):
+def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin=None):
     """--mode train: one optimisation step of the reference's train() loop (src/train.py:119-135) per step."""
     c = pkg.synth.CONFIGS[args.config]
     kw = pkg.synth.model_kwargs(args.config)
@@ -183,11 +235,28 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu):
         res = tr.step(batch)
     fence()
     elapsed = time.perf_counter() - t0
+    ranks = rank_report(torch, dist, world, one_gpu, dev, elapsed / args.steps * 1e3, pin)
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # exposed all-reduce time: the same steps without the gradient exchange (every rank on its own shard, no collective inside)
+    exposed = None
+    if world > 1:
+        solo = pkg.train.Trainer(model, "something", learning_rate=5e-5, weight_decay=1e-3, clip_val=5.0, warmup_steps=2, total_steps=100000, rank=0, world=1)
+        for _ in range(2):
+            solo.step(batch)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            solo.step(batch)
+        torch.cuda.synchronize(dev)
+        solo_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        t = torch.tensor([solo_ms], device="cpu" if one_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed = {"ms_per_step_without_allreduce": round(float(t.item()), 4), "exposed_allreduce_ms": round(ms_per_step - float(t.item()), 4)}
+        fence()
     # per-kernel timing leg: the steps hold collectives when world > 1, so every rank runs them (rank 0 alone reports)
     k_ms, gflops = {}, 0.0
     try:
@@ -225,8 +294,10 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu):
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                      "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4), "flops_per_step": gflops},
         "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
-        "loss": float(res["loss"]), "grad_norm": float(res["grad_norm"]),
+        "loss": float(res["loss"]), "grad_norm": float(res["grad_norm"]), "ranks": ranks,
     }
+    if exposed is not None:
+        out["allreduce"] = exposed
     if world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import stlt_oracle as O
@@ -301,6 +372,7 @@ def main():
     one_gpu = os.environ.get("STLT_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    pin = pin_to_gpu_numa_node(local_rank) if world > 1 and not one_gpu else {"pinned": False, "why": "single process"}
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -317,7 +389,7 @@ def main():
         dist.barrier()
     pkg = importlib.import_module(PKG)
     if args.mode == "train":
-        out = bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu)
+        out = bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin)
         if rank == 0:
             print(json.dumps(out), flush=True)
         if dist is not None:
@@ -355,6 +427,7 @@ def main():
         logits = step()
     fence()
     elapsed = time.perf_counter() - t0
+    ranks = rank_report(torch, dist, world, one_gpu, dev, elapsed / args.steps * 1e3, pin)
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -437,7 +510,7 @@ def main():
             "roofline_attn_spatial": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=false> for N <= 64 (16-row tiles; frames packed per block for N <= 16), attn_core_kernel beyond", "bound": "hbm", "achieved": round(as_gbs, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(as_gbs / HBM_PEAK_GBS, 4),
                                       "traffic": traffic_attn_sp, "launches_per_step": as_n, "us_per_launch": round(as_ms / max(as_n, 1) * 1e3, 2)},
-            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()}, "ranks": ranks,
         }
         if fused:
             mf_ms, mf_n = k_ms["mhsa_fused"]

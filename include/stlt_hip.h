@@ -359,6 +359,10 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
 int stlt_eval_topk(const float* logits, int64_t ld, const int64_t* labels, int64_t B, int64_t K, int64_t* counts,
                    stlt_stream_t stream);
 int64_t stlt_eval_max_clips(void);
+/* EvaluatorActionGenome.process (evaluation.py:76-82) for one batch: pred[i][c] = (double)sigmoid_f32(logits[i][c]) and
+ * truth[i][c] = (double)labels[i][c] written into rows [row0, row0 + B) of the two (total, C) float64 device tables. */
+int stlt_eval_store_sigmoid(const float* logits, int64_t ld, const float* labels, int64_t B, int64_t C, double* pred, double* truth,
+                            int64_t row0, stlt_stream_t stream);
 int stlt_eval_average_precision(const float* scores, const float* truths, int64_t n, int64_t C, double* ap, double* positives,
                                 uint8_t* scratch, stlt_stream_t stream);
 
@@ -378,16 +382,23 @@ int stlt_eval_average_precision(const float* scores, const float* truths, int64_
 #define STLT_K_MISC 12         /* row gathers / scatters, column sums, ragged index, the head's small products */
 #define STLT_K_MHSA_FUSED 13    /* fused in-projection + causal attention core (stlt_mhsa_fused_fwd) */
 #define STLT_K_COUNT 14
+/* The switch is process-wide; the records (and both calls below) belong to the device that is CURRENT when they are made: a
+ * process driving several GPUs collects once per device (with that device current) before it switches timing off, or the
+ * other devices' records stay queued. */
 int stlt_prof_enable(int on);                       /* 1: record events around each launch (serialises nothing, adds events) */
-int stlt_prof_collect(double* ms_out, int64_t* launches_out);
+int stlt_prof_collect(double* ms_out, int64_t* launches_out);  /* sync events, accumulate per-kernel ms / launch counts (STLT_K_COUNT entries each), reset */
 /* FLOPs (2*M*N*K summed over the launches) of the matrix-core products enqueued on the current device while timing was on,
  * since the last call: what the roofline of a step is priced with, whatever the schedule (forward, elided layers, backward). */
-double stlt_prof_take_gemm_flops(void); /* sync events, accumulate per-kernel ms / launch counts, reset */
+double stlt_prof_take_gemm_flops(void);
 
 /* Diagnostics only (tools/attn_stamps.py, tools/gemm_block_times.py): when non-NULL, stlt_attn_core_fwd runs its
- * s_memtime-stamped build (8 uint64 phase stamps per item) and stlt_linear_fwd records per-workgroup start/end
- * times (4 uint64 per workgroup) into dev_buf.  Pass NULL to restore normal operation. */
+ * s_memtime-stamped build (8 uint64 phase stamps per item) and stlt_linear_fwd records per-workgroup data into dev_buf:
+ * 4 uint64 per workgroup (start / end on the 100 MHz clock, XCC id, tile count), then 48 uint64 per workgroup of per-wave
+ * phase stamps (STLT_GEMM_STAMP builds), 1024 spare words and 2 uint64 per workgroup of shader-clock start / end — the
+ * GEMM writes the first and the last region whenever the buffer is set, so it must hold stlt_debug_buffer_bytes().
+ * Pass NULL to restore normal operation. */
 int stlt_debug_set_buffer(void* dev_buf);
+size_t stlt_debug_buffer_bytes(void);  /* (54 * compute units of the current device + 1024) * 8 */
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,7 @@ static bool fused_mhsa();  // defined with the whole-path orchestration below
 extern "C" {
 
 int stlt_debug_set_buffer(void* dev_buf) { g_stlt_debug_buf = (unsigned long long*)dev_buf; return 0; }
+size_t stlt_debug_buffer_bytes(void) { return ((size_t)54 * (size_t)stlt_device_cus() + 1024) * sizeof(unsigned long long); }
 
 int stlt_version(void) { return STLT_VERSION; }
 const char* stlt_last_error(void) { return g_err; }

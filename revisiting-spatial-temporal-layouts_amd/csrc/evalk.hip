@@ -122,7 +122,34 @@ __global__ __launch_bounds__(EV_THREADS) void eval_ap_kernel(const float* __rest
 
 }  // namespace
 
+namespace {
+// one thread per (clip, class): the fp32 sigmoid of the logit (what `x.float().sigmoid()` computes) and the label, widened to
+// the float64 tables the mAP is computed from
+__global__ __launch_bounds__(256) void eval_store_sigmoid_kernel(const float* __restrict__ logits, int64_t ld, const float* __restrict__ labels,
+                                                                 int64_t B, int C, double* __restrict__ pred, double* __restrict__ truth) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i - r * C);
+  const float x = logits[r * ld + c];
+  pred[i] = (double)(1.0f / (1.0f + expf(-x)));
+  truth[i] = (double)labels[i];
+}
+}  // namespace
+
 extern "C" {
+
+int stlt_eval_store_sigmoid(const float* logits, int64_t ld, const float* labels, int64_t B, int64_t C, double* pred, double* truth,
+                            int64_t row0, stlt_stream_t stream) {
+  if (!logits || !labels || !pred || !truth) return stlt_set_error(STLT_EINVAL, "stlt_eval_store_sigmoid: null pointer");
+  if (B < 0 || C <= 0 || C > 0x7fffffff || ld < C || row0 < 0) return stlt_set_error(STLT_EINVAL, "stlt_eval_store_sigmoid: bad shape");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  StltProfScope ps(STLT_K_MISC, s);
+  hipLaunchKernelGGL(eval_store_sigmoid_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, s, logits, ld, labels, B, (int)C,
+                     pred + row0 * C, truth + row0 * C);
+  return stlt_check_launch("eval_store_sigmoid_kernel");
+}
 
 int stlt_eval_topk(const float* logits, int64_t ld, const int64_t* labels, int64_t B, int64_t K, int64_t* counts,
                    stlt_stream_t stream) {

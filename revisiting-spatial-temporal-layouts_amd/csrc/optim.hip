@@ -148,6 +148,11 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict_
   float* dx = dlogits + b * K;
   if (kind == STLT_LOSS_CROSS_ENTROPY) {
     int64_t y = static_cast<const int64_t*>(labels)[b];
+    if (y == -100) {  // nn.CrossEntropyLoss's default ignore_index: the clip contributes nothing (the finish kernel takes the mean over the others)
+      for (int k = threadIdx.x; k < K; k += 256) dx[k] = 0.f;
+      if (threadIdx.x == 0) row_loss[b] = 0.f;
+      return;
+    }
     if (y < 0 || y >= K) {  // torch raises on an out-of-range class index; here the row's loss and gradient become NaN, which
       const float nan = __builtin_nanf("");  // the mean loss, the gradient norm and every later step then show
       for (int k = threadIdx.x; k < K; k += 256) dx[k] = nan;
@@ -176,17 +181,33 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ row_loss, int64_t B, float scale, float* __restrict__ out) {
+// scale = weight / (number of terms the mean runs over, had no clip been ignored).  Cross entropy with ignored clips
+// (label -100): the mean runs over the other clips, so the loss and — the rare case, one block walks the rows — the
+// gradient rows already written with 1/B are rescaled by B / n_valid; no valid clip at all gives NaN, as torch's 0/0 does.
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ row_loss, int64_t B, float scale, float* __restrict__ out,
+                                                          const int64_t* __restrict__ ce_labels, int K, float* __restrict__ dlogits) {
   __shared__ double red[256];
+  __shared__ int ign[256];
   double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < B; i += 256) acc += (double)row_loss[i];
+  int n_ign = 0;
+  for (int64_t i = threadIdx.x; i < B; i += 256) {
+    acc += (double)row_loss[i];
+    if (ce_labels && ce_labels[i] == -100) ++n_ign;
+  }
   red[threadIdx.x] = acc;
+  ign[threadIdx.x] = n_ign;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if (threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; ign[threadIdx.x] += ign[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+  const int ignored = ign[0];
+  const double fix = ignored == 0 ? 1.0 : (double)B / (double)(B - ignored);  // inf when every clip is ignored: 0 * inf = NaN below
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale * fix);
+  if (ignored > 0 && ignored < B) {
+    const float f = (float)fix;
+    for (int64_t i = threadIdx.x; i < B * K; i += 256) dlogits[i] *= f;
+  }
 }
 
 }  // namespace
@@ -202,6 +223,7 @@ extern "C" int stlt_loss_fwd_bwd(const float* logits, const void* labels, int ki
   const float mean = kind == STLT_LOSS_CROSS_ENTROPY ? 1.0f / (float)B : 1.0f / ((float)B * (float)K);
   hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, labels, kind, (int)K, weight * mean, scratch, dlogits);
   if (int e = stlt_check_launch("loss_rows_kernel")) return e;
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, scratch, B, weight * mean, loss_out);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, scratch, B, weight * mean, loss_out,
+                     kind == STLT_LOSS_CROSS_ENTROPY ? static_cast<const int64_t*>(labels) : nullptr, (int)K, dlogits);
   return stlt_check_launch("loss_finish_kernel");
 }

@@ -15,7 +15,19 @@ from . import dist as D
 
 
 def topk_counts(logits: torch.Tensor, labels: torch.Tensor, ks=(1, 5)) -> torch.Tensor:
-    """Number of rows whose label is among the k largest logits, for each k. -> int64 tensor (len(ks),)"""
+    """Number of rows whose label is among the k largest logits, for each k. -> int64 tensor (len(ks),)
+    Device logits with the reference's ks = (1, 5) go through the library's counting kernel (include/stlt_hip.h:
+    stlt_eval_topk, no torch kernels); anything else — CPU tensors in the not-gpu tests, other ks — takes the torch form."""
+    if logits.is_cuda and tuple(ks) == (1, 5) and logits.dim() == 2 and logits.shape[0] > 0:
+        from . import _lib as L
+        lib = L.load()
+        x = logits if (logits.dtype == torch.float32 and logits.stride(-1) == 1) else logits.float().contiguous()
+        y = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        counts = torch.zeros(2, dtype=torch.int64, device=logits.device)
+        with torch.cuda.device(logits.device):
+            L.check(lib.stlt_eval_topk(x.data_ptr(), x.stride(0), y.data_ptr(), x.shape[0], x.shape[1], counts.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "stlt_eval_topk")
+        return counts
     kmax = min(max(ks), logits.shape[1])
     top = logits.topk(kmax, dim=1).indices  # (n, kmax)
     hit = top == labels.view(-1, 1)

@@ -197,7 +197,9 @@ class CrossAttentionFusionBackbone(nn.Module):
         if torch.is_grad_enabled() and any(q.requires_grad for mod in [self] + heads for q in mod.parameters()):
             return self.run_train(batch, fusion_head, layout_head, appearance_head)
         if self.training and self.config.hidden_dropout_prob > 0:
-            raise L.StltHipError("train-mode dropout runs only in the autograd (training) path: call model.train(False) for inference, or enable grad")
+            # train mode without grad: nn.Dropout is still live in the reference (models.py:334,351,376): the training
+            # composition runs (its Functions just execute their forward kernels under no_grad)
+            return self.run_train(batch, fusion_head, layout_head, appearance_head)
         lib = L.load()
         inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=True)
         feats = ops._chk(batch["appearance_features"].contiguous(), torch.float32, "appearance_features")

@@ -194,6 +194,7 @@ class StltBackbone(nn.Module):
         state["_cache"] = None
         state["_ws"] = _Workspace()
         state.pop("_train_bufs", None)
+        state.pop("_flat_grad_buf", None)
         return state
 
     @classmethod
@@ -272,10 +273,10 @@ class StltBackbone(nn.Module):
                 | (L.FLAG_LAST_ROW_ONLY_TEMPORAL if self.last_row_only_temporal else 0)
                 | (L.FLAG_SKIP_PADDING if self.skip_padding else 0))
 
-    def _check_mode(self, grad_path: bool = False):
-        if self.training and self.config.hidden_dropout_prob > 0 and not grad_path:
-            raise L.StltHipError("train-mode dropout runs only in the autograd (training) path: call model.train(False) "
-                                 "for inference, or enable grad")
+    def _dropout_live(self) -> bool:
+        """nn.Dropout is active whenever the module is in training mode, grad or no grad (models.py:27,37,93,109): such
+        forwards take the training kernels (counter-based masks), not the inference schedule."""
+        return self.training and self.config.hidden_dropout_prob > 0
 
     # ---- differentiable forward, composed from the op-level autograd Functions of ops.py ----------------------------
     def _encoder_layer_train(self, l: _EncoderLayerParams, x: torch.Tensor, kpm, causal: bool) -> torch.Tensor:
@@ -320,9 +321,8 @@ class StltBackbone(nn.Module):
 
     def forward_batch_major(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """HIP forward, batch-major (B,T,d) result (the layout the kernels compute in)."""
-        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
-            return self.forward_train(batch)
-        self._check_mode()
+        if (torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())) or self._dropout_live():
+            return self.forward_train(batch)  # under no_grad the op-level Functions just run their forward kernels
         lib = L.load()
         inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=False)
         device = batch["categories"].device
@@ -376,8 +376,9 @@ class Stlt(nn.Module):
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         bb = self.backbone
         grad_path = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
-        bb._check_mode(grad_path)
-        if grad_path:
+        if grad_path or bb._dropout_live():
+            # train mode without grad (a validation pass that forgot model.train(False), MC-dropout): the reference still
+            # applies its dropouts, so the training forward runs here too — same kernels, the tape is just not kept
             params = tuple(self.parameters())
             logits = _StltTrainFn.apply(self, batch, *params)
             return {k: v for k, v in zip(self.logit_names, (logits,))}
@@ -448,7 +449,17 @@ class _StltTrainFn(torch.autograd.Function):
         for q in want:
             layout.append((q, off, q.numel()))
             off += (q.numel() + 3) // 4 * 4
-        flat = torch.zeros(off, device=device, dtype=torch.float32)
+        # The fused trainer consumes the buffer before the next backward, so it is kept per backbone and cleared, not
+        # re-allocated (344 MB at d = 768).  Otherwise the views below become the parameters' .grad tensors and outlive
+        # this call: a fresh buffer every time.
+        reuse = bool(getattr(model, "_flat_grads_only", False))
+        flat = bb.__dict__.get("_flat_grad_buf") if reuse else None
+        if flat is not None and flat.device == device and flat.numel() == off:
+            flat.zero_()
+        else:
+            flat = torch.zeros(off, device=device, dtype=torch.float32)
+            if reuse:
+                bb.__dict__["_flat_grad_buf"] = flat
         views = {id(q): flat[o: o + n].view_as(q) for q, o, n in layout}
         g, gsp, gtp = bb._build_struct(model.prediction_head, lambda t: views[id(t)].data_ptr() if id(t) in views else None)
         tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, p.n_spatial, p.n_temporal)), device)

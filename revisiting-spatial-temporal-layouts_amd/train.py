@@ -6,10 +6,13 @@ weight decay for 1-D parameters and names ending in ".bias", weight decay 1e-3 f
 `Criterion` = CrossEntropyLoss ("something") or BCEWithLogitsLoss ("action_genome") averaged over the logit heads
 (:64-76), gradient clipping at 5.0, and per step: zero_grad -> forward -> loss -> backward -> clip -> step -> sched.
 
-Forward and backward run in the HIP library (modelling/models.py `_StltTrainFn`).  Loss, clipping and AdamW are stock
-torch ops on the GPU, exactly as in the reference harness.  Data parallel: every rank runs the step on its shard of the
-global batch and the gradients are averaged with ONE all-reduce (RCCL over xGMI; 344 MB for d=768) between backward
-and clipping; the loss is a batch mean, so equal shards reproduce the single-process global batch exactly.
+Forward and backward run in the HIP library (modelling/models.py `_StltTrainFn`), and so do — on a GPU, the default — the
+criterion with its gradient (`fused_criterion`: stlt_loss_fwd_bwd), the gradient norm + clipping factor and AdamW
+(`FusedAdamW`: stlt_grad_norm, stlt_adamw_step, straight from the flat gradient buffer the reverse sweep fills);
+`Trainer(fused_optimizer=False)` keeps the stock torch ops of the reference harness.  Data parallel: every rank runs the
+step on its shard of the global batch and the flat gradient buffer is averaged in place over RCCL (344 MB for d=768), in
+two slices of which the first travels while the spatial half of the reverse sweep runs; the loss is a batch mean, so equal
+shards reproduce the single-process global batch exactly.
 """
 from __future__ import annotations
 
@@ -146,14 +149,18 @@ class FusedAdamW(torch.optim.Optimizer):
         for g, table, n_chunks in self._tables:
             if n_chunks == 0:
                 continue
-            step = None
-            for p in g["params"]:
-                st = self.state.get(p)
-                if st is not None and "exp_avg" in st:
-                    st["step"] = st["step"] + 1
-                    step = int(st["step"].item())
-            if step is None:
+            # torch keeps one `step` tensor per parameter; the parameters of a group always step together, so they share
+            # one tensor object here (state dicts still list it per parameter) and the host does one increment per group
+            live = [self.state[p] for p in g["params"] if "exp_avg" in self.state.get(p, {})]
+            if not live:
                 continue
+            shared = live[0]["step"]
+            if any(st["step"] is not shared for st in live):  # first step / after load_state_dict: adopt the furthest count
+                shared = torch.tensor(float(max(float(st["step"]) for st in live)))
+                for st in live:
+                    st["step"] = shared
+            shared += 1
+            step = int(shared.item())
             L.check(lib.stlt_adamw_step(table.data_ptr(), n_chunks, flat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
                                         out.data_ptr() if max_norm > 0 else None, float(g["lr"]), float(g["betas"][0]),
                                         float(g["betas"][1]), float(g["eps"]), step, stream), "stlt_adamw_step")

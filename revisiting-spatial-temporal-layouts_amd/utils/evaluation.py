@@ -117,6 +117,14 @@ def average_precisions(scores: torch.Tensor, truths: torch.Tensor) -> torch.Tens
     return torch.where(n_pos > 0, ap, torch.full_like(ap, float("nan")))
 
 
+def _hip_ap_can_take(scores: torch.Tensor) -> bool:
+    from .. import _lib as L
+    n = scores.shape[0]
+    if n == 0 or n > int(L.load().stlt_eval_max_clips()):
+        return False
+    return scores.dtype == torch.float32 or bool((scores.to(torch.float32).to(scores.dtype) == scores).all())
+
+
 def _average_precisions_hip(scores: torch.Tensor, truths: torch.Tensor) -> torch.Tensor:
     """`stlt_eval_average_precision` on device tables (the empty-clip rule is applied inside)."""
     from .. import _lib as L
@@ -137,10 +145,13 @@ def _average_precisions_hip(scores: torch.Tensor, truths: torch.Tensor) -> torch
 
 def charades_map(scores: torch.Tensor, truths: torch.Tensor):
     """(mAP, weighted AP per class, AP per class) as the reference's `charades_map` (evaluation.py:127-132)."""
-    if scores.is_cuda:
+    if scores.is_cuda and _hip_ap_can_take(scores):
         aps, pos = _average_precisions_hip(scores, truths)
         w_ap = aps * pos / pos.sum()  # gt.sum(axis=0) = positives per class (multi-hot truths)
         return aps.mean(), w_ap, aps
+    # Tables the sorting kernel does not take — more clips than one workgroup sorts in LDS, an empty table, or float64 scores
+    # that fp32 cannot hold exactly (narrowing them could reorder near-ties) — keep the batched torch form of the same
+    # arithmetic on whatever device the table lives on.
     scores = scores.to(torch.float64).clone()
     truths = truths.to(torch.float64)
     empty = truths.sum(dim=1) == 0
@@ -171,8 +182,20 @@ class EvaluatorActionGenome:
             self.predictions = torch.zeros(self.total_instances, self.total_classes, dtype=torch.float64, device=x.device)
             self.ground_truths = torch.zeros_like(self.predictions)
         size = x.shape[0]
-        self.predictions[self.index : self.index + size] = x.float().sigmoid()  # fp32 sigmoid, widened: evaluation.py:79-81
-        self.ground_truths[self.index : self.index + size] = labels.to(x.device)
+        if self.index + size > self.total_instances:
+            raise IndexError(f"EvaluatorActionGenome: {self.index + size} clips processed, tables hold {self.total_instances}")
+        if x.is_cuda:  # one small kernel: fp32 sigmoid + both table writes (include/stlt_hip.h: stlt_eval_store_sigmoid)
+            from .. import _lib as L
+            lib = L.load()
+            xs = x if (x.dtype == torch.float32 and x.dim() == 2 and x.stride(-1) == 1) else x.float().contiguous()
+            ys = labels.to(device=x.device, dtype=torch.float32).contiguous()
+            with torch.cuda.device(x.device):
+                L.check(lib.stlt_eval_store_sigmoid(xs.data_ptr(), xs.stride(0), ys.data_ptr(), size, self.total_classes, self.predictions.data_ptr(),
+                                                    self.ground_truths.data_ptr(), self.index, torch.cuda.current_stream().cuda_stream),
+                        "stlt_eval_store_sigmoid")
+        else:
+            self.predictions[self.index : self.index + size] = x.float().sigmoid()  # fp32 sigmoid, widened: evaluation.py:79-81
+            self.ground_truths[self.index : self.index + size] = labels.to(x.device)
         self.index += size
 
     def _tables(self):

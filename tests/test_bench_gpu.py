@@ -58,6 +58,7 @@ def test_two_rank_launch_line():
     j = _last_json(r.stdout)
     assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["config"]["global_batch"] == 128 and j["value"] > 0
     assert "cpu_baseline" not in j  # rank 0 at N = 1 only
+    assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_by_rank"]) == 2 and len(j["ranks"]["numa_pin_by_rank"]) == 2
 
 
 def test_train_mode_single_process_line():
@@ -83,3 +84,5 @@ def test_train_mode_two_rank_launch_line():
     j = _last_json(r.stdout)
     assert REQUIRED <= set(j) and j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["value"] > 0
     assert "all-reduce" in j["config"]["parallelism"] and "cpu_baseline" not in j
+    assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_by_rank"]) == 2
+    assert j["allreduce"]["ms_per_step_without_allreduce"] > 0  # the same steps without the gradient exchange, for the exposed time

@@ -132,3 +132,39 @@ def test_average_precision_kernel_vs_oracle_random():
         np.testing.assert_allclose(ap.cpu().numpy(), ap_ref, rtol=0, atol=1e-12, equal_nan=True)
         np.testing.assert_allclose(w.cpu().numpy(), w_ref, rtol=0, atol=1e-12, equal_nan=True)
         assert (np.isnan(m_ref) and np.isnan(m.item())) or abs(m.item() - m_ref) < 1e-12
+
+
+@pytest.mark.gpu
+def test_charades_map_tables_the_sort_kernel_does_not_take():
+    """More clips than one workgroup sorts in LDS, an empty table, and float64 scores fp32 cannot hold: the device path falls
+    back to the batched torch form instead of raising (and agrees with the oracle)."""
+    from importlib import import_module
+    lib = import_module("revisiting-spatial-temporal-layouts_amd")._lib.load()
+    n = int(lib.stlt_eval_max_clips()) + 7
+    rng = np.random.RandomState(5)
+    sig = torch.from_numpy(rng.randn(n, 3).astype(np.float32)).sigmoid().numpy().astype(np.float64)
+    gt = (rng.rand(n, 3) < 0.3).astype(np.float64)
+    m_ref, _, ap_ref = O.charades_map(sig, gt)
+    m, _, ap = E.charades_map(torch.from_numpy(sig).cuda(), torch.from_numpy(gt).cuda())
+    np.testing.assert_allclose(ap.cpu().numpy(), ap_ref, rtol=0, atol=1e-12)
+    assert abs(m.item() - m_ref) < 1e-12
+    m0, _, ap0 = E.charades_map(torch.zeros(0, 4, dtype=torch.float64).cuda(), torch.zeros(0, 4, dtype=torch.float64).cuda())
+    assert np.isnan(m0.item()) and ap0.shape == (4,)
+    fine = np.array([[0.5 + 1e-12], [0.5], [0.5 - 1e-12], [0.2]])  # distinct only in float64
+    truth = np.array([[0.0], [1.0], [0.0], [1.0]])
+    m64, _, _ = E.charades_map(torch.from_numpy(fine).cuda(), torch.from_numpy(truth).cuda())
+    assert abs(m64.item() - O.charades_map(fine, truth)[0]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_store_sigmoid_kernel_fills_the_tables_like_torch():
+    g = torch.Generator().manual_seed(2)
+    ev = E.EvaluatorActionGenome(50, 157, ("stlt",))
+    lg = torch.randn(50, 160, generator=g) * 6
+    lab = (torch.rand(50, 157, generator=g) < 0.2).float()
+    xd = lg.cuda()[:, :157]  # strided rows
+    ev.process({"stlt": xd[:20]}, lab[:20])
+    ev.process({"stlt": xd[20:]}, lab[20:].cuda().double())
+    assert torch.equal(ev.predictions.cpu(), lg[:, :157].sigmoid().double()) and torch.equal(ev.ground_truths.cpu(), lab.double())
+    with pytest.raises(IndexError):
+        ev.process({"stlt": xd[:1]}, lab[:1])

@@ -167,13 +167,22 @@ def test_state_dict_roundtrip_and_train_flag(pkg):
         assert torch.equal(sd[k], sd2[k])
     # backbone-only dict (train.py:152 / models.py:130-134): 168 keys
     assert len(m.backbone.state_dict()) == 168
-    # p=0 -> train mode runs the same math; p>0 in train mode WITHOUT grad (no training path) is refused, not silently wrong
+    # p=0 -> train mode runs the same math; p>0 in train mode WITHOUT grad applies the dropouts like the reference's
+    # nn.Dropout modules do (models.py:27,37,93,109): the masked oracle with the same seed gives the same logits
     m.train(True)
     with torch.no_grad():
         a = m(_to(batch))["stlt"]
-    m.backbone.config.hidden_dropout_prob = 0.1
-    with pytest.raises(pkg.StltHipError), torch.no_grad():
-        m(_to(batch))
+    m.backbone.config.hidden_dropout_prob = m.config.hidden_dropout_prob = 0.1
+    m._dropout_seed_override = 4321
+    with torch.no_grad():
+        dropped = m(_to(batch))["stlt"].cpu()
+        bb_dropped = m.backbone(_to(batch))  # the backbone alone takes the op-level training forward
+    assert bb_dropped.shape[1] == batch["categories"].shape[0] and torch.isfinite(bb_dropped).all()
+    H = pkg.synth.CONFIGS[name]["num_attention_heads"]
+    ref = O.stlt_forward(sd, batch, H, drop=O.Dropout(0.1, 4321))["stlt"]
+    assert (dropped - ref).abs().max().item() <= 1e-4 and (dropped - a.cpu()).abs().max().item() > 1e-3
+    m._dropout_seed_override = None
+    m.backbone.config.hidden_dropout_prob = m.config.hidden_dropout_prob = 0.0
     m.train(False)
     with torch.no_grad():
         assert torch.equal(a, m(_to(batch))["stlt"])

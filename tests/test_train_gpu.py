@@ -470,3 +470,20 @@ def test_fused_criterion_flags_an_out_of_range_label(pkg):
     loss, dl = pkg.train.fused_criterion(x, y.to(DEV), "something")
     assert torch.isnan(loss)
     assert torch.isnan(dl[2]).all() and torch.isnan(dl[4]).all() and torch.isfinite(dl[[0, 1, 3]]).all()
+
+
+def test_fused_criterion_ignores_label_minus_100_like_torch(pkg):
+    """nn.CrossEntropyLoss (train_inference_utils.py:67-76) keeps torch's default ignore_index = -100: such clips add nothing
+    and the mean runs over the others; a batch of only ignored clips gives NaN (torch's 0/0)."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 174, generator=g)
+    y = torch.randint(0, 174, (37,), generator=g)
+    y[[3, 11, 36]] = -100
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, y)
+    ref.backward()
+    loss, dl = pkg.train.fused_criterion(x.cuda(), y.cuda(), "something")
+    assert abs(loss.item() - ref.item()) <= 1e-5 and (dl.cpu() - xr.grad).abs().max().item() <= 1e-7
+    assert (dl.cpu()[[3, 11, 36]] == 0).all()
+    loss2, dl2 = pkg.train.fused_criterion(x.cuda(), torch.full((37,), -100).cuda(), "something")
+    assert loss2.item() != loss2.item() and (dl2 == 0).all()
