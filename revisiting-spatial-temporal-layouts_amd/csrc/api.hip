@@ -246,12 +246,14 @@ size_t stlt_workspace_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t 
 
 #define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 
-// STLT_FUSE_RESIDUAL=1: residual add in the out-proj / FFN2 epilogue instead of in the LayerNorm pass (bit-identical
-// logits).  Off by default: measured at cfg2 / 1024 clips the LayerNorm passes drop from 3.06 to 2.00 ms per step and the
-// GEMMs rise from 101.5 to 102.5 ms — the residual tile is read in the epilogue, the one place of the GEMM where memory
-// latency is not hidden (one workgroup per CU) — 107.40 against 107.43 ms per step over five A/B pairs.
+// The residual adds of a post-norm layer ride in the out-proj / FFN2 epilogues and the LayerNorm passes read one tensor
+// instead of two (bit-identical logits: the accumulators start from the bias, the residual is added last).  Round 2 measured
+// it a wash (the residual tile was read inside the exposed epilogue: LayerNorm 3.06 -> 2.00 ms, GEMMs +1.0 ms); with the
+// first half of a tile's residual pieces requested during the tile's last k-step (gemm.hip: STLT_GEMM_RES_PREFETCH) the GEMMs
+// pay 0.4 ms and the forward gains 0.5 ms at cfg2 / 1024 clips (profiles/round3_fwd_residual_ab.txt).  STLT_FUSE_RESIDUAL=0
+// restores the separate pass (A/B runs).
 static bool fuse_residual() {
-  static const bool on = [] { const char* e = getenv("STLT_FUSE_RESIDUAL"); return e ? atoi(e) != 0 : false; }();
+  static const bool on = [] { const char* e = getenv("STLT_FUSE_RESIDUAL"); return e ? atoi(e) != 0 : true; }();
   return on;
 }
 

@@ -66,6 +66,12 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 #ifndef STLT_GEMM_ABLATE
 #define STLT_GEMM_ABLATE 0  // timing-only builds (wrong results): bit 0 no steady-state DMA, bit 3 loaders do not wait for their DMA, bit 4 no epilogue stores, bit 5 loaders re-read k-step 0 of their first tile (cache-hot source)
 #endif
+#ifndef STLT_GEMM_RES_PREFETCH
+#define STLT_GEMM_RES_PREFETCH 1  // the add-source pieces of a tile's first row half are requested at the start of the tile's last k-step (forward layout, loader-wave build, whole tiles): cfg2 / 1024 clips with the residual adds in the epilogues 107.2 -> 106.7 ms (profiles/round3_fwd_residual_ab.txt)
+#endif
+#ifndef STLT_GEMM_STORE_NT
+#define STLT_GEMM_STORE_NT 0  // 1: non-temporal epilogue stores — measured slower (cfg2 / 1024 clips: 107.3 -> 108.1 ms per forward, round 3)
+#endif
 #ifndef STLT_GEMM_GROUPED
 #define STLT_GEMM_GROUPED 1  // 1: every XCD walks a contiguous stretch of a band-major tile order (bands of 4 M-panels, N outer inside a band); 0: round-1 order
 #endif
@@ -510,6 +516,9 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   int c_it = 0, c_kt = kt_begin(0);  // MFMA stream position
   if constexpr (GROUP) nk = grp.p[g_p0].nk;  // k-steps of the MFMA stream's current tile
   int stage = 0;
+  constexpr bool RES_PF = STLT_GEMM_RES_PREFETCH && ADD && WS && !SK && !TA && !TB;
+  f32x4 rpf[RES_PF ? 8 : 1];  // add-source pieces of row half a = 0 of the current tile, in flight during its last k-step
+  bool rpf_ok = false;
   unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0;
 #define GSTAMP(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); t_acc[k] += t_now - t_prev; t_prev = t_now; __builtin_amdgcn_sched_barrier(0); } } while (0)
   if (STAMP) { t_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
@@ -520,6 +529,18 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
     const bool prefetch = (STLT_GEMM_ABLATE & 1) ? false : step + 2 < total_steps;  // step+2's operands go to the stage retired by the previous barrier
     const bool bias_step = c_kt == nk - 1 && c_it + 1 < my_tiles;
     if (!WS && bias_step) dma_bias(c_it + 1);  // older than this step's operand DMA: covered by the counted wait below
+    if constexpr (RES_PF) {
+      if (c_kt == nk - 1) {  // the epilogue is 64 MFMAs away: its first eight residual pieces travel under them
+        int m0, n0, split;
+        tile_origin(c_it, m0, n0, split);
+        rpf_ok = (m0 + BM <= M) && (n0 + BN <= N) && (ldr & 3) == 0 && ((uintptr_t)R & 15) == 0;
+        if (rpf_ok) {
+          const float* rrow = R + (int64_t)(m0 + wm * 64 + lr) * ldr + n0;
+#pragma unroll
+          for (int h = 0; h < 8; ++h) rpf[h] = *reinterpret_cast<const f32x4*>(rrow + wn * 64 + (h >> 2) * 32 + 8 * (h & 3) + 4 * lh);
+        }
+      }
+    }
     // chunks 0..2: read the next chunk of this stage, 16 MFMAs on the current one, a third of step+2's DMA
     fb = read_frags(stage, 1);
     mfma_chunk(fa);
@@ -597,8 +618,13 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
 #pragma unroll
           for (int g = 0; g < 8; ++g) {
             if (ADD && g % RB == 0) {
+              if (RES_PF && a == 0 && rpf_ok) {
 #pragma unroll
-              for (int h = 0; h < RB; ++h) rv[ADD ? h : 0] = *reinterpret_cast<const f32x4*>(rrow + t_col4(g + h));
+                for (int h = 0; h < RB; ++h) rv[ADD ? h : 0] = rpf[RES_PF ? h : 0];
+              } else {
+#pragma unroll
+                for (int h = 0; h < RB; ++h) rv[ADD ? h : 0] = *reinterpret_cast<const f32x4*>(rrow + t_col4(g + h));
+              }
             }
             f32x4 val = group(a, g);
             if (ADD) val += rv[ADD ? g % RB : 0];
@@ -607,8 +633,9 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
               if (ACT == STLT_ACT_GELU) val[j] = gelu_epilogue(val[j]);
               if (ACT == STLT_ACT_RELU) val[j] = fmaxf(val[j], 0.f);
             }
-            if (STLT_GEMM_ABLATE & 16) asm volatile("" :: "v"(val)); else
-            *reinterpret_cast<f32x4*>(yrow + t_col4(g)) = val;
+            if (STLT_GEMM_ABLATE & 16) asm volatile("" :: "v"(val));
+            else if (STLT_GEMM_STORE_NT) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(yrow + t_col4(g)));
+            else *reinterpret_cast<f32x4*>(yrow + t_col4(g)) = val;
           }
         }
       } else {

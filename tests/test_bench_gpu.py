@@ -43,7 +43,9 @@ def test_side_legs_ride_on_the_default_line():
         assert "error" not in j[key], j[key]
         assert j[key]["value"] > 0 and j[key]["per_gpu_batch"] == 64 and 0 < j[key]["roofline"]["frac"] < 1, j[key]
     assert j["train_step"]["loss"] == j["train_step"]["loss"] and j["train_step"]["grad_norm"] > 0
-    assert j["cfg4"]["roofline_attn_spatial"]["frac"] > 0 and j["small_batch"]["roofline_attn_temporal"]["frac"] > 0
+    assert j["cfg4"]["roofline_attn_spatial"]["frac"] > 0 and j["cfg4"]["roofline_attn_temporal"]["frac"] > 0  # T = 64: the two-launch path
+    assert j["small_batch"]["roofline_mhsa_fused"]["frac"] > 0 and j["small_batch"]["roofline_attn_spatial"]["frac"] > 0  # T = 32: fused kernel
+    assert j["roofline_mhsa_fused"]["frac"] > 0 and j["roofline_attn_temporal"]["frac"] > 0  # the core alone is still reported against HBM
 
 
 def test_two_rank_launch_line():
