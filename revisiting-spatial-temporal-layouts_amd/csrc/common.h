@@ -101,9 +101,15 @@ int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias
                   int64_t N, int64_t K, int act, hipStream_t s);
 int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y,
                       int64_t ldy, int64_t M, int64_t N, int64_t K, hipStream_t s);
+// Epilogue of the fused GELU backward (act == STLT_ACT_GELU_BWD, internal): C = drop(A·B) ∘ gelu'(U) with U passed as the
+// add-source (r / ldr), the dropout of the FFN hidden (site, drop_rows as launch_gelu_bwd_colsum), and the column sums of C
+// (the producing Linear's bias gradient) left as partial rows: cs_part[(tile row * 16 + slot) * N + n], 16 slots per 256-row
+// tile row, every slot written — launch_reduce_slabs(cs_part, N, ceil(M/256)*16, g, N, 1) finishes them.
+constexpr int STLT_ACT_GELU_BWD = 3;
+struct StltGemmEpi { StltDrop dr; uint32_t site; const int* drop_rows; float* cs_part; };
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
-                int64_t K, int n_split, int act, hipStream_t s);
+                int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi = nullptr);
 // Scratch for stream-K partial tiles (2 images of 256x128 floats per workgroup).  While a StltGemmScratch is alive
 // on the calling thread, launch_gemm may cut under-filled launches into equal k-step ranges; the buffer is only
 // touched by kernels enqueued on the launch stream.  Whole-path entry points lend a slice of their workspace.

@@ -109,6 +109,46 @@ __device__ __forceinline__ float gelu_epilogue(float x) {
 #endif
 }
 
+// d/dx gelu(x) = Phi(x) + x phi(x), fixed cost like gelu_epilogue (same erf fit, two v_exp_f32)
+__device__ __forceinline__ float gelu_grad_epilogue(float x) {
+  const float z = x * 0.70710678118654752440f;
+  const float t = fminf(fabsf(z), 3.95f);
+  float q = 1.1830035617776957e-07f;
+  q = fmaf(q, t, -3.0875787615514128e-06f);
+  q = fmaf(q, t, 3.5860794014297426e-05f);
+  q = fmaf(q, t, -0.00024206875241361558f);
+  q = fmaf(q, t, 0.0010191010078415275f);
+  q = fmaf(q, t, -0.002435620641335845f);
+  q = fmaf(q, t, 0.00011764218652388081f);
+  q = fmaf(q, t, 0.027792135253548622f);
+  q = fmaf(q, t, -0.14836618304252625f);
+  q = fmaf(q, t, -0.9184255599975586f);
+  q = fmaf(q, t, -1.6279090642929077f);
+  q = fmaf(q, t, 2.831300349726007e-08f);
+  const float e = copysignf(1.0f - __builtin_amdgcn_exp2f(q), z);
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  return fmaf(x, pdf, 0.5f * (1.0f + e));
+}
+// dropout mask of the FFN hidden + gelu'(u) on four consecutive columns of row `drow`
+__device__ __forceinline__ f32x4 gelu_bwd4(f32x4 g, f32x4 u, const StltGemmEpi& epi, uint64_t key, uint64_t idx0) {
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = g[j];
+    if (epi.dr.thr) v = stlt_keep_k(epi.dr.thr, key, idx0 + j) ? v * epi.dr.scale : 0.f;
+    o[j] = v * gelu_grad_epilogue(u[j]);
+  }
+  return o;
+}
+__device__ __forceinline__ float half_wave_sum(float x) {  // over the 32 lanes that share lane >> 5
+  x += __shfl_xor(x, 1, 64);
+  x += __shfl_xor(x, 2, 64);
+  x += __shfl_xor(x, 4, 64);
+  x += __shfl_xor(x, 8, 64);
+  x += __shfl_xor(x, 16, 64);
+  return x;
+}
+
 // Stream-K launches on a full grid of 8 x Gx workgroups with at least one round of whole tiles to spare run as a hybrid:
 // `dp_rounds` rounds of whole tiles in the XCD-grouped order (no partial tiles, the L2-friendly order), then only the
 // remaining tiles — positions [dp_rounds*G, n_tiles) of the same order — as k-step ranges.  XCD x owns the tail steps
@@ -129,8 +169,9 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
                                                                   int tiles_m, int tiles_n, int n_split,
                                                                   float* __restrict__ partials,
                                                                   unsigned long long* __restrict__ dbg, const SkPlan plan,
-                                                                  const StltGemmGroup grp) {
+                                                                  const StltGemmGroup grp, const StltGemmEpi epi) {
   static_assert(!GROUP || (SK && WS), "grouped launches are stream-K launches of the loader-wave build");
+  static_assert(ACT != STLT_ACT_GELU_BWD || (ADD && !GROUP), "the fused GELU backward reads u through the add-source");
   constexpr int prio = STLT_GEMM_PRIO_MODE;
   constexpr int NBIAS = 2;  // bias strips, by tile parity
   __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE_FLOATS + NBIAS * BN];  // operand stages + bias strips
@@ -603,6 +644,81 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int g = 0; g < 8; ++g) *reinterpret_cast<f32x4*>(P + t_row(a) * BN + t_col4(g)) = group(a, g);
+      } else if (ACT == STLT_ACT_GELU_BWD && vec_ok) {
+        // du = drop(dh) ∘ gelu'(u) + the tile's column sums: the column groups go in batches of GB, a batch's u pieces
+        // (2 rows x GB groups) requested together; a group's two rows are summed per lane, then over the 32 lanes of the half
+        // wave (the wave's 64 rows); the wave's sums go to slot wm of the tile row, slots wm + 4 / 8 / 12 get zeros (the
+        // fix-up kernel of a split tile fills all 16 slots itself)
+        const uint64_t key = stlt_drop_key(epi.dr, epi.site);
+        float* cs_row = epi.cs_part + ((size_t)(m0 / BM) * 16 + wm) * (size_t)N + n0;
+        uint64_t drow[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) drow[a] = epi.drop_rows ? (uint64_t)epi.drop_rows[m0 + t_row(a)] : (uint64_t)(m0 + t_row(a));
+        constexpr int GB = 2;  // column groups per batch of u loads (4 per batch spill 6-13 registers at the 168 budget)
+#pragma unroll
+        for (int hf = 0; hf < 8 / GB; ++hf) {
+          f32x4 uv[2][GB];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < GB; ++q) uv[a][q] = *reinterpret_cast<const f32x4*>(R + (int64_t)(m0 + t_row(a)) * ldr + n0 + t_col4(hf * GB + q));
+#pragma unroll
+          for (int q = 0; q < GB; ++q) {
+            const int g = hf * GB + q;
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const f32x4 val = gelu_bwd4(group(a, g), uv[a][q], epi, key, drow[a] * (uint64_t)N + (uint64_t)(n0 + t_col4(g)));
+              *reinterpret_cast<f32x4*>(Yt + (int64_t)(m0 + t_row(a)) * ldy + n0 + t_col4(g)) = val;
+              cs += val;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = half_wave_sum(cs[j]);
+            if (lr == 0) {
+              *reinterpret_cast<f32x4*>(cs_row + t_col4(g)) = cs;
+#pragma unroll
+              for (int k = 1; k < 4; ++k) *reinterpret_cast<f32x4*>(cs_row + (size_t)(4 * k) * N + t_col4(g)) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+      } else if (ACT == STLT_ACT_GELU_BWD) {
+        // ragged tile: the same with guards
+        const uint64_t key = stlt_drop_key(epi.dr, epi.site);
+        float* cs_row = epi.cs_part + ((size_t)(m0 / BM) * 16 + wm) * (size_t)N;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+          const int n = n0 + t_col4(g);
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int m = m0 + t_row(a);
+            const f32x4 acc4 = group(a, g);
+            if (m < M) {
+              const uint64_t drow1 = epi.drop_rows ? (uint64_t)epi.drop_rows[m] : (uint64_t)m;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (n + j < N) {
+                  float v = acc4[j];
+                  if (epi.dr.thr) v = stlt_keep_k(epi.dr.thr, key, drow1 * (uint64_t)N + (uint64_t)(n + j)) ? v * epi.dr.scale : 0.f;
+                  v *= gelu_grad_epilogue(R[(int64_t)m * ldr + n + j]);
+                  Yt[(int64_t)m * ldy + n + j] = v;
+                  cs[j] += v;
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cs[j] = half_wave_sum(cs[j]);
+          if (lr == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (n + j < N) {
+                cs_row[n + j] = cs[j];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) cs_row[(size_t)(4 * k) * N + n + j] = 0.f;
+              }
+          }
+        }
       } else if (vec_ok) {
         // whole tile, 16-byte aligned rows: straight-line code, 16 stores of 16 bytes per lane
 #pragma unroll
@@ -691,7 +807,8 @@ template <int ACT>
 __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict__ partials, int S, int nk,
                                                          const float* __restrict__ bias, const float* __restrict__ R,
                                                          int64_t ldr, float* __restrict__ Y, int64_t ldy, int M, int N,
-                                                         int tiles_m, int tiles_n, int G, const SkPlan plan) {
+                                                         int tiles_m, int tiles_n, int G, const SkPlan plan, const StltGemmEpi epi) {
+  __shared__ float cs_red[8][BN];  // fused GELU backward: the column sums of this workgroup's rows
   const int t = blockIdx.x / FIXUP_CHUNKS, chunk = blockIdx.x - t * FIXUP_CHUNKS;  // a workgroup sums BM/FIXUP_CHUNKS rows of a tile
   const int lo = t * nk, hi = lo + nk;  // hybrid: t counts the tail tiles, steps are tail steps
   const bool hy = plan.dp_rounds > 0;
@@ -729,6 +846,8 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict
 #pragma unroll
   for (int e = 0; e < 4; ++e) bv[e] = (bias && n0 + c4 + e < N) ? bias[n0 + c4 + e] : 0.f;
   const int r_end = (chunk + 1) * (BM / FIXUP_CHUNKS);
+  const uint64_t key = ACT == STLT_ACT_GELU_BWD ? stlt_drop_key(epi.dr, epi.site) : 0ull;
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
   for (int rr = chunk * (BM / FIXUP_CHUNKS) + (threadIdx.x >> 5); rr < r_end; rr += 8) {
     const int m = m0 + rr;
     if (m >= M) break;
@@ -738,16 +857,34 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const float* __restrict
       const size_t slot = (size_t)(2 * v + (start_of(v) >= lo ? 0 : 1));
       acc += *reinterpret_cast<const f32x4*>(partials + slot * (BM * BN) + rr * BN + c4);
     }
+    const uint64_t drow = (ACT == STLT_ACT_GELU_BWD && epi.drop_rows) ? (uint64_t)epi.drop_rows[m] : (uint64_t)m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = n0 + c4 + e;
       if (n < N) {
         float val = acc[e] + bv[e];
-        if (R) val += R[(int64_t)m * ldr + n];
+        if (ACT == STLT_ACT_GELU_BWD) {  // du = drop(dh) * gelu'(u), u read through the add-source pointer
+          if (epi.dr.thr) val = stlt_keep_k(epi.dr.thr, key, drow * (uint64_t)N + (uint64_t)n) ? val * epi.dr.scale : 0.f;
+          val *= gelu_grad_epilogue(R[(int64_t)m * ldr + n]);
+          cs[e] += val;
+        } else if (R) {
+          val += R[(int64_t)m * ldr + n];
+        }
         if (ACT == STLT_ACT_GELU) val = gelu_epilogue(val);
         if (ACT == STLT_ACT_RELU) val = fmaxf(val, 0.f);
         Y[(int64_t)m * ldy + n] = val;
       }
+    }
+  }
+  if (ACT == STLT_ACT_GELU_BWD) {  // slot `chunk` of the tile row: this workgroup's rows, summed in row-thread order
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs_red[threadIdx.x >> 5][c4 + e] = cs[e];
+    __syncthreads();
+    if (threadIdx.x < BN && n0 + (int)threadIdx.x < N) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tsum += cs_red[k][threadIdx.x];
+      epi.cs_part[((size_t)(m0 / BM) * 16 + chunk) * (size_t)N + n0 + threadIdx.x] = tsum;
     }
   }
 }
@@ -935,19 +1072,24 @@ static bool make_sk_plan(int64_t n_tiles, int64_t nk, int64_t G, const double* w
 // C (M,N) = opA(A)·opB(B) [+ bias | + R], contraction length K (multiple of 32).  n_split > 1: C is a slab buffer.
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
-                int64_t K, int n_split, int act, hipStream_t s) {
+                int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi_in) {
   if (!a || !b || !c) return stlt_set_error(STLT_EINVAL, "gemm: null pointer");
+  const StltGemmEpi epi = epi_in ? *epi_in : StltGemmEpi{StltDrop{0u, 1.0f, 0ull}, 0u, nullptr, nullptr};
+  if (act == STLT_ACT_GELU_BWD) {
+    if (!epi_in || !epi.cs_part || !r || transA || !transB || n_split != 1 || bias)
+      return stlt_set_error(STLT_EINVAL, "gemm: the fused GELU backward is the dX layout with u as the add-source and a column-sum buffer");
+  }
   if (M < 0 || N <= 0 || K <= 0 || K % BK != 0)
     return stlt_set_error(STLT_EINVAL, "gemm: contraction length K=%lld must be a positive multiple of %d (N=%lld)", (long long)K, BK, (long long)N);
   if (lda % 4 != 0 || ldb % 4 != 0 || (r && ldr < N) || ldc < N || lda < (transA ? M : K) || ldb < (transB ? N : K))
     return stlt_set_error(STLT_EINVAL, "gemm: bad leading dimension (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
   if (M > 0x7fffff00LL || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gemm: M/N too large");
-  if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU) return stlt_set_error(STLT_EINVAL, "gemm: unknown activation %d", act);
+  if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU && act != STLT_ACT_GELU_BWD) return stlt_set_error(STLT_EINVAL, "gemm: unknown activation %d", act);
   if (n_split < 1 || (K / BK) % n_split != 0) return stlt_set_error(STLT_EINVAL, "gemm: n_split=%d must divide K/32=%lld", n_split, (long long)(K / BK));
   if (transA && !transB) return stlt_set_error(STLT_EINVAL, "gemm: the (transA, !transB) layout is not built");
   if (n_split > 1 && (bias || act != STLT_ACT_NONE || r)) return stlt_set_error(STLT_EINVAL, "gemm: a split product takes no bias / activation / add-source");
-  if ((transA || transB) && (act != STLT_ACT_NONE || bias)) return stlt_set_error(STLT_EINVAL, "gemm: bias/activation only with the forward (NT) layout");
-  if (r && act != STLT_ACT_NONE) return stlt_set_error(STLT_EINVAL, "gemm: an add-source excludes an activation");
+  if ((transA || transB) && ((act != STLT_ACT_NONE && act != STLT_ACT_GELU_BWD) || bias)) return stlt_set_error(STLT_EINVAL, "gemm: bias/activation only with the forward (NT) layout");
+  if (r && act != STLT_ACT_NONE && act != STLT_ACT_GELU_BWD) return stlt_set_error(STLT_EINVAL, "gemm: an add-source excludes an activation");
   if (M == 0) return 0;
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   if (tiles_m * tiles_n * n_split > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "gemm: too many tiles");
@@ -988,9 +1130,10 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
         if (make_sk_plan(n_tiles, nk, G, xcd_weights(), weighted, plan, tail)) fix_tiles = tail;
         else plan = SkPlan{};
       }
-#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan, StltGemmGroup{})
+#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan, StltGemmGroup{}, epi)
 #define LAUNCH_SK(ACTV, TAV, TBV, ADDV) do { if (ws_sk) LAUNCH_SK1(ACTV, TAV, TBV, ADDV, true, dim3(GEMM_THREADS_WS)); else LAUNCH_SK1(ACTV, TAV, TBV, ADDV, false, block); } while (0)
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
+      else if (transB && act == STLT_ACT_GELU_BWD) LAUNCH_SK(STLT_ACT_GELU_BWD, false, true, true);
       else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
       else if (r) LAUNCH_SK(STLT_ACT_NONE, false, false, true);  // y = x·Wᵀ + b + r (the residual of a post-norm layer)
       else if (act == STLT_ACT_GELU) LAUNCH_SK(STLT_ACT_GELU, false, false, false);
@@ -1000,8 +1143,9 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 #undef LAUNCH_SK1
       if (int e = stlt_check_launch("gemm_nt_kernel(stream-k)")) return e;
       dim3 fgrid((unsigned)(fix_tiles * FIXUP_CHUNKS)), fblock(256);
-#define FIX(ACTV) hipLaunchKernelGGL((gemm_fixup_kernel<ACTV>), fgrid, fblock, 0, s, P, S, (int)nk, bias, r, ldr, c, ldc, (int)M, (int)N, (int)tiles_m, (int)tiles_n, (int)G, plan)
-      if (act == STLT_ACT_GELU) FIX(STLT_ACT_GELU);
+#define FIX(ACTV) hipLaunchKernelGGL((gemm_fixup_kernel<ACTV>), fgrid, fblock, 0, s, P, S, (int)nk, bias, r, ldr, c, ldc, (int)M, (int)N, (int)tiles_m, (int)tiles_n, (int)G, plan, epi)
+      if (act == STLT_ACT_GELU_BWD) FIX(STLT_ACT_GELU_BWD);
+      else if (act == STLT_ACT_GELU) FIX(STLT_ACT_GELU);
       else if (act == STLT_ACT_RELU) FIX(STLT_ACT_RELU);
       else FIX(STLT_ACT_NONE);
 #undef FIX
@@ -1012,9 +1156,10 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   // wave-specialised build (4 DMA-only waves beside the 8 MFMA waves) unless STLT_GEMM_WS=0 (A/B measurements)
   static const bool ws = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
   const dim3 block_ws(GEMM_THREADS_WS);
-#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf, SkPlan{}, StltGemmGroup{})
+#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf, SkPlan{}, StltGemmGroup{}, epi)
 #define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws) LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
+  else if (transB && act == STLT_ACT_GELU_BWD) LAUNCH(STLT_ACT_GELU_BWD, false, false, true, true);
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
   else if (r) LAUNCH(STLT_ACT_NONE, false, false, false, true);  // y = x·Wᵀ + b + r
   else if (g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true, false, false, false);  // diagnostic build path only
@@ -1068,7 +1213,7 @@ int launch_weight_grad_group(const StltWeightGradItem* items, int n_items, hipSt
   float* P = t_gemm_scratch;
   hipLaunchKernelGGL((gemm_nt_kernel<STLT_ACT_NONE, false, true, true, true, true, true, true>), dim3((unsigned)G), dim3(GEMM_THREADS_WS), 0, s,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, (int64_t)0,
-                     (float*)nullptr, (int64_t)0, (int64_t)0, 0, 0, BK, 0, 0, 1, P, (unsigned long long*)nullptr, SkPlan{}, grp);
+                     (float*)nullptr, (int64_t)0, (int64_t)0, 0, 0, BK, 0, 0, 1, P, (unsigned long long*)nullptr, SkPlan{}, grp, StltGemmEpi{StltDrop{0u, 1.0f, 0ull}, 0u, nullptr, nullptr});
   if (int e = stlt_check_launch("gemm_nt_kernel(grouped stream-k)")) return e;
   hipLaunchKernelGGL(gemm_fixup_group_kernel, dim3((unsigned)(tiles * FIXUP_CHUNKS)), dim3(256), 0, s, P, S, grp);
   return stlt_check_launch("gemm_fixup_group_kernel");

@@ -83,6 +83,7 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   s.slabs = take((int64_t)s.slab_floats);
   int64_t red = ln_bwd_scratch_floats(d);
   if (512 * 4 * d > red) red = 512 * 4 * d;  // gelu_bwd column-sum partials (512 x 4d); attn_bwd needs 256 x 3d
+  if ((tokp + 255) / 256 * 16 * 4 * d > red) red = (tokp + 255) / 256 * 16 * 4 * d;  // fused GELU backward: 16 partial rows per 256-row tile row
   if (16 * (T + 5) * d > red) red = 16 * (T + 5) * d;  // frames-embedding parameter partials
   const int64_t eb = embed_bwd_scratch_floats(B * T * N, C, d);
   if (eb > red) red = eb;
@@ -124,6 +125,22 @@ static int weight_grad_all(const StltWeightGradItem* items, int n, const Scratch
   return 0;
 }
 
+// dh = df·W2 followed by du = drop(dh) ∘ gelu'(u) and lin1_b += column sums of du.  Fused (default): the activation
+// derivative, the dropout mask and the column sums ride in the product's epilogue / fix-up (gemm.hip: STLT_ACT_GELU_BWD) and
+// one reduction finishes the bias gradient; STLT_FUSE_GELU_BWD=0 keeps the stand-alone pass behind the product (A/B runs).
+static int ffn_hidden_backward(const float* df, const float* lin2_w, const float* u, float* du, int64_t rows, int64_t d, float* g_lin1_b,
+                               const Scratch& sc, StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s) {
+  static const bool fused = [] { const char* e = getenv("STLT_FUSE_GELU_BWD"); return e ? atoi(e) != 0 : true; }();
+  if (fused && g_lin1_b) {
+    const StltGemmEpi epi{dr, site, drop_rows, sc.red};
+    TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi));
+    return launch_reduce_slabs(sc.red, 4 * d, (int)((rows + 255) / 256 * 16), g_lin1_b, 4 * d, 1, s);
+  }
+  TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, nullptr, 0, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
+  if (g_lin1_b) return launch_gelu_bwd_colsum(du, u, du, rows, 4 * d, g_lin1_b, sc.red, s, dr, site, drop_rows);  // du; lin1_b += colsum(du)
+  return launch_gelu_bwd(du, u, du, rows * 4 * d, s, dr, site, drop_rows, 4 * d);
+}
+
 // backward of one encoder layer.  dy: gradient wrt the layer output (M,d) in bufA; on return bufA holds the gradient
 // wrt the layer input.  bufB / bufC / bufD / bufE (M,d), bufQ (M,3d), bufH (M,4d) are scratch with zero row padding.
 // The four output gradients of the layer's Linears (df, du, da, dqkv) stay alive until the end of the layer, where their
@@ -143,10 +160,8 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
                     G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0,
                     G(&stlt_layer_params::lin2_b)));                                               // bufB = ds2, df; lin2_b += colsum(df)
   // f = h·W2ᵀ + b2
-  TRY(launch_gemm(0, 1, df, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, M, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
-  // h = drop(gelu(u))
-  if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_gelu_bwd_colsum(bufH, t.u, bufH, M, 4 * d, gb, sc.red, s, dr, site0 + 2));  // bufH = du; lin1_b += colsum(du)
-  else TRY(launch_gelu_bwd(bufH, t.u, bufH, M * 4 * d, s, dr, site0 + 2));
+  // h = drop(gelu(u)): bufH = du = drop(df·W2) ∘ gelu'(u); lin1_b += colsum(du)
+  TRY(ffn_hidden_backward(df, lp.lin2_w, t.u, bufH, M, d, G(&stlt_layer_params::lin1_b), sc, dr, site0 + 2, nullptr, s));
   // u = x1·W1ᵀ + b1
   TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, M, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x + drop(a))
@@ -233,9 +248,7 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   // y = LN2(x1 + drop(f))
   TRY(launch_ln_bwd(dy, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, n, d, bufB, d, G(&stlt_layer_params::norm2_w),
                     G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0, G(&stlt_layer_params::lin2_b), rows));
-  TRY(launch_gemm(0, 1, df, d, lp.lin2_w, 4 * d, nullptr, nullptr, 0, bufH, 4 * d, 0, n, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
-  if (float* gb = G(&stlt_layer_params::lin1_b)) TRY(launch_gelu_bwd_colsum(bufH, t.u, bufH, n, 4 * d, gb, sc.red, s, dr, site0 + 2, rows));
-  else TRY(launch_gelu_bwd(bufH, t.u, bufH, n * 4 * d, s, dr, site0 + 2, rows, 4 * d));
+  TRY(ffn_hidden_backward(df, lp.lin2_w, t.u, bufH, n, d, G(&stlt_layer_params::lin1_b), sc, dr, site0 + 2, rows, s));  // bufH = du
   TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, n, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x[rows] + drop(a)), a = ctx[rows]·Woᵀ + bo: gather the two inputs again (bufQ is free until the attention backward)
   float* g_x = bufQ;

@@ -103,6 +103,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._layout_key = None
+        self._group_step = {}
 
     def _bind(self, layout, device):
         from . import _lib as L
@@ -131,6 +132,7 @@ class FusedAdamW(torch.optim.Optimizer):
             assert arr.dtype.itemsize == C.sizeof(L.OptChunk)
             self._tables.append((g, torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(rows)))
         self._scratch = torch.zeros(1024 + 2, device=device, dtype=torch.float32)
+        self._group_step = {}  # re-read from the (possibly just loaded) per-parameter step tensors at the next step
         self._layout_key = tuple((id(p), p.data_ptr(), off, n) for p, off, n in layout)
 
     @torch.no_grad()
@@ -149,18 +151,16 @@ class FusedAdamW(torch.optim.Optimizer):
         for g, table, n_chunks in self._tables:
             if n_chunks == 0:
                 continue
-            # torch keeps one `step` tensor per parameter; the parameters of a group always step together, so they share
-            # one tensor object here (state dicts still list it per parameter) and the host does one increment per group
-            live = [self.state[p] for p in g["params"] if "exp_avg" in self.state.get(p, {})]
-            if not live:
-                continue
-            shared = live[0]["step"]
-            if any(st["step"] is not shared for st in live):  # first step / after load_state_dict: adopt the furthest count
-                shared = torch.tensor(float(max(float(st["step"]) for st in live)))
-                for st in live:
-                    st["step"] = shared
-            shared += 1
-            step = int(shared.item())
+            # torch keeps one `step` tensor per parameter; the parameters of a group step together, so the host keeps one
+            # integer per group and writes the per-parameter tensors only when a state dict is asked for (state_dict())
+            gi = id(g)
+            if gi not in self._group_step:
+                live = [float(self.state[p]["step"]) for p in g["params"] if "exp_avg" in self.state.get(p, {})]
+                if not live:
+                    continue
+                self._group_step[gi] = int(max(live))
+            self._group_step[gi] += 1
+            step = self._group_step[gi]
             L.check(lib.stlt_adamw_step(table.data_ptr(), n_chunks, flat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
                                         out.data_ptr() if max_norm > 0 else None, float(g["lr"]), float(g["betas"][0]),
                                         float(g["betas"][1]), float(g["eps"]), step, stream), "stlt_adamw_step")
@@ -169,11 +169,26 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         raise RuntimeError("FusedAdamW consumes the flat gradient buffer of the native backward: call step_flat(flat, layout)")
 
+    def _sync_step_tensors(self):
+        for g in self.param_groups:
+            n = getattr(self, "_group_step", {}).get(id(g))
+            if n is None:
+                continue
+            for p in g["params"]:
+                st = self.state.get(p)
+                if st is not None and "exp_avg" in st:
+                    st["step"] = torch.tensor(float(n))  # one tensor per parameter, as torch.optim.AdamW keeps them
+
+    def state_dict(self):
+        self._sync_step_tensors()
+        return super().state_dict()
+
     def load_state_dict(self, state_dict):
         """torch's loader replaces `self.state[p]` with fresh tensors, which no longer alias the flat moment buffers the
         kernel updates: drop the binding so that the next step_flat() re-binds and copies the loaded moments in."""
         super().load_state_dict(state_dict)
         self._layout_key = None
+        self._group_step = {}
 
 
 class Trainer:
