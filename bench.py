@@ -502,13 +502,14 @@ def main():
         # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes of this same command (PMC cannot be
         # collected from inside the process); the summary is committed under profiles/ and only quoted when it was
         # taken on this workload.
-        traffic_gemm = traffic_attn = traffic_attn_sp = None
-        tpath = os.path.join(ROOT, "profiles", "round2_traffic_pmc.json")
+        traffic_gemm = traffic_attn = traffic_attn_sp = traffic_mhsa = None
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"round{r}_traffic_pmc.json") for r in (3, 2)) if os.path.exists(q)), "")
         if args.config == "cfg2" and B == 1024 and not args.no_cls_only and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             traffic_gemm, traffic_attn, traffic_attn_sp = (tj.get("gemm_avg_bytes_per_launch"), tj.get("attn_temporal_avg_bytes_per_launch"),
                                                            tj.get("attn_spatial_avg_bytes_per_launch"))
+            traffic_mhsa = tj.get("mhsa_fused_avg_bytes_per_launch")
         out = {
             "metric": "clips/s STLT forward (T=32, N_obj=7, d=768)" if args.config == "cfg2" else f"clips/s STLT forward ({args.config})",
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
@@ -521,10 +522,10 @@ def main():
                        "flops_per_clip_dense": pkg.synth.flops_per_clip(T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"])},
             "roofline": {"kernel": "gemm_nt_kernel (f32 MFMA nn.Linear)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                         "traffic": traffic_gemm, "traffic_note": "avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), profiles/round2_traffic_pmc.json", "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
+                         "traffic": traffic_gemm, "traffic_note": "avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), from the committed rocprofv3 --pmc passes of this command: " + os.path.basename(tpath), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
             "roofline_attn_temporal": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=true> for T <= 64 (16-row tiles), attn_core_kernel beyond", "bound": "hbm", "achieved": round(at_gbs, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at_gbs / HBM_PEAK_GBS, 4),
-                                       "traffic": traffic_attn, "traffic_note": attn_temporal_note + "bytes/launch of the temporal kernel (its own symbol: the CAUSAL=true instantiation), L2 memory-side, profiles/round2_traffic_pmc.json; algorithmic " + str(int(at_bytes)), "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
+                                       "traffic": traffic_attn, "traffic_note": attn_temporal_note + "bytes/launch of the temporal kernel (its own symbol: the CAUSAL=true instantiation), L2 memory-side, " + os.path.basename(tpath) + "; algorithmic " + str(int(at_bytes)), "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
             "roofline_attn_spatial": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=false> for N <= 64 (16-row tiles; frames packed per block for N <= 16), attn_core_kernel beyond", "bound": "hbm", "achieved": round(as_gbs, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(as_gbs / HBM_PEAK_GBS, 4),
                                       "traffic": traffic_attn_sp, "launches_per_step": as_n, "us_per_launch": round(as_ms / max(as_n, 1) * 1e3, 2)},
@@ -532,6 +533,7 @@ def main():
         }
         if fused:
             out["roofline_mhsa_fused"] = mhsa_fused_roofline(k_ms, B, T, d, c["num_attention_heads"])
+            out["roofline_mhsa_fused"]["traffic"] = traffic_mhsa
         if world == 1 and not args.no_skip_padding:
             try:
                 # Same workload with STLT_FLAG_SKIP_PADDING (opt-in: only the real tokens / frames of the padded batch are
