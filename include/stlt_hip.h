@@ -187,6 +187,9 @@ typedef struct {
 #define STLT_FLAG_TRAIN_UPPER_ONLY 8   /* stlt_train_backward: stop after the prediction head and the temporal tower (their gradients are final) */
 #define STLT_FLAG_TRAIN_LOWER_ONLY 16  /* stlt_train_backward: resume from there (frames embeddings, spatial tower, token embeddings); the scratch must be
                                           untouched in between.  Lets a data-parallel caller all-reduce the upper gradients while the lower half runs. */
+#define STLT_FLAG_TRAIN_BACKBONE 32     /* stlt_train_forward / _backward as the StltBackbone of a fusion model (models.py:136-152 inside :446-483): no
+                                         * prediction head, every temporal layer on every frame; the forward's `logits` argument receives the (B*T, d)
+                                         * backbone output and the backward's `dlogits` argument is its gradient (B*T, d).  Not with STLT_FLAG_SKIP_PADDING. */
 #define STLT_FLAG_LAST_ROW_ONLY_TEMPORAL 2 /* stlt_forward with out_btd == NULL: last temporal layer's out-proj/FFN on the rows at lengths-1 only (models.py:189-192) */
 
 /* bytes of scratch the whole-path calls need for this shape */
@@ -346,6 +349,35 @@ int stlt_loss_fwd_bwd(const float* logits, const void* labels, int kind, int64_t
 int stlt_grad_norm(const float* flat_grad, int64_t n, float max_norm, float* scratch, float* out, stlt_stream_t stream);
 int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const float* flat_grad, float* exp_avg, float* exp_avg_sq,
                     const float* norm_and_clip, float lr, float beta1, float beta2, float eps, int64_t step, stlt_stream_t stream);
+
+/* ---- block-level training calls for the fusion models (CAF / CACNF / LCF; reference models.py:328-431, 239-246) ----
+ * One native forward and one native reverse call per residual block, so an optimisation step of a fusion model is a few
+ * dozen calls instead of a few hundred op-level ones.  The caller owns the tape tensors (q / kv / ctx / a, u / h / f) and the
+ * scratch (stlt_block_scratch_bytes(rows, d), rows = the larger token count of the block).
+ *   attention block (SelfAttentionLayer / CrossAttentionLayer :345-382, and the first half of nn.TransformerEncoderLayer):
+ *     out = LN_eps(x + drop(MHA(x, c, c) Wo^T + bo)); c == NULL: self-attention on a packed q|k|v buffer q (S*Lq, 3d);
+ *     else q (S*Lq, d) and kv (S*Lk, 2d).  kpm (S*Lk) bytes over the keys (never NULL: pass zeros).  Dropout sites: site0 =
+ *     attention probabilities, site0 + 1 = in front of the residual.
+ *   feed-forward block (:384-401 layout_ffn, and the second half of nn.TransformerEncoderLayer):
+ *     out = LN_eps(x + drop(W2 drop_inner(act(W1 x + b1)) + b2)), act = STLT_ACT_GELU (u and h kept) or STLT_ACT_RELU (h kept);
+ *     inner_dropout != 0 applies site0 to the hidden, site0 + 1 is the dropout in front of the residual.
+ * gemm_scratch (forward calls): NULL, or stlt_gemm_scratch_bytes() of device memory lent for the call's stream-K launches.
+ * The backward calls ACCUMULATE (+=) into the gradient struct's buffers (NULL members are skipped), write dx (and dc, the
+ * gradient wrt the context tokens of a cross-attention block), and recompute the dropout masks from (drop_p, seed, site0). */
+size_t stlt_block_scratch_bytes(int64_t rows, int64_t d);
+int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_t H, float eps, const float* x, int64_t Lq, const float* c,
+                              int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed, uint32_t site0, float* q,
+                              float* kv, float* ctx, float* a, float* out, void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream);
+int stlt_attn_block_bwd_train(const stlt_attn_block_params* p, const stlt_attn_block_params* g, int64_t d, int64_t H, float eps, const float* x,
+                              int64_t Lq, const float* c, int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed,
+                              uint32_t site0, const float* q, const float* kv, const float* ctx, const float* a, const float* dy, float* dx,
+                              float* dc, void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+int stlt_ffn_block_fwd_train(const stlt_ffn_block_params* p, int64_t d, float eps, int act, int inner_dropout, const float* x, int64_t M,
+                             float drop_p, uint64_t seed, uint32_t site0, float* u, float* h, float* f, float* out, void* gemm_scratch,
+                             size_t gemm_scratch_bytes, stlt_stream_t stream);
+int stlt_ffn_block_bwd_train(const stlt_ffn_block_params* p, const stlt_ffn_block_params* g, int64_t d, float eps, int act, int inner_dropout,
+                             const float* x, int64_t M, float drop_p, uint64_t seed, uint32_t site0, const float* u, const float* h, const float* f,
+                             const float* dy, float* dx, void* scratch, size_t scratch_bytes, stlt_stream_t stream);
 
 /* ---- evaluators on the device (reference src/utils/evaluation.py) ----
  * stlt_eval_topk: EvaluatorSomething.process (evaluation.py:21-34) for one logit head.  counts[0] += clips whose label is

@@ -15,6 +15,7 @@ FLAG_LAST_ROW_ONLY_TEMPORAL = 2
 FLAG_SKIP_PADDING = 4
 FLAG_TRAIN_UPPER_ONLY = 8
 FLAG_TRAIN_LOWER_ONLY = 16
+FLAG_TRAIN_BACKBONE = 32
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _f = C.POINTER(C.c_float)
@@ -134,6 +135,15 @@ SIGNATURES = {
     "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
     "stlt_dropout": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp]),
     "stlt_relu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "stlt_block_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "stlt_attn_block_fwd_train": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_float, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_float,
+                                            C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "stlt_attn_block_bwd_train": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_float, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_float,
+                                            C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "stlt_ffn_block_fwd_train": (C.c_int, [_vp, C.c_int64, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp, _vp, _vp,
+                                           _vp, _vp, C.c_size_t, _vp]),
+    "stlt_ffn_block_bwd_train": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp, _vp,
+                                           _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "stlt_prof_take_gemm_flops": (C.c_double, []),
     "stlt_eval_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_eval_max_clips": (C.c_int64, []),

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstlt_hip.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 SOURCES = ["api.hip", "rowwise.hip", "gemm.hip", "attn.hip", "backward.hip", "train.hip", "collate.hip", "caf.hip", "ragged.hip",
-           "optim.hip", "bwd_api.hip", "evalk.hip", "attn16.hip", "attn_bwd16.hip", "mhsa.hip"]
+           "optim.hip", "bwd_api.hip", "evalk.hip", "attn16.hip", "attn_bwd16.hip", "mhsa.hip", "blocks.hip"]
 BASE_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
 

@@ -1,0 +1,194 @@
+// Block-level training entry points: one native forward and one native reverse call per residual block of the fusion
+// models (reference src/modelling/models.py:328-431 — SelfAttentionLayer / CrossAttentionLayer / the feed-forward block —
+// and the two halves of nn.TransformerEncoderLayer as configured at :46-52, :118-124, :239-246), so that a CAF / CACNF /
+// LCF optimisation step is a few dozen calls through the C-ABI instead of a few hundred op-level ones.  Pure orchestration
+// of launchers the STLT path already has; the caller owns the tape tensors and the scratch.
+//   attention block:  out = LN_eps( x + drop( MHA(x, c, c; kpm, causal, prob-dropout) · Woᵀ + bo ) )      c = x for self-attention
+//   feed-forward block: out = LN_eps( x + drop( W2 · drop_inner( act(W1 x + b1) ) + b2 ) )                 act = GELU | ReLU
+// Dropout sites: site0 = attention probabilities / inner dropout, site0 + 1 = the dropout in front of the residual.
+#include "common.h"
+
+namespace {
+
+#define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct BlockScratch {
+  char* lin;        // stlt_linear_bwd's scratch (stream-K partial tiles + column-sum partials)
+  size_t lin_bytes;
+  float *ds, *da, *dctx, *dq, *dkv, *dh, *red;
+  size_t total;
+};
+
+// rows = the larger of the query-side and key-side row counts
+BlockScratch block_scratch(char* base, int64_t rows, int64_t d) {
+  BlockScratch b;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = align256(off + bytes); return p; };
+  b.lin_bytes = stlt_linear_bwd_scratch_bytes(4 * d);
+  b.lin = take(b.lin_bytes);
+  const size_t f = sizeof(float);
+  b.ds = (float*)take((size_t)rows * d * f);
+  b.da = (float*)take((size_t)rows * d * f);
+  b.dctx = (float*)take((size_t)rows * d * f);
+  b.dq = (float*)take((size_t)rows * 3 * d * f);
+  b.dkv = (float*)take((size_t)rows * 2 * d * f);
+  b.dh = (float*)take((size_t)rows * 4 * d * f);
+  int64_t red = ln_bwd_scratch_floats(d);
+  if (512 * 4 * d > red) red = 512 * 4 * d;
+  b.red = (float*)take((size_t)red * f);
+  b.total = off;
+  return b;
+}
+
+// The weight-gradient products of a block are collected and run as ONE grouped stream-K launch at the end of the block's
+// backward (gemm.hip: launch_weight_grad_group) when every product contracts over a multiple of 32 rows; otherwise product
+// by product (MFMA over the 32-row multiple + the strided kernel for the rest: stlt_linear_bwd).
+struct DwList {
+  StltWeightGradItem it[4];
+  int n = 0;
+  void add(const float* dy, int64_t n_out, const float* x, int64_t k_in, int64_t rows, float* g_w) {
+    if (g_w && rows > 0) it[n++] = StltWeightGradItem{dy, n_out, x, k_in, rows, g_w};
+  }
+};
+int flush_dw(const DwList& l, const BlockScratch& sc, hipStream_t s) {
+  if (l.n == 0) return 0;
+  bool group_ok = true;
+  for (int i = 0; i < l.n; ++i) group_ok = group_ok && l.it[i].rows % 32 == 0;
+  StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
+  if (group_ok) return launch_weight_grad_group(l.it, l.n, s);
+  for (int i = 0; i < l.n; ++i)
+    TRY(stlt_linear_bwd(l.it[i].x, l.it[i].g_w /* unused: dx is null */, l.it[i].dy, l.it[i].rows, l.it[i].n_out, l.it[i].k_in, nullptr, l.it[i].g_w, nullptr,
+                        sc.lin, sc.lin_bytes, (stlt_stream_t)s));
+  return 0;
+}
+
+// dx (M,K) = dy·W (+ add); the weight gradient dw (N,K) += dyᵀ·x is queued on `dws`; db (N) += column sums of dy.
+// N (the contraction length of dx) is a multiple of 32 for every Linear of these blocks (d, 2d, 3d, 4d with d = 64 H).
+int linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, const float* add, float* dw,
+               float* db, DwList& dws, const BlockScratch& sc, hipStream_t s) {
+  if (dx && M > 0) {
+    StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
+    TRY(launch_gemm(0, 1, dy, N, w, K, nullptr, add, K, dx, K, 0, M, K, N, 1, STLT_ACT_NONE, s));
+  }
+  dws.add(dy, N, x, K, M, dw);
+  if (db && M > 0) return launch_colsum_acc(dy, N, M, N, db, sc.red, s);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t stlt_block_scratch_bytes(int64_t rows, int64_t d) {
+  if (rows <= 0 || d <= 0) return 0;
+  return block_scratch(nullptr, rows, d).total;
+}
+
+int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_t H, float eps, const float* x, int64_t Lq, const float* c,
+                              int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed, uint32_t site0, float* q,
+                              float* kv, float* ctx, float* a, float* out, void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream) {
+  if (!p || !x || !kpm || !q || !ctx || !a || !out || (c && !kv)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_fwd_train: null argument");
+  if (gemm_scratch && gemm_scratch_bytes < STLT_GEMM_SCRATCH_BYTES) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_block_fwd_train: gemm scratch too small");
+  StltGemmScratch lend(gemm_scratch, STLT_GEMM_SCRATCH_BYTES);  // under-filled products run as stream-K when scratch is lent
+  if (d <= 0 || H <= 0 || d != H * 64) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_fwd_train: head dim must be 64");
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
+  if (!c && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_fwd_train: self-attention needs Lq == Lk");
+  hipStream_t s = (hipStream_t)stream;
+  const StltDrop dr = stlt_drop_make(drop_p, seed);
+  const int64_t Mq = S * Lq, Mk = S * Lk;
+  const int kid = causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL;
+  if (!c) {  // packed q | k | v
+    TRY(launch_linear(x, d, p->in_proj_w, p->in_proj_b, q, 3 * d, Mq, 3 * d, d, STLT_ACT_NONE, s));
+    TRY(launch_attn(q, kpm, causal, S, Lq, H, 64, ctx, kid, s, dr, site0));
+  } else {   // q from x, k | v from the other modality's tokens (models.py:362-382)
+    TRY(launch_linear(x, d, p->in_proj_w, p->in_proj_b, q, d, Mq, d, d, STLT_ACT_NONE, s));
+    TRY(launch_linear(c, d, p->in_proj_w + d * d, p->in_proj_b + d, kv, 2 * d, Mk, 2 * d, d, STLT_ACT_NONE, s));
+    TRY(launch_attn_general(q, d, kv, kv + d, 2 * d, kpm, causal, S, Lq, Lk, H, 64, ctx, kid, s, dr, site0));
+  }
+  TRY(launch_linear(ctx, d, p->out_proj_w, p->out_proj_b, a, d, Mq, d, d, STLT_ACT_NONE, s));
+  return launch_add_layernorm(a, d, x, d, p->ln_w, p->ln_b, eps, Mq, d, out, d, s, dr, site0 + 1);
+}
+
+// g: gradient buffers of the block's parameters (same struct; ACCUMULATED into; null members are skipped).
+// dx (S*Lq, d) = gradient wrt x; dc (S*Lk, d) = gradient wrt the context tokens (cross-attention only, may be null).
+int stlt_attn_block_bwd_train(const stlt_attn_block_params* p, const stlt_attn_block_params* g, int64_t d, int64_t H, float eps, const float* x,
+                              int64_t Lq, const float* c, int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed,
+                              uint32_t site0, const float* q, const float* kv, const float* ctx, const float* a, const float* dy, float* dx,
+                              float* dc, void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
+  if (!p || !g || !x || !kpm || !q || !ctx || !a || !dy || !dx || !scratch || (c && !kv)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: null argument");
+  if (d <= 0 || H <= 0 || d != H * 64) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: head dim must be 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t Mq = S * Lq, Mk = S * Lk;
+  const BlockScratch sc = block_scratch((char*)scratch, Mq > Mk ? Mq : Mk, d);
+  if (scratch_bytes < sc.total) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_block_bwd_train: scratch %zu B < required %zu B", scratch_bytes, sc.total);
+  const StltDrop dr = stlt_drop_make(drop_p, seed);
+  auto G = [&](const float* q_) { return const_cast<float*>(q_); };
+  // out = LN(x + drop(a)): ds = residual-path gradient, da = gradient wrt a (= ds without dropout); out_proj_b += colsum(da)
+  float* da = dr.thr ? sc.da : sc.ds;
+  TRY(launch_ln_bwd(dy, d, x, d, a, d, p->ln_w, eps, Mq, d, sc.ds, d, G(g->ln_w), G(g->ln_b), sc.red, s, dr, site0 + 1, sc.da, 0, G(g->out_proj_b)));
+  // a = ctx·Woᵀ + bo
+  DwList dws;
+  TRY(linear_bwd(ctx, p->out_proj_w, da, Mq, d, d, sc.dctx, nullptr, G(g->out_proj_w), nullptr, dws, sc, s));
+  if (!c) {
+    // packed self-attention: dqkv (Mq, 3d); in_proj_b += its column sums (accumulated by the attention backward)
+    TRY(launch_attn_bwd(q, sc.dctx, kpm, causal, S, Lq, H, 64, sc.dq, s, dr, site0, G(g->in_proj_b), sc.red));
+    TRY(linear_bwd(x, p->in_proj_w, sc.dq, Mq, 3 * d, d, dx, sc.ds, G(g->in_proj_w), nullptr, dws, sc, s));  // dx = dqkv·Win + ds
+    return flush_dw(dws, sc, s);
+  }
+  TRY(stlt_attn_bwd(q, d, kv, kv + d, 2 * d, sc.dctx, kpm, causal, S, Lq, Lk, H, 64, drop_p, seed, site0, sc.dq, d, sc.dkv, sc.dkv + d, 2 * d, stream));
+  TRY(linear_bwd(x, p->in_proj_w, sc.dq, Mq, d, d, dx, sc.ds, G(g->in_proj_w), G(g->in_proj_b), dws, sc, s));  // dx = dq·Wq + ds
+  TRY(linear_bwd(c, p->in_proj_w + d * d, sc.dkv, Mk, 2 * d, d, dc, nullptr, g->in_proj_w ? G(g->in_proj_w) + d * d : nullptr,
+                 g->in_proj_b ? G(g->in_proj_b) + d : nullptr, dws, sc, s));
+  return flush_dw(dws, sc, s);
+}
+
+int stlt_ffn_block_fwd_train(const stlt_ffn_block_params* p, int64_t d, float eps, int act, int inner_dropout, const float* x, int64_t M,
+                             float drop_p, uint64_t seed, uint32_t site0, float* u, float* h, float* f, float* out, void* gemm_scratch,
+                             size_t gemm_scratch_bytes, stlt_stream_t stream) {
+  if (!p || !x || !h || !f || !out || (act == STLT_ACT_GELU && !u)) return stlt_set_error(STLT_EINVAL, "stlt_ffn_block_fwd_train: null argument");
+  if (gemm_scratch && gemm_scratch_bytes < STLT_GEMM_SCRATCH_BYTES) return stlt_set_error(STLT_EWORKSPACE, "stlt_ffn_block_fwd_train: gemm scratch too small");
+  StltGemmScratch lend(gemm_scratch, STLT_GEMM_SCRATCH_BYTES);
+  if (act != STLT_ACT_GELU && act != STLT_ACT_RELU) return stlt_set_error(STLT_EINVAL, "stlt_ffn_block_fwd_train: activation must be GELU or ReLU");
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
+  hipStream_t s = (hipStream_t)stream;
+  const StltDrop dr = stlt_drop_make(drop_p, seed);
+  const StltDrop inner = inner_dropout ? dr : StltDrop{0u, 1.0f, 0ull};
+  if (act == STLT_ACT_GELU) {
+    TRY(launch_linear(x, d, p->lin1_w, p->lin1_b, u, 4 * d, M, 4 * d, d, STLT_ACT_NONE, s));
+    TRY(launch_gelu_fwd(u, h, M * 4 * d, s, inner, site0));
+  } else {
+    TRY(launch_linear(x, d, p->lin1_w, p->lin1_b, h, 4 * d, M, 4 * d, d, STLT_ACT_RELU, s));
+    if (inner.thr) TRY(stlt_dropout(h, h, M * 4 * d, drop_p, seed, site0, stream));
+  }
+  TRY(launch_linear(h, 4 * d, p->lin2_w, p->lin2_b, f, d, M, d, 4 * d, STLT_ACT_NONE, s));
+  return launch_add_layernorm(f, d, x, d, p->ln_w, p->ln_b, eps, M, d, out, d, s, dr, site0 + 1);
+}
+
+int stlt_ffn_block_bwd_train(const stlt_ffn_block_params* p, const stlt_ffn_block_params* g, int64_t d, float eps, int act, int inner_dropout,
+                             const float* x, int64_t M, float drop_p, uint64_t seed, uint32_t site0, const float* u, const float* h, const float* f,
+                             const float* dy, float* dx, void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
+  if (!p || !g || !x || !h || !f || !dy || !dx || !scratch || (act == STLT_ACT_GELU && !u)) return stlt_set_error(STLT_EINVAL, "stlt_ffn_block_bwd_train: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const BlockScratch sc = block_scratch((char*)scratch, M, d);
+  if (scratch_bytes < sc.total) return stlt_set_error(STLT_EWORKSPACE, "stlt_ffn_block_bwd_train: scratch %zu B < required %zu B", scratch_bytes, sc.total);
+  const StltDrop dr = stlt_drop_make(drop_p, seed);
+  const StltDrop inner = inner_dropout ? dr : StltDrop{0u, 1.0f, 0ull};
+  auto G = [&](const float* q_) { return const_cast<float*>(q_); };
+  float* df = dr.thr ? sc.da : sc.ds;
+  TRY(launch_ln_bwd(dy, d, x, d, f, d, p->ln_w, eps, M, d, sc.ds, d, G(g->ln_w), G(g->ln_b), sc.red, s, dr, site0 + 1, sc.da, 0, G(g->lin2_b)));
+  DwList dws;
+  TRY(linear_bwd(h, p->lin2_w, df, M, d, 4 * d, sc.dh, nullptr, G(g->lin2_w), nullptr, dws, sc, s));  // dh = df·W2 ; lin2_w += dfᵀ·h
+  if (act == STLT_ACT_GELU) {
+    if (g->lin1_b) TRY(launch_gelu_bwd_colsum(sc.dh, u, sc.dh, M, 4 * d, G(g->lin1_b), sc.red, s, inner, site0));
+    else TRY(launch_gelu_bwd(sc.dh, u, sc.dh, M * 4 * d, s, inner, site0));
+  } else {
+    if (inner.thr) TRY(stlt_dropout(sc.dh, sc.dh, M * 4 * d, drop_p, seed, site0, stream));
+    TRY(stlt_relu_bwd(sc.dh, h, sc.dh, M * 4 * d, stream));  // h > 0 <=> pre-activation > 0 and kept
+    if (g->lin1_b) TRY(launch_colsum_acc(sc.dh, 4 * d, M, 4 * d, G(g->lin1_b), sc.red, s));
+  }
+  TRY(linear_bwd(x, p->lin1_w, sc.dh, M, 4 * d, d, dx, sc.ds, G(g->lin1_w), nullptr, dws, sc, s));  // dx = du·W1 + ds ; lin1_w += duᵀ·x
+  return flush_dw(dws, sc, s);
+}
+
+}  // extern "C"

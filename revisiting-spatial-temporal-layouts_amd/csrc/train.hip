@@ -273,14 +273,14 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   return 0;
 }
 
-static int check_train(const stlt_params* p, const stlt_inputs* in) {
+static int check_train(const stlt_params* p, const stlt_inputs* in, bool need_head = true) {
   if (!p || !in) return stlt_set_error(STLT_EINVAL, "null params/inputs");
   if (p->d <= 0 || p->H <= 0 || p->d % p->H != 0 || p->d / p->H != 64) return stlt_set_error(STLT_EINVAL, "head dim must be 64");
   if (p->n_spatial < 0 || p->n_spatial > 64 || p->n_temporal < 0 || p->n_temporal > 64) return stlt_set_error(STLT_EINVAL, "layer count out of range");
   if (in->B <= 0 || in->T <= 0 || in->N <= 0 || in->T > p->n_positions) return stlt_set_error(STLT_EINVAL, "bad batch shape");
   if (!in->categories || !in->boxes || !in->kpm_boxes || !in->frame_types || !in->kpm_frames || !in->lengths)
     return stlt_set_error(STLT_EINVAL, "null input tensor");
-  if (!p->fc1_w || !p->fc2_w || p->n_classes <= 0) return stlt_set_error(STLT_EINVAL, "prediction head missing");
+  if (need_head && (!p->fc1_w || !p->fc2_w || p->n_classes <= 0)) return stlt_set_error(STLT_EINVAL, "prediction head missing");
   return 0;
 }
 
@@ -314,7 +314,9 @@ static int read_ragged_counts(const RaggedIndex& ix, int64_t& Ms, int64_t& Mf, h
 
 int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_mem, size_t tape_bytes, float* logits,
                        float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream) {
-  TRY(check_train(p, in));
+  const bool backbone_only = (flags & STLT_FLAG_TRAIN_BACKBONE) != 0;  // `logits` is then the (B*T, d) backbone output
+  TRY(check_train(p, in, !backbone_only));
+  if (backbone_only && (flags & STLT_FLAG_SKIP_PADDING)) return stlt_set_error(STLT_EINVAL, "STLT_FLAG_TRAIN_BACKBONE excludes STLT_FLAG_SKIP_PADDING");
   if (!logits || !tape_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_forward: null logits/tape");
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
@@ -335,7 +337,7 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
     TRY(launch_padded_rows(in->lengths, B, T, N, ix, s));  // rows the tail layers pick: f*N and b*T + lengths-1
   }
   // the last layer of each tower only has to produce the rows that are read afterwards (layer_forward_tail)
-  const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = p->n_temporal > 0 && 2 * B <= BT;
+  const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = !backbone_only && p->n_temporal > 0 && 2 * B <= BT;
   float* x0 = p->n_spatial > 0 ? t.sp[0].x : t.sp_out;
   TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
                    p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, tok, d, x0, s, t.s_embed, dr, ragged ? ix.t_orig : nullptr));
@@ -350,7 +352,8 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
                         ragged ? ix.t_seg_start : nullptr, ragged ? ix.t_seg_end : nullptr));
     }
   }
-  float* g0 = p->n_temporal > 0 ? t.tp[0].x : t.tp_out;
+  float* tp_dst = backbone_only ? logits : t.tp_out;  // where the temporal tower's output rows land
+  float* g0 = p->n_temporal > 0 ? t.tp[0].x : tp_dst;
   const float* cls = t.sp_out;  // (frames, d) when the tail layer ran, else the CLS rows inside the token buffer
   int64_t cls_stride = d;
   if (!sp_tail) {
@@ -369,11 +372,12 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
       TRY(layer_forward_tail(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL,
                              ragged ? ix.f_seg_start : nullptr, ragged ? ix.f_seg_end : nullptr, ix.last_row, B, t.h0, dr, site, s));
     } else {
-      float* y = l + 1 < p->n_temporal ? t.tp[l + 1].x : t.tp_out;
+      float* y = l + 1 < p->n_temporal ? t.tp[l + 1].x : tp_dst;
       TRY(layer_forward(p->temporal[l], d, H, t.tp[l], BT, B, T, in->kpm_frames, 1, STLT_K_ATTN_TEMPORAL, y, dr, site, s,
                         ragged ? ix.f_seg_start : nullptr, ragged ? ix.f_seg_end : nullptr));
     }
   }
+  if (backbone_only) return 0;
   if (!tp_tail) TRY(launch_gather_rows(t.tp_out, d, ix.last_row, B, d, t.h0, s));                    // models.py:189-192
   TRY(launch_linear(t.h0, d, p->fc1_w, p->fc1_b, t.u0, d, B, d, d, STLT_ACT_NONE, s));
   TRY(launch_gelu_fwd(t.u0, t.z1, B * d, s));
@@ -385,7 +389,9 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
 int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_inputs* in, const void* tape_mem,
                         size_t tape_bytes, void* scratch_mem, size_t scratch_bytes, const float* dlogits,
                         float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream) {
-  TRY(check_train(p, in));
+  const bool backbone_only = (flags & STLT_FLAG_TRAIN_BACKBONE) != 0;  // `dlogits` is then the gradient of the (B*T, d) backbone output
+  TRY(check_train(p, in, !backbone_only));
+  if (backbone_only && (flags & STLT_FLAG_SKIP_PADDING)) return stlt_set_error(STLT_EINVAL, "STLT_FLAG_TRAIN_BACKBONE excludes STLT_FLAG_SKIP_PADDING");
   if (!g || !dlogits || !tape_mem || !scratch_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: null argument");
   hipStream_t s = (hipStream_t)stream;
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H, K = p->n_classes;
@@ -429,8 +435,16 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     TRY(zero_rows(sc.tQKV, 3 * d, BT, btp, s));
     TRY(zero_rows(sc.tH, 4 * d, BT, btp, s));
   }
-  const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = p->n_temporal > 0 && 2 * B <= BT;  // as the forward decided
-  if (do_upper) {
+  const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = !backbone_only && p->n_temporal > 0 && 2 * B <= BT;  // as the forward decided
+  if (do_upper && backbone_only) {
+    // the gradient of every row of the temporal tower's output arrives from the fusion layers: no head, no row gather
+    if (hipError_t e = hipMemcpyAsync(sc.tA, dlogits, (size_t)BT * d * sizeof(float), hipMemcpyDeviceToDevice, s); e != hipSuccess)
+      return stlt_set_error((int)e, "train_backward: copy: %s", hipGetErrorString(e));
+    TRY(zero_rows(sc.tA, d, BT, btp, s));
+    for (int64_t l = p->n_temporal - 1; l >= 0; --l)
+      TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
+                         sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s, nullptr));
+  } else if (do_upper) {
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
   if (g->fc2_b) TRY(launch_colsum_acc(dlogits, K, B, K, W(g->fc2_b), sc.red, s));

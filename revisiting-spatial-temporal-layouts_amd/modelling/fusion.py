@@ -116,20 +116,11 @@ class CrossAttentionFusionBackbone(nn.Module):
         return ops.LinearFn.apply(x, lin.weight, lin.bias)
 
     def _attn_block(self, blk: _AttnBlock, x, ctx, kpm, causal, p_drop):
-        """SelfAttentionLayer (ctx is x) / CrossAttentionLayer, models.py:345-382: LN(dropout(MHA(x, ctx, ctx)) + x)."""
-        H, d = self.config.num_attention_heads, x.shape[-1]
-        W, b = blk.attn.in_proj_weight, blk.attn.in_proj_bias
-        if ctx is x:
-            qkv = ops.LinearFn.apply(x, W, b)
-            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-        else:
-            q = ops.LinearFn.apply(x, W[:d], b[:d])
-            kv = ops.LinearFn.apply(ctx, W[d:], b[d:])
-            k, v = kv[..., :d], kv[..., d:]
-        a = ops.AttnFn.apply(q, k, v, kpm, causal, H, p_drop if self.training else 0.0)
-        o = ops.LinearFn.apply(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
-        o = ops.dropout(o, p_drop, self.training)
-        return ops.AddLayerNormFn.apply(o, x, blk.ln.weight, blk.ln.bias, self.config.layer_norm_eps)
+        """SelfAttentionLayer (ctx is x) / CrossAttentionLayer, models.py:345-382: LN(dropout(MHA(x, ctx, ctx)) + x) — one native
+        call each way (ops.AttnBlockFn)."""
+        return ops.AttnBlockFn.apply(x, None if ctx is x else ctx, kpm, causal, self.config.num_attention_heads, self.config.layer_norm_eps,
+                                     p_drop if self.training else 0.0, blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.attn.out_proj.weight,
+                                     blk.attn.out_proj.bias, blk.ln.weight, blk.ln.bias)
 
     def _appearance_train(self, feats):
         """TransformerResnet.forward_features from the feature map on (models.py:257-271), batch-major (B, S+1, d)."""
@@ -139,15 +130,13 @@ class CrossAttentionFusionBackbone(nn.Module):
         x = ops.LinearFn.apply(feats.flatten(2).transpose(1, 2).contiguous(), ab.projector.weight.view(d, Cc), ab.projector.bias)
         x = torch.cat((ab.cls_token.view(1, 1, d).expand(B, -1, -1), x), dim=1) + ab.pos_embed.view(1, -1, d)
         H = self.config.num_attention_heads
+        p = 0.1 if self.training else 0.0
         for l in ab.transformer.layers:  # nn.TransformerEncoderLayer defaults: ReLU, post-norm, eps 1e-5, dropout 0.1
             sa = l.self_attn
-            qkv = ops.LinearFn.apply(x, sa.in_proj_weight, sa.in_proj_bias)
-            a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], None, False, H, 0.1 if self.training else 0.0)
-            a = ops.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), 0.1, self.training)
-            x = ops.AddLayerNormFn.apply(a, x, l.norm1.weight, l.norm1.bias, 1e-5)
-            h = ops.dropout(ops.LinearFn.apply(x, l.linear1.weight, l.linear1.bias, L.ACT_RELU), 0.1, self.training)
-            h = ops.dropout(self._lin(h, l.linear2), 0.1, self.training)
-            x = ops.AddLayerNormFn.apply(h, x, l.norm2.weight, l.norm2.bias, 1e-5)
+            x = ops.AttnBlockFn.apply(x, None, None, False, H, 1e-5, p, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                                      l.norm1.weight, l.norm1.bias)
+            x = ops.FfnBlockFn.apply(x, 1e-5, L.ACT_RELU, True, p, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias,
+                                     l.norm2.weight, l.norm2.bias)
         return x
 
     def _head_train(self, h, x):
@@ -180,8 +169,9 @@ class CrossAttentionFusionBackbone(nn.Module):
             aa = self._attn_block(m.cross_attn, Ah, Lh, kpm, False, p)
             la = self._attn_block(m.layout_attn, la, la, kpm, True, p)
             aa = self._attn_block(m.appearance_attn, aa, aa, None, False, p)
-            f = self._lin(ops.GeluFn.apply(self._lin(la, m.layout_ffn.linear1)), m.layout_ffn.linear2)
-            Lh = ops.AddLayerNormFn.apply(ops.dropout(f, p, self.training), la, m.layout_ffn.ln.weight, m.layout_ffn.ln.bias, eps)
+            ff = m.layout_ffn
+            Lh = ops.FfnBlockFn.apply(la, eps, L.ACT_GELU, False, p if self.training else 0.0, ff.linear1.weight, ff.linear1.bias, ff.linear2.weight,
+                                      ff.linear2.bias, ff.ln.weight, ff.ln.bias)
             Ah = self._attn_block(m.appearance_ffn, aa, aa, None, False, p)
         fused = torch.cat((Lh[idx, last], Ah[:, 0]), dim=-1)
         caf = self._head_train(fusion_head, fused)

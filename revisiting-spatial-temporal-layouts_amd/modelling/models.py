@@ -280,23 +280,24 @@ class StltBackbone(nn.Module):
 
     # ---- differentiable forward, composed from the op-level autograd Functions of ops.py ----------------------------
     def _encoder_layer_train(self, l: _EncoderLayerParams, x: torch.Tensor, kpm, causal: bool) -> torch.Tensor:
-        """nn.TransformerEncoderLayer as configured at models.py:46-52,118-124 (post-norm, GELU, eps 1e-5); dropout with the
-        native counter-based mask at every site (post-attention / feed-forward through `ops.dropout`, the attention
-        probabilities inside the attention kernel)."""
-        p, H, d = self.config.hidden_dropout_prob, self.config.num_attention_heads, x.shape[-1]
+        """nn.TransformerEncoderLayer as configured at models.py:46-52,118-124 (post-norm, GELU, eps 1e-5) as two native
+        block calls each way (attention half, feed-forward half; ops.AttnBlockFn / ops.FfnBlockFn), dropout with the native
+        counter-based masks at the reference's four sites."""
+        p, H = self.config.hidden_dropout_prob if self.training else 0.0, self.config.num_attention_heads
         sa = l.self_attn
-        qkv = ops.LinearFn.apply(x, sa.in_proj_weight, sa.in_proj_bias)
-        a = ops.AttnFn.apply(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], kpm, causal, H, p if self.training else 0.0)
-        a = ops.dropout(ops.LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias), p, self.training)
-        x = ops.AddLayerNormFn.apply(a, x, l.norm1.weight, l.norm1.bias, _ENC_EPS)
-        h = ops.dropout(ops.GeluFn.apply(ops.LinearFn.apply(x, l.linear1.weight, l.linear1.bias)), p, self.training)
-        h = ops.dropout(ops.LinearFn.apply(h, l.linear2.weight, l.linear2.bias), p, self.training)
-        return ops.AddLayerNormFn.apply(h, x, l.norm2.weight, l.norm2.bias, _ENC_EPS)
+        x = ops.AttnBlockFn.apply(x, None, kpm, causal, H, _ENC_EPS, p, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                                  l.norm1.weight, l.norm1.bias)
+        return ops.FfnBlockFn.apply(x, _ENC_EPS, L.ACT_GELU, True, p, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias,
+                                    l.norm2.weight, l.norm2.bias)
 
     def forward_train(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """(B,T,d) backbone output with an autograd graph: what a model that consumes EVERY row of the backbone (the fusion
         models) trains through.  `Stlt` itself trains through the single native reverse sweep instead (`_StltTrainFn`).
         Layouts of at most 256 frames / 256 object slots (the op-level attention backward streams keys above 64)."""
+        if not self.skip_padding and self.config.hidden_size == 64 * self.config.num_attention_heads and "lengths" in batch:
+            # one native tape forward / reverse sweep (csrc/train.hip with STLT_FLAG_TRAIN_BACKBONE): the last spatial layer
+            # runs its out-proj / norms / FFN on the CLS rows only, weight gradients go out layer by layer in grouped launches
+            return _BackboneTrainFn.apply(self, batch, *tuple(self.parameters()))
         fe = self.frames_embeddings
         le = fe.layout_embedding
         cbe = le.category_box_embeddings
@@ -491,6 +492,73 @@ class _StltTrainFn(torch.autograd.Function):
         model._flat_layout = layout
         if getattr(model, "_flat_grads_only", False):  # train.FusedAdamW reads the flat buffer: skip the per-parameter .grad copies
             return (None, None) + tuple(None for _ in ctx.params)
+        return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)
+
+
+class _BackboneTrainFn(torch.autograd.Function):
+    """The backbone alone under autograd, for models that consume EVERY row of its output (the fusion models' layout branch,
+    models.py:446-483): the same native tape forward / reverse sweep as `_StltTrainFn` with STLT_FLAG_TRAIN_BACKBONE — no
+    prediction head, every temporal layer on every frame, the (B,T,d) output's gradient as the sweep's seed."""
+
+    @staticmethod
+    def forward(ctx, bb, batch, *params):
+        lib = L.load()
+        inp, keep, (B, T, N) = _prep_inputs(batch, need_lengths=True)
+        device = batch["categories"].device
+        p, _, _ = bb.c_params(None)
+        cfg = bb.config
+        d = cfg.hidden_size
+        tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, p.n_spatial, p.n_temporal)), device)
+        bb._tape_gen = ctx.tape_gen = getattr(bb, "_tape_gen", 0) + 1
+        out = torch.empty(B, T, d, device=device, dtype=torch.float32)
+        drop_p = float(cfg.hidden_dropout_prob) if bb.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0
+        with torch.cuda.device(device):
+            L.check(lib.stlt_train_forward(C.byref(p), C.byref(inp), tape.data_ptr(), tape.numel(), out.data_ptr(), drop_p, seed,
+                                           L.FLAG_TRAIN_BACKBONE, torch.cuda.current_stream().cuda_stream), "stlt_train_forward")
+        ctx.bb, ctx.batch, ctx.shape, ctx.params, ctx.drop = bb, batch, (B, T, N, d), params, (drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        bb, batch = ctx.bb, ctx.batch
+        B, T, N, d = ctx.shape
+        device = dout.device
+        if getattr(bb, "_tape_gen", 0) != ctx.tape_gen:
+            raise L.StltHipError("StltBackbone backward: the activation tape was overwritten by a later grad-enabled forward of the same "
+                                 "backbone (one tape per backbone): run each forward's backward before the next forward")
+        inp, keep, _ = _prep_inputs(batch, need_lengths=True)
+        p, _, _ = bb.c_params(None)
+        le = bb.frames_embeddings.layout_embedding
+        skip = {id(q) for q in le.encoder_layer.parameters()}
+        if "scores" not in batch:
+            skip |= {id(q) for q in le.category_box_embeddings.score_embeddings.parameters()}
+        want = [prm for prm in ctx.params if prm.requires_grad and id(prm) not in skip]
+        # parameters whose .grad is bound to a trainer's flat buffer are accumulated into in place (no temporary, autograd gets
+        # None for them); the others get views of a fresh zero buffer that autograd accumulates
+        direct = {}
+        for q in want:
+            bound = getattr(q, "_stlt_bound", None)
+            if bound is not None and q.grad is not None and bound.owns(q):
+                bound.touch(q)
+                direct[id(q)] = q.grad
+        layout, off = [], 0
+        for q in want:
+            if id(q) not in direct:
+                layout.append((q, off, q.numel()))
+                off += (q.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, device=device, dtype=torch.float32) if off else None
+        views = {id(q): flat[o: o + n].view_as(q) for q, o, n in layout}
+        target = lambda t: direct[id(t)].data_ptr() if id(t) in direct else (views[id(t)].data_ptr() if id(t) in views else None)  # noqa: E731
+        g, gsp, gtp = bb._build_struct(None, target)
+        tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, p.n_spatial, p.n_temporal)), device)
+        scratch = bb._train_buf("scratch", int(lib.stlt_train_scratch_bytes(B, T, N, d, p.n_categories)), device)
+        dl = dout.contiguous().float()
+        with torch.cuda.device(device):
+            L.check(lib.stlt_train_backward(C.byref(p), C.byref(g), C.byref(inp), tape.data_ptr(), tape.numel(), scratch.data_ptr(), scratch.numel(),
+                                            dl.data_ptr(), ctx.drop[0], ctx.drop[1], L.FLAG_TRAIN_BACKBONE, torch.cuda.current_stream().cuda_stream),
+                    "stlt_train_backward")
         return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)
 
 

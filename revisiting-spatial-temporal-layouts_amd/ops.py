@@ -440,6 +440,138 @@ class GeluFn(torch.autograd.Function):
         return du
 
 
+_BLOCK_SITE = [0x400000]
+_SK_SCRATCH = {}
+
+
+def _sk_scratch(device) -> torch.Tensor:
+    """Per-device stream-K scratch lent to the block-level forward calls (kept for the life of the process: kernels enqueued
+    on the device's streams may still be reading it)."""
+    buf = _SK_SCRATCH.get(device)
+    if buf is None:
+        _SK_SCRATCH[device] = buf = torch.empty(int(L.load().stlt_gemm_scratch_bytes()), dtype=torch.uint8, device=device)
+    return buf
+
+
+
+def _block_dropout(p: float):
+    """(p, seed, site0) of a block call: one seed per call from torch's CPU generator, two consecutive site ids."""
+    p = float(p)
+    if p <= 0.0:
+        return 0.0, 0, 0
+    _BLOCK_SITE[0] = 0x400000 | ((_BLOCK_SITE[0] + 2) & 0xfffff)
+    return p, int(torch.randint(0, 2 ** 62, (1,)).item()), _BLOCK_SITE[0]
+
+
+def grad_targets(ws, needs):
+    """Where a block's backward accumulates its parameter gradients.  A parameter whose .grad is a view of a trainer's flat
+    gradient buffer (train.BoundFlatGrads) is accumulated into IN PLACE by the native call (and autograd is handed None for it):
+    no zero-filled temporary, no AccumulateGrad add.  Any other parameter gets a fresh zero tensor that autograd accumulates."""
+    targets, returned = [], []
+    for w, need in zip(ws, needs):
+        bound = getattr(w, "_stlt_bound", None)
+        if not need:
+            targets.append(None); returned.append(None)
+        elif bound is not None and w.grad is not None and bound.owns(w):
+            bound.touch(w)
+            targets.append(w.grad); returned.append(None)
+        else:
+            g = torch.zeros_like(w)
+            targets.append(g); returned.append(g)
+    return targets, returned
+
+
+class AttnBlockFn(torch.autograd.Function):
+    """One residual attention block as ONE native call each way (include/stlt_hip.h: stlt_attn_block_fwd_train / _bwd_train):
+    LN_eps(x + drop(MHA(x, c, c) Woᵀ + bo)) — SelfAttentionLayer / CrossAttentionLayer of the fusion models (models.py:345-382)
+    and the attention half of nn.TransformerEncoderLayer.  x (S,Lq,d); c (S,Lk,d) or None (self-attention); kpm (S,Lk) or None."""
+
+    @staticmethod
+    def forward(ctx, x, c, kpm, causal, heads, eps, drop_p, in_w, in_b, out_w, out_b, ln_w, ln_b):
+        lib = L.load()
+        x = _chk(x.contiguous(), torch.float32, "x")
+        S, Lq, d = x.shape
+        if c is not None:
+            c = _chk(c.contiguous(), torch.float32, "c")
+        Lk = Lq if c is None else c.shape[1]
+        kpm8 = torch.zeros(S, Lk, dtype=torch.uint8, device=x.device) if kpm is None else _mask_u8(kpm.contiguous(), "kpm")
+        q = torch.empty(S * Lq, (3 if c is None else 1) * d, device=x.device, dtype=torch.float32)
+        kv = None if c is None else torch.empty(S * Lk, 2 * d, device=x.device, dtype=torch.float32)
+        att, a, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        params = L.AttnBlockParams(*[_p(t) for t in (in_w, in_b, out_w, out_b, ln_w, ln_b)])
+        p, seed, site = _block_dropout(drop_p)
+        sk = _sk_scratch(x.device)
+        L.check(lib.stlt_attn_block_fwd_train(C.byref(params), d, heads, float(eps), _p(x), Lq, _p(c), Lk, _p(kpm8), int(bool(causal)), S, p, seed, site,
+                                              _p(q), _p(kv), _p(att), _p(a), _p(out), sk.data_ptr(), sk.numel(), _stream()), "stlt_attn_block_fwd_train")
+        ctx.save_for_backward(x, c, kpm8, q, kv, att, a)
+        ctx.ws = (in_w, in_b, out_w, out_b, ln_w, ln_b)
+        ctx.meta = (bool(causal), heads, float(eps), p, seed, site)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, c, kpm8, q, kv, att, a = ctx.saved_tensors
+        causal, heads, eps, p, seed, site = ctx.meta
+        S, Lq, d = x.shape
+        Lk = Lq if c is None else c.shape[1]
+        dy = dy.contiguous()
+        ws = ctx.ws
+        targets, grads = grad_targets(ws, ctx.needs_input_grad[7:13])
+        dx = torch.empty_like(x)
+        dc = torch.empty_like(c) if (c is not None and ctx.needs_input_grad[1]) else None
+        params = L.AttnBlockParams(*[_p(t) for t in ws])
+        gstruct = L.AttnBlockParams(*[_p(t) for t in targets])
+        sc = _scratch(int(lib.stlt_block_scratch_bytes(S * max(Lq, Lk), d)), x.device)
+        L.check(lib.stlt_attn_block_bwd_train(C.byref(params), C.byref(gstruct), d, heads, eps, _p(x), Lq, _p(c), Lk, _p(kpm8), int(causal), S, p, seed,
+                                              site, _p(q), _p(kv), _p(att), _p(a), _p(dy), _p(dx), _p(dc), sc.data_ptr(), sc.numel(), _stream()),
+                "stlt_attn_block_bwd_train")
+        return (dx, dc, None, None, None, None, None, *grads)
+
+
+class FfnBlockFn(torch.autograd.Function):
+    """One residual feed-forward block as ONE native call each way: LN_eps(x + drop(W2 drop_inner(act(W1 x + b1)) + b2)) — the
+    fusion models' layout_ffn (models.py:384-401; GELU, no inner dropout) and the feed-forward half of nn.TransformerEncoderLayer
+    (GELU in the layout towers, ReLU in the appearance encoder; inner dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, act, inner_dropout, drop_p, w1, b1, w2, b2, ln_w, ln_b):
+        lib = L.load()
+        x = _chk(x.contiguous(), torch.float32, "x")
+        d = x.shape[-1]
+        M = x.numel() // d
+        u = torch.empty(M, 4 * d, device=x.device, dtype=torch.float32) if act == L.ACT_GELU else None
+        h = torch.empty(M, 4 * d, device=x.device, dtype=torch.float32)
+        f, out = torch.empty_like(x), torch.empty_like(x)
+        params = L.FfnBlockParams(*[_p(t) for t in (w1, b1, w2, b2, ln_w, ln_b)])
+        p, seed, site = _block_dropout(drop_p)
+        sk = _sk_scratch(x.device)
+        L.check(lib.stlt_ffn_block_fwd_train(C.byref(params), d, float(eps), int(act), int(bool(inner_dropout)), _p(x), M, p, seed, site, _p(u), _p(h),
+                                             _p(f), _p(out), sk.data_ptr(), sk.numel(), _stream()), "stlt_ffn_block_fwd_train")
+        ctx.save_for_backward(x, u, h, f)
+        ctx.ws = (w1, b1, w2, b2, ln_w, ln_b)
+        ctx.meta = (float(eps), int(act), bool(inner_dropout), p, seed, site)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, u, h, f = ctx.saved_tensors
+        eps, act, inner, p, seed, site = ctx.meta
+        d = x.shape[-1]
+        M = x.numel() // d
+        dy = dy.contiguous()
+        ws = ctx.ws
+        targets, grads = grad_targets(ws, ctx.needs_input_grad[5:11])
+        dx = torch.empty_like(x)
+        params = L.FfnBlockParams(*[_p(t) for t in ws])
+        gstruct = L.FfnBlockParams(*[_p(t) for t in targets])
+        sc = _scratch(int(lib.stlt_block_scratch_bytes(M, d)), x.device)
+        L.check(lib.stlt_ffn_block_bwd_train(C.byref(params), C.byref(gstruct), d, eps, act, int(inner), _p(x), M, p, seed, site, _p(u), _p(h), _p(f),
+                                             _p(dy), _p(dx), sc.data_ptr(), sc.numel(), _stream()), "stlt_ffn_block_bwd_train")
+        return (dx, None, None, None, None, *grads)
+
+
 class EmbedFn(torch.autograd.Function):
     """K1 (CategoryBoxEmbeddings, models.py:29-39) under autograd: native forward keeping the pre-LayerNorm sum, native backward."""
 

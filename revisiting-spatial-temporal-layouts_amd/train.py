@@ -191,16 +191,65 @@ class FusedAdamW(torch.optim.Optimizer):
         self._group_step = {}
 
 
+class BoundFlatGrads:
+    """Every trainable parameter's .grad as a view of ONE flat buffer (16-byte aligned slots), for models whose backward is
+    composed of autograd Functions (the fusion models): autograd accumulates into the views in place, a step clears the buffer
+    with one memset, the data-parallel all-reduce and the fused clip + AdamW (FusedAdamW.step_flat) read it directly.
+    Parameters that received no gradient in a step are left out of that step's layout — torch.optim.AdamW skips
+    `p.grad is None` the same way (the dead `encoder_layer` copy, unused `score_embeddings`, frozen weights)."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.layout_all, off = [], 0
+        for p in self.params:
+            self.layout_all.append((p, off, p.numel()))
+            off += (p.numel() + 3) // 4 * 4
+        dev = self.params[0].device
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self._touched = set()
+        self._slot = {}
+        for p, o, n in self.layout_all:
+            p.grad = self.flat[o: o + n].view_as(p)
+            p.register_post_accumulate_grad_hook(lambda q, s=self._touched: s.add(id(q)))
+            p._stlt_bound = self  # the native block backwards accumulate straight into the view (ops.grad_targets)
+            self._slot[id(p)] = o
+        self._layout_cache = (None, None)
+
+    def owns(self, p) -> bool:
+        o = self._slot.get(id(p))
+        return o is not None and p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + 4 * o
+
+    def touch(self, p):
+        self._touched.add(id(p))
+
+    def zero(self):
+        for p, o, n in self.layout_all:  # a caller (or zero_grad(set_to_none=True)) may have dropped a view: bind it again
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                p.grad = self.flat[o: o + n].view_as(p)
+        self.flat.zero_()
+        self._touched.clear()
+
+    def layout(self):
+        key = frozenset(self._touched)
+        if self._layout_cache[0] != key:
+            self._layout_cache = (key, [(p, o, n) for p, o, n in self.layout_all if id(p) in key])
+        return self._layout_cache[1]
+
+
 class Trainer:
     def __init__(self, model, dataset_name: str = "something", learning_rate: float = 5e-5, weight_decay: float = 1e-3,
                  clip_val: float = 5.0, warmup_steps: int = 0, total_steps: int = 1, rank: int = 0, world: int = 1,
                  fused_optimizer: Optional[bool] = None):
         self.model, self.dataset_name, self.clip_val = model, dataset_name, clip_val
         self.rank, self.world = rank, world
-        if fused_optimizer is None:  # the fused path needs the native model's flat gradient buffer on a GPU
-            first = next(iter(model.parameters()), None)
-            fused_optimizer = hasattr(model, "_grad_params") and first is not None and first.is_cuda
+        first = next(iter(model.parameters()), None)
+        on_gpu = first is not None and first.is_cuda
+        if fused_optimizer is None:  # the fused path reads a flat gradient buffer on a GPU
+            fused_optimizer = on_gpu
         self.fused = fused_optimizer
+        # Stlt fills its own flat buffer in the native reverse sweep; any other model (the fusion models) gets its .grad
+        # tensors bound to one
+        self.bound = BoundFlatGrads(model) if (fused_optimizer and not hasattr(model, "_grad_params")) else None
         opt = FusedAdamW if fused_optimizer else torch.optim.AdamW  # same defaults (betas 0.9/0.999, eps 1e-8)
         self.optimizer = opt(add_weight_decay(model, weight_decay), lr=learning_rate)
         self.scheduler = linear_schedule_with_warmup(self.optimizer, warmup_steps, total_steps)
@@ -222,6 +271,8 @@ class Trainer:
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
         """One optimisation step on this rank's shard of the global batch (train.py:119-135)."""
         self.model.train(True)
+        if self.bound is not None:
+            return self._step_bound(batch)
         self.optimizer.zero_grad()
         self.model._flat_grads_only = self.fused
         self.model._grad_sync = self._sync_slice if (self.fused and self.world > 1) else None
@@ -253,6 +304,26 @@ class Trainer:
         # ordinary per-parameter .grad tensors again
         self.model._flat_grads_only = False
         self.model._grad_sync = None
+        return {"loss": loss.detach(), "grad_norm": grad_norm.detach()}
+
+    def _step_bound(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
+        """The same step for a model whose gradients arrive through autograd (CAF / CACNF / LCF): .grad views of one flat
+        buffer, native criterion per logit head, in-place all-reduce, fused clip + AdamW."""
+        self.bound.zero()
+        logits = self.model(batch)
+        heads = list(logits.values())
+        loss, grads = 0.0, []
+        for v in heads:
+            l, g = fused_criterion(v, batch["labels"], self.dataset_name, 1.0 / len(heads))
+            loss = loss + l
+            grads.append(g)
+        torch.autograd.backward(heads, grads)
+        flat = self.bound.flat
+        if self.world > 1:
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+            flat.div_(self.world)
+        grad_norm = self.optimizer.step_flat(flat, self.bound.layout(), self.clip_val)
+        self.scheduler.step()
         return {"loss": loss.detach(), "grad_norm": grad_norm.detach()}
 
     def fit(self, batches: Iterable[Dict[str, torch.Tensor]], device) -> List[Dict[str, float]]:

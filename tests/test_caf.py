@@ -239,3 +239,45 @@ def test_fusion_training_with_long_layouts_runs_through_the_streamed_attention_b
         assert (prm.grad.cpu() - g_ref).abs().max().item() / g_ref.abs().max().item() <= 1e-3, k
         checked += 1
     assert checked > 150
+
+
+@pytest.mark.gpu
+def test_trainer_on_a_fusion_model_matches_the_stock_loop(pkg):
+    """train.Trainer on CACNF (gradients bound to one flat buffer, native block backwards accumulating into it in place, native
+    criterion, fused clip + AdamW) against the reference's loop written with stock torch ops (zero_grad, F.cross_entropy per
+    head, clip_grad_norm_, torch.optim.AdamW) on a twin model: same losses, same gradient norm, same parameters after 3 steps."""
+    kw = dict(pkg.synth.model_kwargs(NAME), **EXTRA)
+    kw["hidden_dropout_prob"] = 0.0
+    c = pkg.synth.CONFIGS[NAME]
+    batch = pkg.synth.make_batch(6, c["T"], c["N"], seed=21)
+    batch["appearance_features"] = pkg.synth.make_appearance_features(6, seed=22)
+    batch = {k: v.to("cuda") for k, v in batch.items()}
+    labels = torch.randint(0, c["num_classes"], (6,), generator=torch.Generator().manual_seed(5)).cuda()
+    batch["labels"] = labels
+    twins = []
+    for _ in range(2):
+        m = pkg.CrossAttentionCentralNetFusion(pkg.MultimodalModelConfig(**kw))
+        m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=7))
+        m.train(False).to("cuda")  # eval-mode arithmetic (the appearance encoder's fixed 0.1 dropout included: the two loops would
+        twins.append(m)            # draw different masks); gradients still flow, grad is enabled
+    ours, ref = twins
+    tr = pkg.train.Trainer(ours, "something", learning_rate=1e-3, weight_decay=1e-3, clip_val=5.0, warmup_steps=0, total_steps=1000)
+    tr_train = ours.train
+    ours.train = lambda mode=True: ours  # Trainer.step() switches to train mode: keep this twin in eval mode
+    opt = torch.optim.AdamW(pkg.train.add_weight_decay(ref, 1e-3), lr=1e-3)
+    sched = pkg.train.linear_schedule_with_warmup(opt, 0, 1000)
+    for step in range(3):
+        res = tr.step(batch)
+        opt.zero_grad(set_to_none=True)
+        out = ref(batch)
+        loss = sum(torch.nn.functional.cross_entropy(v, labels) for v in out.values()) / len(out)
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 5.0)
+        opt.step(); sched.step()
+        assert abs(res["loss"].item() - loss.item()) <= 2e-5, (step, res["loss"].item(), loss.item())
+        assert abs(res["grad_norm"].item() - norm.item()) <= 2e-4 * max(1.0, norm.item()), (step, res["grad_norm"].item(), norm.item())
+    ours.train = tr_train
+    worst = max((a - b).abs().max().item() for a, b in zip(ours.parameters(), ref.parameters()))
+    assert worst <= 5e-5, worst
+    untouched = [n for (n, a), b in zip(ours.named_parameters(), ref.parameters()) if b.grad is None]
+    assert untouched and all("encoder_layer" in n or "score_embeddings" in n or "classifier" in n for n in untouched), untouched

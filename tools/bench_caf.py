@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--model", default="cacnf", choices=["caf", "cacnf"])
     ap.add_argument("--skip-padding", action="store_true", help="layout branch on the real tokens / frames only (inference)")
     ap.add_argument("--train", action="store_true", help="time an optimisation step instead of the inference call")
+    ap.add_argument("--stock-loop", action="store_true", help="--train: zero_grad / F.cross_entropy / clip_grad_norm_ / torch.optim.AdamW instead of train.Trainer")
     ap.add_argument("--dropout", type=float, default=0.1, help="--train: hidden_dropout_prob (reference default 0.1)")
     args = ap.parse_args()
     import torch
@@ -44,18 +45,27 @@ def main():
                 mod.skip_padding = True
     if args.train:
         labels = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(rank)).to(dev)
-        opt = torch.optim.AdamW(pkg.train.add_weight_decay(m, 1e-3), lr=5e-5)
+        batch["labels"] = labels
+        if args.stock_loop:  # the reference's loop with stock torch ops: zero_grad, CE per head, backward, clip, AdamW
+            opt = torch.optim.AdamW(pkg.train.add_weight_decay(m, 1e-3), lr=5e-5)
 
-        def step():
-            opt.zero_grad(set_to_none=True)
-            out = m(batch)
-            loss = sum(torch.nn.functional.cross_entropy(v, labels) for v in out.values()) / len(out)
-            loss.backward()
-            if world > 1:
-                pkg.train.allreduce_gradients(m, world)
-            torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
-            opt.step()
-            return out
+            def step():
+                opt.zero_grad(set_to_none=True)
+                out = m(batch)
+                loss = sum(torch.nn.functional.cross_entropy(v, labels) for v in out.values()) / len(out)
+                loss.backward()
+                if world > 1:
+                    pkg.train.allreduce_gradients(m, world)
+                torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+                opt.step()
+                return out
+        else:  # train.Trainer: gradients bound to one flat buffer, native criterion, fused clip + AdamW
+            tr = pkg.train.Trainer(m, "something", learning_rate=5e-5, weight_decay=1e-3, clip_val=5.0, warmup_steps=0, total_steps=100000,
+                                   rank=rank, world=world)
+
+            def step():
+                res = tr.step(batch)
+                return {"loss": res["loss"].reshape(1)}
     else:
         def step():
             with torch.no_grad():  # with grad enabled the module takes its autograd path
