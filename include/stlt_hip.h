@@ -302,6 +302,14 @@ typedef struct {
 size_t stlt_linear_bwd_scratch_bytes(int64_t N);
 int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, float* dw, float* db,
                     void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+/* Backward of K3 on the packed projection (what the training sweep runs per layer): dqkv (S*L, 3*H*64) from qkv and dctx, with
+ * the masks of stlt_attn_core_fwd, optional dropout of the probabilities (site as in stlt_train_forward) and, when in_proj_b_grad
+ * is not NULL, in_proj_b_grad (3*H*64) += column sums of dqkv.  L <= 64: v_mfma_f32_16x16x4_f32 tiles (one wave per sequence and
+ * head); up to 256: plain FMA, keys streamed through LDS.  scratch: stlt_attn_core_bwd_scratch_bytes(H) bytes. */
+size_t stlt_attn_core_bwd_scratch_bytes(int64_t H);
+int stlt_attn_core_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
+                       float dropout_p, uint64_t seed, uint32_t site, float* dqkv, float* in_proj_b_grad, void* scratch, size_t scratch_bytes,
+                       stlt_stream_t stream);
 /* attention with train-mode dropout of the probabilities (nn.MultiheadAttention(dropout=p)): counter-based mask from
  * (seed, site, query row, head, key position); stlt_attn_bwd given the same (p, seed, site) recomputes it.  p = 0: none. */
 int stlt_attn_fwd_dropout(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm, int causal,

@@ -122,6 +122,9 @@ SIGNATURES = {
                                         C.c_float, C.c_uint64, C.c_uint32, _vp, _vp]),
     "stlt_attn_bwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_float, C.c_uint64, C.c_uint32, _vp, C.c_int64, _vp, _vp, C.c_int64, _vp]),
+    "stlt_attn_core_bwd_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "stlt_attn_core_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp, _vp, _vp,
+                                     C.c_size_t, _vp]),
     "stlt_add_layernorm_bwd_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "stlt_add_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "stlt_embed_fwd_train": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_int64, C.c_int64, _vp, _vp, _vp]),

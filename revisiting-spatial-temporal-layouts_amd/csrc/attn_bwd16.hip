@@ -1,17 +1,18 @@
-// Attention core backward on v_mfma_f32_16x16x4_f32 for the groups the training step is made of: sequences of at most 32
-// tokens on the packed QKV buffer (cfg2: T = 32 frames per clip, N = 7 objects per frame), with the key-padding /
-// causal masks, the dropout on the attention probabilities and the in-projection bias gradient of backward.hip's
-// attn_bwd_kernel, which stays the kernel of the ragged (skip-padding) layout and of 33-64-token sequences.
+// Attention core backward on v_mfma_f32_16x16x4_f32 for the groups the training step is made of: sequences of at most 64
+// tokens on the packed QKV buffer (cfg2: T = 32 frames per clip, N = 7 objects per frame; cfg4: T = 64, N = 36; the fusion
+// models' 33 appearance tokens), with the key-padding / causal masks, the dropout on the attention probabilities and the
+// in-projection bias gradient of backward.hip's attn_bwd_kernel, which stays the kernel of the ragged (skip-padding) layout.
 //   P = softmax(scale·Q·Kᵀ + mask), Pd = P∘D (dropout), O = Pd·V
 //   dV = Pdᵀ·dO ; dPd = dO·Vᵀ ; dP = dPd∘D ; dS = P∘(dP − rowsum(P∘dP)) ; dQ = scale·dS·K ; dK = scale·dSᵀ·Q
-// One wave per (item, head); an item is two 16-row blocks:
-//   FULL (16 < L <= 32): one sequence, every (query block, key block) pair — the lower triangle when causal;
-//   DIAG (L <= 16): floor(16/L) whole sequences per block, diagonal pairs only (2 frames per block at N = 7).
-// Q, K, V, dO tiles (32 x 64 each) arrive by LDS-DMA in the swizzled layout of attn16.hip.  Scores and dPd are computed
+// One wave per (item, head); an item is NB 16-row blocks:
+//   FULL (16 < L <= 16 NB, NB = 2 / 3 / 4): one sequence, every (query block, key block) pair — the lower triangle when causal;
+//   DIAG (L <= 16, NB = 2): floor(16/L) whole sequences per block, diagonal pairs only (2 frames per block at N = 7).
+// Q, K, V, dO tiles (16 NB x 64 each) arrive by LDS-DMA in the swizzled layout of attn16.hip; 4 / 3 / 2 waves per workgroup at
+// NB = 2 / 3 / 4 (32 / 48 / 64 KB of LDS per wave), one workgroup per CU.  Scores and dPd are computed
 // transposed — Sᵀ = K·Qᵀ, dPdᵀ = V·dOᵀ — so that a query's row sits in 4 lanes x 4 registers per key block: the softmax
 // and the rowsum are in-register + two shuffles, and dSᵀ is already the B operand of dQᵀ = Kᵀ·dSᵀ.  dK and dV contract
-// over the queries and want dS / Pd with the keys in the lane index instead: both go through a 32 x 32 LDS transpose (in
-// the V tile's space, which is dead by then).  Outputs leave as 16-byte stores (a lane holds 4 consecutive channels).
+// over the queries and want dS / Pd with the keys in the lane index instead: both go through an LDS transpose (dS in the V
+// tile's space, Pd in the K tile's: both are dead by then).  Outputs leave as 16-byte stores (a lane holds 4 consecutive channels).
 // A wave keeps one head for its whole life (wave w: head w % H, items w / H, w / H + chunks, ...), so the column sums of
 // dQ / dK / dV (the in-projection bias gradient) accumulate in registers per lane and are reduced once at the end into
 // slab w / H of the scratch buffer, which launch_reduce_slabs adds in fixed order: bitwise reproducible.
@@ -21,9 +22,7 @@
 namespace {
 
 constexpr int BD = 64;      // head dim
-constexpr int BROWS = 32;   // rows of an item
-constexpr int BWAVES = 4;   // independent waves per workgroup (32.1 KB of LDS each)
-constexpr int TILE = BROWS * BD;
+constexpr int waves_for(int nb) { return nb == 2 ? 4 : nb == 3 ? 3 : 2; }  // independent waves per workgroup (16 NB KB of LDS each)
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
@@ -42,8 +41,9 @@ struct BwdGeo {
   uint32_t site;
 };
 
-template <bool FULL, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo geo) {
+template <int NB, bool FULL, bool CAUSAL, bool DROP>
+__global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const BwdGeo geo) {
+  constexpr int BROWS = 16 * NB, TILE = BROWS * BD, BWAVES = waves_for(NB);
   __shared__ __attribute__((aligned(16))) float smem_all[BWAVES * (4 * TILE + BROWS)];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* Qs = smem_all + wave * (4 * TILE + BROWS);
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
   float* Vs = Ks + TILE;
   float* Gs = Vs + TILE;
   int* kmeta = reinterpret_cast<int*>(Gs + TILE);
-  float* Tds = Vs;             // dS[key][query], 32 x 32, once the V tile is dead
-  float* Tpd = Vs + 32 * 32;   // Pd[key][query]
+  float* Tds = Vs;             // dS[key][query], BROWS x BROWS, once the V tile is dead
+  float* Tpd = Ks;             // Pd[key][query], once the K tile is dead (after the last dQ)
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int H = geo.H, L = geo.L, d = H * BD;
@@ -109,9 +109,9 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // wave-local: tiles and key metadata are in LDS
 
-    f32x4 ds[2][2], pd[2][2];  // dSᵀ and Pdᵀ of (query block, key block): lane = query li, register r = key 4*lg + r
+    f32x4 ds[NB][NB], pd[NB][NB];  // dSᵀ and Pdᵀ of (query block, key block): lane = query li, register r = key 4*lg + r
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NB; ++qb) {
       // ---- Sᵀ = K·Qᵀ and dPdᵀ = V·dOᵀ for this query block
       const int qrow = qb * 16 + li;
       f32x4 qf[4], gf[4];
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
         qf[c] = *reinterpret_cast<const f32x4*>(Qs + swz(qrow, 4 * c + lg));
         gf[c] = *reinterpret_cast<const f32x4*>(Gs + swz(qrow, 4 * c + lg));
       }
-      f32x4 st[2], dp[2];
+      f32x4 st[NB], dp[NB];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < NB; ++kb) {
         st[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         dp[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!used(kb, qb)) continue;
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
       const int qtok = row_token(t0, qb, li);
       const int mq = qtok >= 0 ? row_meta(qb) : -1;
       const int q_seq = mq >> 8, q_pos = mq & 0xff;
-      int kpos[2][4];
+      int kpos[NB][4];
       float m = -1e30f;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < NB; ++kb) {
         if (!used(kb, qb)) continue;
         const int4 km = *reinterpret_cast<const int4*>(kmeta + kb * 16 + 4 * lg);
         const int kmv[4] = {km.x, km.y, km.z, km.w};
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
       m = fmaxf(m, __shfl_xor(m, 32, 64));
       float sum = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < NB; ++kb) {
         if (!used(kb, qb)) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
       float dsum = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < NB; ++kb) {
         pd[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!used(kb, qb)) continue;
 #pragma unroll
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
       dsum += __shfl_xor(dsum, 16, 64);
       dsum += __shfl_xor(dsum, 32, 64);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < NB; ++kb) {
         ds[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!used(kb, qb)) continue;
 #pragma unroll
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) o[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < NB; ++kb) {
         if (!used(kb, qb)) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -239,29 +239,29 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
     // ---- transposes: dS and Pd with the key in the row, 4 consecutive queries per 16-byte read (V tile is dead)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < NB; ++qb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kb * 16 + 4 * lg + r;
-          Tds[key * 32 + qb * 16 + li] = ds[qb][kb][r];
-          Tpd[key * 32 + qb * 16 + li] = pd[qb][kb][r];
+          Tds[key * BROWS + qb * 16 + li] = ds[qb][kb][r];
+          Tpd[key * BROWS + qb * 16 + li] = pd[qb][kb][r];
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // ---- dKᵀ[channel][key] = scale·Qᵀ·dS and dVᵀ[channel][key] = dOᵀ·Pd: MFMA step (qb, r) sums queries qb*16 + 4g + r
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NB; ++kb) {
       const int ktok = row_token(t0, kb, li);
       f32x4 ok_[4], ov[4];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) { ok_[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < NB; ++qb) {
         if (!used(kb, qb)) continue;
-        const f32x4 bs = *reinterpret_cast<const f32x4*>(Tds + (kb * 16 + li) * 32 + qb * 16 + 4 * lg);
-        const f32x4 bp = *reinterpret_cast<const f32x4*>(Tpd + (kb * 16 + li) * 32 + qb * 16 + 4 * lg);
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(Tds + (kb * 16 + li) * BROWS + qb * 16 + 4 * lg);
+        const f32x4 bp = *reinterpret_cast<const f32x4*>(Tpd + (kb * 16 + li) * BROWS + qb * 16 + 4 * lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = qb * 16 + 4 * lg + r;
@@ -308,10 +308,11 @@ __global__ __launch_bounds__(64 * BWAVES) void attn_bwd16_kernel(const BwdGeo ge
   }
 }
 
-template <bool FULL, bool CAUSAL>
+template <int NB, bool FULL, bool CAUSAL>
 int launch_bwd16(const BwdGeo& g, int n_wg, hipStream_t s) {
-  if (g.dr.thr) hipLaunchKernelGGL((attn_bwd16_kernel<FULL, CAUSAL, true>), dim3((unsigned)n_wg), dim3(64 * BWAVES), 0, s, g);
-  else hipLaunchKernelGGL((attn_bwd16_kernel<FULL, CAUSAL, false>), dim3((unsigned)n_wg), dim3(64 * BWAVES), 0, s, g);
+  constexpr int BWAVES = waves_for(NB);
+  if (g.dr.thr) hipLaunchKernelGGL((attn_bwd16_kernel<NB, FULL, CAUSAL, true>), dim3((unsigned)n_wg), dim3(64 * BWAVES), 0, s, g);
+  else hipLaunchKernelGGL((attn_bwd16_kernel<NB, FULL, CAUSAL, false>), dim3((unsigned)n_wg), dim3(64 * BWAVES), 0, s, g);
   return stlt_check_launch("attn_bwd16_kernel");
 }
 
@@ -322,11 +323,13 @@ int launch_bwd16(const BwdGeo& g, int n_wg, hipStream_t s) {
 int launch_attn_bwd16(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* dqkv,
                       StltDrop dr, uint32_t site, float* scratch, int want_colsum, int* chunks_out, hipStream_t s, bool* taken) {
   *taken = false;
-  static const int enabled = [] { const char* e = getenv("STLT_ATTN_BWD16"); return e ? atoi(e) : 1; }();
-  if (!enabled || L < 1 || L > 32) return 0;
+  static const int enabled = [] { const char* e = getenv("STLT_ATTN_BWD16"); return e ? atoi(e) : 1; }();  // 0: off; 2: sequences of at most 32 tokens only (round-2 coverage, A/B runs)
+  if (!enabled || L < 1 || L > 64 || (enabled == 2 && L > 32)) return 0;
   if (L <= 16 && causal) return 0;  // short causal sequences are not a shape of the path
   const int64_t n_tokens = S * L;
   if (n_tokens > 0x7fffffffLL || H > 4096) return 0;
+  const int nb = L <= 32 ? 2 : L <= 48 ? 3 : 4;  // 16-row blocks of an item
+  const int bwaves = waves_for(nb);
   BwdGeo g;
   g.qkv = qkv; g.dctx = dctx; g.kpm = kpm; g.dqkv = dqkv;
   g.n_tokens = (int)n_tokens; g.L = (int)L; g.H = (int)H;
@@ -337,18 +340,20 @@ int launch_attn_bwd16(const float* qkv, const float* dctx, const uint8_t* kpm, i
   const int64_t items = (n_tokens + g.rows_per_item - 1) / g.rows_per_item;
   if (items > 0x7fffffffLL) return 0;
   g.n_items = (int)items;
-  // one workgroup (4 waves, 128.5 KB of LDS) per CU; waves = chunks x heads, at most 256 chunks (the slab scratch)
-  int64_t chunks = ((int64_t)stlt_device_cus() * BWAVES) / H;
+  // one workgroup (4 / 3 / 2 waves, 128-148 KB of LDS) per CU; waves = chunks x heads, at most 256 chunks (the slab scratch)
+  int64_t chunks = ((int64_t)stlt_device_cus() * bwaves) / H;
   if (chunks < 1) chunks = 1;
   if (chunks > items) chunks = items;
   if (chunks > 256) chunks = 256;
   g.chunks = (int)chunks;
   g.cs = want_colsum ? scratch : nullptr;
   if (chunks_out) *chunks_out = (int)chunks;
-  const int n_wg = (int)((chunks * H + BWAVES - 1) / BWAVES);
+  const int n_wg = (int)((chunks * H + bwaves - 1) / bwaves);
   int rc;
-  if (L <= 16) rc = launch_bwd16<false, false>(g, n_wg, s);
-  else rc = causal ? launch_bwd16<true, true>(g, n_wg, s) : launch_bwd16<true, false>(g, n_wg, s);
+  if (L <= 16) rc = launch_bwd16<2, false, false>(g, n_wg, s);
+  else if (nb == 2) rc = causal ? launch_bwd16<2, true, true>(g, n_wg, s) : launch_bwd16<2, true, false>(g, n_wg, s);
+  else if (nb == 3) rc = causal ? launch_bwd16<3, true, true>(g, n_wg, s) : launch_bwd16<3, true, false>(g, n_wg, s);
+  else rc = causal ? launch_bwd16<4, true, true>(g, n_wg, s) : launch_bwd16<4, true, false>(g, n_wg, s);
   *taken = true;
   return rc;
 }

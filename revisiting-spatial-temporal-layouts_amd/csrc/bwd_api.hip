@@ -354,6 +354,20 @@ int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, i
   return stlt_check_launch("attn_bwd_general_kernel");
 }
 
+size_t stlt_attn_core_bwd_scratch_bytes(int64_t H) { return (size_t)256 * 3 * (size_t)(H > 0 ? H : 0) * 64 * sizeof(float); }
+
+int stlt_attn_core_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
+                       float dropout_p, uint64_t seed, uint32_t site, float* dqkv, float* in_proj_b_grad, void* scratch, size_t scratch_bytes,
+                       stlt_stream_t stream) {
+  if (!qkv || !dctx || !kpm || !dqkv) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_bwd: null pointer");
+  if (dh != 64 || H <= 0 || S < 0 || L <= 0) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_bwd: head dim must be 64");
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
+  if (in_proj_b_grad && (!scratch || scratch_bytes < stlt_attn_core_bwd_scratch_bytes(H))) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_core_bwd: scratch too small");
+  if (S == 0) return 0;
+  return launch_attn_bwd(qkv, dctx, kpm, causal, S, L, H, dh, dqkv, (hipStream_t)stream, stlt_drop_make(dropout_p, seed), site, in_proj_b_grad,
+                         (float*)scratch);
+}
+
 size_t stlt_add_layernorm_bwd_scratch_bytes(int64_t d) { return (size_t)ln_bwd_scratch_floats(d > 0 ? d : 0) * sizeof(float); }
 
 int stlt_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* ln_w, float eps, int64_t M, int64_t d,

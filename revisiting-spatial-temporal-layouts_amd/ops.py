@@ -142,6 +142,22 @@ def weight_grad_group(items):
     L.check(lib.stlt_weight_grad_group(arr, len(items), _stream()), "stlt_weight_grad_group")
 
 
+def attn_core_bwd(qkv: torch.Tensor, dctx: torch.Tensor, kpm: torch.Tensor, causal: bool, num_heads: int, dropout_p: float = 0.0, seed: int = 0,
+                  site: int = 0, want_bias_grad: bool = False):
+    """Backward of K3 on the packed projection (include/stlt_hip.h: stlt_attn_core_bwd): qkv (S,L,3d), dctx (S,L,d) -> dqkv (S,L,3d)
+    [, column sums of dqkv (3d)]."""
+    lib = L.load()
+    _chk(qkv, torch.float32, "qkv"); _chk(dctx, torch.float32, "dctx")
+    kpm = _mask_u8(kpm, "kpm")
+    S, Lq, d3 = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    gb = torch.zeros(d3, device=qkv.device, dtype=torch.float32) if want_bias_grad else None
+    sc = _scratch(int(lib.stlt_attn_core_bwd_scratch_bytes(num_heads)), qkv.device)
+    L.check(lib.stlt_attn_core_bwd(_p(qkv), _p(dctx), _p(kpm), int(bool(causal)), S, Lq, num_heads, d3 // 3 // num_heads, float(dropout_p), int(seed),
+                                   int(site), _p(dqkv), _p(gb), sc.data_ptr(), sc.numel(), _stream()), "stlt_attn_core_bwd")
+    return (dqkv, gb) if want_bias_grad else dqkv
+
+
 def mhsa_fused(x: torch.Tensor, in_proj_w: torch.Tensor, in_proj_b: torch.Tensor, kpm: torch.Tensor, num_heads: int):
     """Fused in-projection + causal attention core (temporal tower): x (S,32,d), kpm (S,32) -> ctx (S,32,d)."""
     lib = L.load()

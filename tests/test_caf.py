@@ -278,6 +278,6 @@ def test_trainer_on_a_fusion_model_matches_the_stock_loop(pkg):
         assert abs(res["grad_norm"].item() - norm.item()) <= 2e-4 * max(1.0, norm.item()), (step, res["grad_norm"].item(), norm.item())
     ours.train = tr_train
     worst = max((a - b).abs().max().item() for a, b in zip(ours.parameters(), ref.parameters()))
-    assert worst <= 5e-5, worst
+    assert worst <= 5e-4, worst  # lr / 2: Adam's m / sqrt(v) amplifies rounding differences of near-zero gradients up to the step size
     untouched = [n for (n, a), b in zip(ours.named_parameters(), ref.parameters()) if b.grad is None]
     assert untouched and all("encoder_layer" in n or "score_embeddings" in n or "classifier" in n for n in untouched), untouched

@@ -530,3 +530,47 @@ def test_mhsa_fused_matches_projection_plus_attention_core(pkg, S, H):
     assert (got - two).abs().max().item() <= 2e-5
     with pytest.raises(pkg._lib.StltHipError):
         pkg.ops.mhsa_fused(xd[:, :16].contiguous(), wd, bd, kd[:, :16].contiguous(), H)
+
+
+@pytest.mark.parametrize("L", [17, 24, 31, 32, 33, 36, 40, 47, 48, 49, 57, 63, 64])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_attn_core_bwd_mfma_blocks_vs_fp64(pkg, L, causal, p):
+    """stlt_attn_core_bwd on 2 / 3 / 4 sixteen-row blocks (17-32, 33-48, 49-64 tokens: cfg2's clips, the fusion models' 33
+    appearance tokens, cfg4's 36 objects and 64 frames): dqkv and its column sums against torch autograd in fp64 on the oracle's
+    attention, with padded keys, a fully padded sequence, and the dropout mask the forward would have drawn."""
+    S, H = 21, 3
+    d = 64 * H
+    qkv = _rand(S, L, 3 * d, seed=L, scale=1.5)
+    g = _rand(S, L, d, seed=L + 1)
+    kpm = torch.rand(S, L, generator=torch.Generator().manual_seed(L)) < 0.3
+    kpm[:, 0] = False
+    kpm[4, :] = True  # a fully padded sequence: zero output, zero gradient
+    seed, site = 1234 + L, 24
+    dqkv, gb = pkg.ops.attn_core_bwd(qkv.to(DEV), g.to(DEV), kpm.to(DEV), causal, H, p, seed, site, want_bias_grad=True)
+    x = qkv.double().requires_grad_(True)
+    sp = lambda t: t.reshape(S, L, H, 64).transpose(1, 2)
+    sc = sp(x[..., :d]) @ sp(x[..., d:2 * d]).transpose(-1, -2) / 8.0
+    masked = kpm[:, None, None, :].expand(S, H, L, L).clone()
+    if causal:
+        masked |= torch.ones(L, L, dtype=torch.bool).triu(1)
+    pr = torch.softmax(sc.masked_fill(masked, float("-inf")), -1)
+    pr = torch.nan_to_num(pr, nan=0.0)  # fully masked rows
+    if p > 0:
+        pr = pr * _drop_mask(O, p, seed, site, S, H, L)
+    (pr @ sp(x[..., 2 * d:])).transpose(1, 2).reshape(S, L, d).backward(g.double())
+    ref = x.grad
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert torch.isfinite(dqkv).all()
+    assert (dqkv.cpu().double() - ref).abs().max().item() / scale <= 2e-5
+    assert (gb.cpu().double() - ref.reshape(-1, 3 * d).sum(0)).abs().max().item() / max(ref.reshape(-1, 3 * d).sum(0).abs().max().item(), 1e-6) <= 5e-5
+    assert dqkv[4].abs().max().item() == 0.0
+
+
+def _drop_mask(O, p, seed, site, S, H, L):
+    """(S,H,L,L) multiplicative mask of the attention probabilities: element (s,h,i,j) has idx = (((s*L+i)*H + h) << 8) | j."""
+    s_, h_, i_, j_ = np.meshgrid(np.arange(S, dtype=np.uint64), np.arange(H, dtype=np.uint64), np.arange(L, dtype=np.uint64),
+                                 np.arange(L, dtype=np.uint64), indexing="ij")
+    idx = ((((s_ * np.uint64(L) + i_) * np.uint64(H)) + h_) << np.uint64(8)) | j_
+    keep = O.dropout_keep(p, seed, site, idx)
+    return torch.from_numpy(keep).double() * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
