@@ -360,8 +360,8 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["STLT_BENCH_FAULT_DUMP"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps; default 50 forwards / 20 optimisation steps (SURVEY 8d: >= 50 timed, >= 10 warm-up iterations)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps; default 10 / 5")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--mode", choices=("forward", "train"), default="forward")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step; default 1024 for the forward (every cfg2 GEMM is then a whole "
@@ -374,6 +374,10 @@ def main():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 1024 if args.mode == "forward" else 64
+    if args.steps is None:
+        args.steps = 50 if args.mode == "forward" else 20
+    if args.warmup is None:
+        args.warmup = 10 if args.mode == "forward" else 5
 
     import torch
 
@@ -453,13 +457,14 @@ def main():
     if rank == 0:
         # ---- per-kernel durations: hipEvents around every launch inside the library, same workload
         try:
+            n_prof = min(args.steps, 20)  # per-kernel events: 20 replayed steps are plenty
             pkg.ops.prof_enable(True)
-            for _ in range(args.steps):
+            for _ in range(n_prof):
                 step()
             torch.cuda.synchronize(dev)
             prof = pkg.ops.prof_collect()
             pkg.ops.prof_enable(False)
-            k_ms = {k: (ms / args.steps, int(n / args.steps)) for k, (ms, n) in prof.items()}
+            k_ms = {k: (ms / n_prof, int(n / n_prof)) for k, (ms, n) in prof.items()}
         except Exception as exc:  # the roofline leg must never cost the main line
             print(f"[bench] per-kernel timing failed: {type(exc).__name__}: {exc}", file=sys.stderr)
             k_ms = {}
@@ -541,14 +546,15 @@ def main():
                 # padded rows too, and `value` is priced on that schedule.
                 real_tok = int(((~cpu_batch["src_key_padding_mask_boxes"]) & (~cpu_batch["src_key_padding_mask_frames"])[:, :, None]).sum())
                 model.backbone.skip_padding = True
-                for _ in range(args.warmup):
+                n_sk = min(args.steps, 20)
+                for _ in range(min(args.warmup, 5)):
                     step()
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
-                for _ in range(args.steps):
+                for _ in range(n_sk):
                     sk_logits = step()
                 torch.cuda.synchronize(dev)
-                sk_s = (time.perf_counter() - t1) / args.steps
+                sk_s = (time.perf_counter() - t1) / n_sk
                 model.backbone.skip_padding = False
                 out["skip_padding"] = {"value": round(B / sk_s, 2), "unit": "clips/s", "ms_per_step": round(sk_s * 1e3, 4),
                                        "real_token_frac": round(real_tok / (B * T * N), 4),

@@ -50,3 +50,19 @@ def test_oracle_backbone_output_time_major(synth):
         out = O.backbone_forward(sd, batch, H, prefix="backbone.")
     # reference returns (T,B,d); every row incl. padded frames is defined
     assert np.abs(out.transpose(0, 1).numpy() - z["backbone_tbd"]).max() <= 5e-5
+
+
+def test_dropout_mask_definition_statistics():
+    """The build's own counter-based dropout mask (oracle restatement of csrc/common.h: stlt_keep): keep rate, independence of
+    neighbouring elements and of sites / seeds, and indices beyond 32 bits folding in instead of wrapping."""
+    n = 1 << 20
+    idx = np.arange(n, dtype=np.uint64)
+    for p in (0.1, 0.5):
+        k = O.dropout_keep(p, 1234, 8, idx)
+        assert abs(k.mean() - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n)
+        # neighbours, sites and seeds are uncorrelated: joint keep rate = product of the marginals
+        for other in (np.roll(k, 1), O.dropout_keep(p, 1234, 9, idx), O.dropout_keep(p, 1235, 8, idx)):
+            assert abs((k & other).mean() - (1 - p) ** 2) < 6 * np.sqrt((1 - p) ** 2 / n)
+    hi = O.dropout_keep(0.5, 7, 3, idx + (np.uint64(1) << np.uint64(32)))
+    assert abs((hi == O.dropout_keep(0.5, 7, 3, idx)).mean() - 0.5) < 0.01  # the high word changes the stream
+    assert O.dropout_keep(0.0, 1, 1, idx[:1000]).all()
