@@ -39,10 +39,15 @@ struct BwdGeo {
   float scale;
   StltDrop dr;
   uint32_t site;
+  // RAGGED (skip-padding layout): item g = rows [grp_ptr[g], grp_ptr[g+1]) of the compacted buffer — whole segments, at most 16 NB
+  // rows; a row's segment starts at seg_start[row].  No key-padding bytes: every row is real.
+  const int* grp_ptr;
+  const int* seg_start;
 };
 
-template <int NB, bool FULL, bool CAUSAL, bool DROP>
+template <int NB, bool FULL, bool CAUSAL, bool DROP, bool RAGGED = false>
 __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const BwdGeo geo) {
+  static_assert(!RAGGED || FULL, "ragged items are walked as FULL items: segments may straddle the 16-row blocks");
   constexpr int BROWS = 16 * NB, TILE = BROWS * BD, BWAVES = waves_for(NB);
   __shared__ __attribute__((aligned(16))) float smem_all[BWAVES * (4 * TILE + BROWS)];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -62,16 +67,17 @@ __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const Bw
   if (chunk >= geo.chunks) return;  // the grid is rounded up to whole workgroups
 
   auto used = [&](int kb, int qb) __attribute__((always_inline)) { return FULL ? (!CAUSAL || kb <= qb) : kb == qb; };
+  int item_rows = L;  // RAGGED: rows of the current item
   // token of block b, local row r of the item that starts at token t0; -1 = no such row
   auto row_token = [&](int t0, int b, int r) __attribute__((always_inline)) {
     const int local = FULL ? b * 16 + r : r;
-    const int limit = FULL ? L : geo.P * L;
+    const int limit = RAGGED ? item_rows : FULL ? L : geo.P * L;
     const int tok = FULL ? t0 + local : t0 + b * geo.P * L + r;
     return (local < limit && tok < geo.n_tokens) ? tok : -1;
   };
-  // (sequence inside the block << 8) | position inside the sequence
-  auto row_meta = [&](int b) __attribute__((always_inline)) {
-    const int local = FULL ? b * 16 + li : li;
+  // (sequence inside the item << 8) | position inside the sequence, of a real row (token tok, local index `local`)
+  auto meta_of = [&](int t0, int tok, int local) __attribute__((always_inline)) {
+    if (RAGGED) { const int ss = geo.seg_start[tok]; return ((ss - t0) << 8) | (tok - ss); }
     return ((FULL ? 0 : local / L) << 8) | (FULL ? local : local % L);
   };
   // float offset of channel chunk c (4 floats) of row `row` in a swizzled tile
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const Bw
       for (int c = 0; c < 4; ++c) csum[a][b][c] = 0.f;
 
   for (int item = chunk; item < geo.n_items; item += geo.chunks) {
-    const int t0 = item * geo.rows_per_item;
+    const int t0 = RAGGED ? geo.grp_ptr[item] : item * geo.rows_per_item;
+    if (RAGGED) item_rows = geo.grp_ptr[item + 1] - t0;
     // ---- tiles by LDS-DMA: 4 rows (1 KB) per instruction, chunk slot q holds channels 4*(q ^ (row & 15))..
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous item's LDS reads have returned
 #pragma unroll
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const Bw
       const int b = lane >> 4, r = lane & 15;
       const int tok = row_token(t0, b, r);
       const int local = FULL ? b * 16 + r : r;
-      kmeta[lane] = (tok >= 0 && geo.kpm[tok] == 0) ? (((FULL ? 0 : local / L) << 8) | (FULL ? local : local % L)) : -1;
+      kmeta[lane] = (tok >= 0 && (RAGGED || geo.kpm[tok] == 0)) ? meta_of(t0, tok, local) : -1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // wave-local: tiles and key metadata are in LDS
 
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const Bw
       }
       // ---- mask, softmax, dropout, dS
       const int qtok = row_token(t0, qb, li);
-      const int mq = qtok >= 0 ? row_meta(qb) : -1;
+      const int mq = qtok >= 0 ? meta_of(t0, qtok, FULL ? qb * 16 + li : li) : -1;
       const int q_seq = mq >> 8, q_pos = mq & 0xff;
       int kpos[NB][4];
       float m = -1e30f;
@@ -316,7 +323,46 @@ int launch_bwd16(const BwdGeo& g, int n_wg, hipStream_t s) {
   return stlt_check_launch("attn_bwd16_kernel");
 }
 
+template <int NB, bool CAUSAL>
+int launch_bwd16_ragged(const BwdGeo& g, int n_wg, hipStream_t s) {
+  constexpr int BWAVES = waves_for(NB);
+  if (g.dr.thr) hipLaunchKernelGGL((attn_bwd16_kernel<NB, true, CAUSAL, true, true>), dim3((unsigned)n_wg), dim3(64 * BWAVES), 0, s, g);
+  else hipLaunchKernelGGL((attn_bwd16_kernel<NB, true, CAUSAL, false, true>), dim3((unsigned)n_wg), dim3(64 * BWAVES), 0, s, g);
+  return stlt_check_launch("attn_bwd16_kernel(ragged)");
+}
+
 }  // namespace
+
+// The same for the ragged (skip-padding) layout: groups of whole segments of at most 64 rows (AttnBwdRagged of common.h).
+int launch_attn_bwd16_ragged(const float* qkv, const float* dctx, const AttnBwdRagged& rg, int causal, int64_t H, float* dqkv, StltDrop dr,
+                             uint32_t site, float* scratch, int want_colsum, int* chunks_out, hipStream_t s, bool* taken) {
+  *taken = false;
+  static const int enabled = [] { const char* e = getenv("STLT_ATTN_BWD16"); return e ? atoi(e) : 1; }();
+  if (enabled != 1 || rg.max_rows < 1 || rg.max_rows > 64 || rg.n_groups < 1 || rg.n_rows > 0x7fffffffLL || H > 4096) return 0;
+  const int nb = rg.max_rows <= 32 ? 2 : rg.max_rows <= 48 ? 3 : 4;
+  const int bwaves = waves_for(nb);
+  BwdGeo g;
+  g.qkv = qkv; g.dctx = dctx; g.kpm = nullptr; g.dqkv = dqkv;
+  g.n_tokens = (int)rg.n_rows; g.L = rg.max_rows; g.H = (int)H; g.P = 1; g.rows_per_item = rg.max_rows;
+  g.scale = 0.125f;
+  g.dr = dr; g.site = site;
+  g.grp_ptr = rg.grp_ptr; g.seg_start = rg.seg_start;
+  g.n_items = (int)rg.n_groups;
+  int64_t chunks = ((int64_t)stlt_device_cus() * bwaves) / H;
+  if (chunks < 1) chunks = 1;
+  if (chunks > rg.n_groups) chunks = rg.n_groups;
+  if (chunks > 256) chunks = 256;
+  g.chunks = (int)chunks;
+  g.cs = want_colsum ? scratch : nullptr;
+  if (chunks_out) *chunks_out = (int)chunks;
+  const int n_wg = (int)((chunks * H + bwaves - 1) / bwaves);
+  int rc;
+  if (nb == 2) rc = causal ? launch_bwd16_ragged<2, true>(g, n_wg, s) : launch_bwd16_ragged<2, false>(g, n_wg, s);
+  else if (nb == 3) rc = causal ? launch_bwd16_ragged<3, true>(g, n_wg, s) : launch_bwd16_ragged<3, false>(g, n_wg, s);
+  else rc = causal ? launch_bwd16_ragged<4, true>(g, n_wg, s) : launch_bwd16_ragged<4, false>(g, n_wg, s);
+  *taken = true;
+  return rc;
+}
 
 // *taken = true when the launch was made (return value: 0 or the error; column-sum slabs, if asked for, are in `scratch`:
 // *chunks_out slabs of 3*H*64 floats, to be added by launch_reduce_slabs), false when the shape is not this kernel's.
@@ -335,6 +381,7 @@ int launch_attn_bwd16(const float* qkv, const float* dctx, const uint8_t* kpm, i
   g.n_tokens = (int)n_tokens; g.L = (int)L; g.H = (int)H;
   g.scale = 0.125f;  // 1 / sqrt(64)
   g.dr = dr; g.site = site;
+  g.grp_ptr = nullptr; g.seg_start = nullptr;
   if (L <= 16) { g.P = (int)(16 / L); g.rows_per_item = 2 * g.P * (int)L; }
   else { g.P = 1; g.rows_per_item = (int)L; }
   const int64_t items = (n_tokens + g.rows_per_item - 1) / g.rows_per_item;

@@ -701,11 +701,19 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
     }
     return 0;
   }
-  if (!rg && dh == 64) {  // padded layout, sequences of at most 32 tokens: the MFMA kernel (attn_bwd16.hip)
+  if (!rg && dh == 64) {  // padded layout, sequences of at most 64 tokens: the MFMA kernel (attn_bwd16.hip)
     if (g_colsum && !scratch) return stlt_set_error(STLT_EINVAL, "attn_bwd: column sums need scratch");
     bool taken = false;
     int slabs = 0;
     const int rc = launch_attn_bwd16(qkv, dctx, kpm, causal, S, L, H, dqkv, dr, site, scratch, g_colsum != nullptr, &slabs, s, &taken);
+    if (rc != 0) return rc;
+    if (taken) return g_colsum ? launch_reduce_slabs(scratch, 3 * H * dh, slabs, g_colsum, 3 * H * dh, 1, s) : 0;
+  }
+  if (rg && dh == 64) {  // ragged layout, groups of at most 64 rows: the same kernel with segment masks
+    if (g_colsum && !scratch) return stlt_set_error(STLT_EINVAL, "attn_bwd: column sums need scratch");
+    bool taken = false;
+    int slabs = 0;
+    const int rc = launch_attn_bwd16_ragged(qkv, dctx, *rg, causal, H, dqkv, dr, site, scratch, g_colsum != nullptr, &slabs, s, &taken);
     if (rc != 0) return rc;
     if (taken) return g_colsum ? launch_reduce_slabs(scratch, 3 * H * dh, slabs, g_colsum, 3 * H * dh, 1, s) : 0;
   }

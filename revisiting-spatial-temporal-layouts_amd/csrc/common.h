@@ -152,6 +152,9 @@ int launch_attn_bwd16(const float* qkv, const float* dctx, const uint8_t* kpm, i
                       bool* taken);  // attn_bwd16.hip; *taken = false: not this kernel's shape
 int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, const uint8_t* kpm, int64_t n_clips, int64_t T, int64_t H,
                       int64_t d, float* ctx, hipStream_t s);  // mhsa.hip: in-projection + causal attention core, T == 32, 64-channel heads
+struct AttnBwdRagged;
+int launch_attn_bwd16_ragged(const float* qkv, const float* dctx, const AttnBwdRagged& rg, int causal, int64_t H, float* dqkv, StltDrop dr,
+                             uint32_t site, float* scratch, int want_colsum, int* chunks_out, hipStream_t s, bool* taken);  // attn_bwd16.hip, ragged layout
 int launch_attn_general(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm,
                         int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx, int kid,
                         hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
