@@ -527,6 +527,7 @@ def main():
                        "flops_per_clip_dense": pkg.synth.flops_per_clip(T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"])},
             "roofline": {"kernel": "gemm_nt_kernel (f32 MFMA nn.Linear)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                         "note": "the out-proj / FFN2 products carry the layers' residual adds in their epilogues (STLT_FUSE_RESIDUAL, default on: LayerNorm passes read one tensor); with the adds in the LayerNorm pass the products alone measure about 0.006 higher",
                          "traffic": traffic_gemm, "traffic_note": "avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), from the committed rocprofv3 --pmc passes of this command: " + os.path.basename(tpath), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
             "roofline_attn_temporal": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=true> for T <= 64 (16-row tiles), attn_core_kernel beyond", "bound": "hbm", "achieved": round(at_gbs, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at_gbs / HBM_PEAK_GBS, 4),

@@ -67,6 +67,7 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 #define STLT_GEMM_ABLATE 0  // timing-only builds (wrong results): bit 0 no steady-state DMA, bit 3 loaders do not wait for their DMA, bit 4 no epilogue stores, bit 5 loaders re-read k-step 0 of their first tile (cache-hot source)
 #endif
 #ifndef STLT_GEMM_RES_PREFETCH
+// (requesting the second row half's pieces ahead of the first half's stores as well was tried: 8 pieces spill 72 registers at the 168 budget, 4 spill 32)
 #define STLT_GEMM_RES_PREFETCH 1  // the add-source pieces of a tile's first row half are requested at the start of the tile's last k-step (forward layout, loader-wave build, whole tiles): cfg2 / 1024 clips with the residual adds in the epilogues 107.2 -> 106.7 ms (profiles/round3_fwd_residual_ab.txt)
 #endif
 #ifndef STLT_GEMM_STORE_NT
