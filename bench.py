@@ -181,6 +181,52 @@ def side_forward_leg(pkg, torch, dev, config, B, steps, warmup):
             "roofline_attn_spatial": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **at["attn_spatial"])}
 
 
+def side_fusion_leg(pkg, torch, dev, B, steps, warmup):
+    """BASELINE config 5 for the default line's `cfg5` sub-object: CACNF inference (the STLT layout branch fused with precomputed
+    ResNet3D appearance features, cfg2 layout shapes + (B, 2048, 2, 4, 4) features) as one native call per batch."""
+    c = pkg.synth.CONFIGS["cfg2"]
+    kw = dict(pkg.synth.model_kwargs("cfg2"), appearance_num_frames=32)
+    m = pkg.models_factory["cacnf"](pkg.MultimodalModelConfig(**kw))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234))
+    m.train(False).to(dev)
+    batch = pkg.synth.make_batch(B, c["T"], c["N"], seed=3000)
+    batch["appearance_features"] = pkg.synth.make_appearance_features(B, seed=1)
+    batch = {k: v.to(dev) for k, v in batch.items()}
+
+    def step():
+        with torch.no_grad():
+            return m(batch)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    pkg.ops.prof_take_gemm_flops()
+    pkg.ops.prof_enable(True)
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        prof = pkg.ops.prof_collect()
+        gflops = pkg.ops.prof_take_gemm_flops() / steps
+    finally:
+        pkg.ops.prof_enable(False)
+    k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
+    gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
+    tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return {"workload": "cfg5: CACNF forward (layout branch T=32, N=7, d=768 + appearance features (B,2048,2,4,4) -> 33 tokens, cross-modal fusion layers, "
+                        "4 logit heads), precomputed appearance features", "per_gpu_batch": B, "steps": steps, "warmup": warmup,
+            "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4), "finite": bool(all(torch.isfinite(v).all() for v in out.values())),
+            "roofline": {"kernel": "gemm_nt_kernel launches of the call (the fused MHSA kernel of the layout branch is timed apart)", "bound": "mfma",
+                         "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                         "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items() if v[1] > 0}}
+
+
 def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
     """BASELINE config 3 on one GPU for the default line's `train_step` sub-object: the same step `--mode train` times."""
     c = pkg.synth.CONFIGS[config]
@@ -368,7 +414,7 @@ def main():
                                                            "number of 256-tile rounds), 64 for --mode train (the reference's batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-skip-padding", action="store_true", help="do not time the opt-in skip-padding variant after the main measurement (profiling runs)")
-    ap.add_argument("--no-side-legs", action="store_true", help="skip the bounded sub-measurements of the default line (train_step, cfg4, small_batch)")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the bounded sub-measurements of the default line (train_step, cfg4, small_batch, cfg5)")
     ap.add_argument("--side-legs", action="store_true", help="run the sub-measurements at any --batch (they ride on the default cfg2 / 1024-clip line only otherwise)")
     ap.add_argument("--no-cls-only", action="store_true", help="dense schedule: run the last spatial / last temporal layer on every token")
     args = ap.parse_args()
@@ -568,7 +614,8 @@ def main():
             # seconds each); `value` above is untouched.  Each leg frees its buffers before the next one starts.
             for key, fn in (("train_step", lambda: side_train_leg(pkg, torch, dev, "cfg2", 64, 10, 3)),
                             ("cfg4", lambda: side_forward_leg(pkg, torch, dev, "cfg4", 64, 10, 3)),
-                            ("small_batch", lambda: side_forward_leg(pkg, torch, dev, "cfg2", 64, 20, 5))):
+                            ("small_batch", lambda: side_forward_leg(pkg, torch, dev, "cfg2", 64, 20, 5)),
+                            ("cfg5", lambda: side_fusion_leg(pkg, torch, dev, 256, 5, 2))):
                 try:
                     out[key] = fn()
                 except Exception as exc:  # the secondary legs must never cost the main line
