@@ -57,7 +57,18 @@ def main():
                     tot_f += fl * layers
                     tot_t += ms * layers
                     print(f"{tower} {name:5s} {kind:3s} M={M:6d} out={n_out:5d} in={k_in:5d}  {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TFLOP/s  ({fl/ms/1e9/157.3:.3f})", flush=True)
-    print(f"step total ({4}+{8} layers) {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")
+        # the step itself does not run the four dW products of a layer one by one: they go out as ONE grouped stream-K launch
+        for tower, M in (("sp", B * T * N), ("tp", B * T)):
+            Mp = M // 32 * 32
+            items, fl = [], 0.0
+            for n_out, k_in in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d)):
+                dy = torch.rand(Mp, n_out, device=dev, generator=g) * 2 - 1
+                x = torch.rand(Mp, k_in, device=dev, generator=g) * 2 - 1
+                items.append((dy, x, torch.zeros(n_out, k_in, device=dev)))
+                fl += 2.0 * Mp * n_out * k_in
+            ms = timed(lambda: pkg.ops.weight_grad_group(items), args.iters)
+            print(f"{tower} 4 x dw, grouped launch  M={M:6d}                {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TFLOP/s  ({fl/ms/1e9/157.3:.3f})", flush=True)
+    print(f"step total ({4}+{8} layers, products one at a time) {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
