@@ -54,7 +54,7 @@ struct DwList {
 int flush_dw(const DwList& l, const BlockScratch& sc, hipStream_t s) {
   if (l.n == 0) return 0;
   bool group_ok = true;
-  for (int i = 0; i < l.n; ++i) group_ok = group_ok && l.it[i].rows % 32 == 0;
+  for (int i = 0; i < l.n; ++i) group_ok = group_ok && l.it[i].rows % 32 == 0 && l.it[i].rows <= 4096;  // long contractions: separate launches are as fast (train.hip: weight_grad_all)
   StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
   if (group_ok) return launch_weight_grad_group(l.it, l.n, s);
   for (int i = 0; i < l.n; ++i)

@@ -120,7 +120,13 @@ static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k
 // fill, at most two partial tiles per workgroup and one fix-up for the layer instead of four of each.
 static int weight_grad_all(const StltWeightGradItem* items, int n, const Scratch& sc, hipStream_t s) {
   static const bool grouped = [] { const char* e = getenv("STLT_GEMM_GROUP_DW"); return e ? atoi(e) != 0 : true; }();  // A/B knob
-  if (grouped && sc.sk && stlt_gemm_has_scratch()) return launch_weight_grad_group(items, n, s);
+  // Grouping pays where the products are launch-bound (the temporal tower at 64 clips: 54 k-steps per workgroup for all four,
+  // 322 -> 266 us); with long contractions (the spatial tower: 378 k-steps per workgroup) the four separate launches are
+  // slightly faster — three interleaved A/B pairs of the 64-clip step: 27.17 ms grouped everywhere, 27.07 ms with this limit
+  static const int64_t max_rows = [] { const char* e = getenv("STLT_GEMM_GROUP_DW_MAXROWS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+  int64_t rows = 0;
+  for (int i = 0; i < n; ++i) if (items[i].rows > rows) rows = items[i].rows;
+  if (grouped && rows <= max_rows && sc.sk && stlt_gemm_has_scratch()) return launch_weight_grad_group(items, n, s);
   for (int i = 0; i < n; ++i) TRY(weight_grad(items[i].dy, items[i].n_out, items[i].x, items[i].k_in, items[i].rows, items[i].g_w, sc, s));
   return 0;
 }
