@@ -471,29 +471,33 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ boxes, const float* __restrict__ scores,
                                                         int C, int64_t n_tokens, int d, int64_t tok_per_block,
                                                         float* __restrict__ partials, const int* __restrict__ src_index) {
+  // block = (token chunk, 256-channel slice); the per-category sums of the thread's channel live in LDS ([C][256]: a thread
+  // only ever touches its own column, so plain read-modify-writes, no conflicts), the box / score sums in registers
+  extern __shared__ float cat_acc[];
   const int64_t t0 = (int64_t)blockIdx.x * tok_per_block;
   const int64_t t1 = t0 + tok_per_block < n_tokens ? t0 + tok_per_block : n_tokens;
   float* out = partials + (int64_t)blockIdx.x * (C + 7) * d;
-  for (int c = threadIdx.x; c < d; c += 256) {
-    float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bw3 = 0.f, bb = 0.f, sw = 0.f;
-    for (int k = 0; k < C; ++k) out[(int64_t)k * d + c] = 0.f;
-    for (int64_t t = t0; t < t1; ++t) {
-      const float g = dx[t * d + c];
-      const int64_t src = src_index ? src_index[t] : t;  // ragged: gradient row -> token of the padded batch
-      const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + src * 4);
-      bw0 += g * bx.x; bw1 += g * bx.y; bw2 += g * bx.z; bw3 += g * bx.w;
-      bb += g;
-      if (scores) sw += g * scores[src];
-      int64_t cat = categories[src];
-      cat = cat < 0 ? 0 : (cat >= C ? C - 1 : cat);
-      out[cat * d + c] += g;  // same thread owns this (row, channel): plain read-modify-write
-    }
-    out[(int64_t)(C + 0) * d + c] = bw0; out[(int64_t)(C + 1) * d + c] = bw1;
-    out[(int64_t)(C + 2) * d + c] = bw2; out[(int64_t)(C + 3) * d + c] = bw3;
-    out[(int64_t)(C + 4) * d + c] = bb;
-    out[(int64_t)(C + 5) * d + c] = sw;
-    out[(int64_t)(C + 6) * d + c] = bb;  // score_b gradient equals box_b's (both are plain sums)
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= d) return;
+  for (int k = 0; k < C; ++k) cat_acc[k * 256 + threadIdx.x] = 0.f;
+  float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f, bw3 = 0.f, bb = 0.f, sw = 0.f;
+  for (int64_t t = t0; t < t1; ++t) {
+    const float g = dx[t * d + c];
+    const int64_t src = src_index ? src_index[t] : t;  // ragged: gradient row -> token of the padded batch
+    const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + src * 4);
+    bw0 += g * bx.x; bw1 += g * bx.y; bw2 += g * bx.z; bw3 += g * bx.w;
+    bb += g;
+    if (scores) sw += g * scores[src];
+    int64_t cat = categories[src];
+    cat = cat < 0 ? 0 : (cat >= C ? C - 1 : cat);
+    cat_acc[(int)cat * 256 + threadIdx.x] += g;
   }
+  for (int k = 0; k < C; ++k) out[(int64_t)k * d + c] = cat_acc[k * 256 + threadIdx.x];
+  out[(int64_t)(C + 0) * d + c] = bw0; out[(int64_t)(C + 1) * d + c] = bw1;
+  out[(int64_t)(C + 2) * d + c] = bw2; out[(int64_t)(C + 3) * d + c] = bw3;
+  out[(int64_t)(C + 4) * d + c] = bb;
+  out[(int64_t)(C + 5) * d + c] = sw;
+  out[(int64_t)(C + 6) * d + c] = bb;  // score_b gradient equals box_b's (both are plain sums)
 }
 
 // sum the block partials in block order and scatter into the parameter-gradient tensors (accumulating)
@@ -502,11 +506,21 @@ __global__ __launch_bounds__(256) void embed_bwd_finalize_kernel(const float* __
                                                                  float* __restrict__ g_box_w, float* __restrict__ g_box_b,
                                                                  float* __restrict__ g_score_w,
                                                                  float* __restrict__ g_score_b) {
+  // block = (16 channels, one partial row kind); 16 lanes per channel each sum every 16th block partial, then a fixed-order
+  // LDS pass adds the 16 lanes: deterministic, and 16x the parallelism of one thread per channel
+  __shared__ float part[16][17];
   const int row = blockIdx.y;  // 0..C+6
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d) return;
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + col;
   float acc = 0.f;
-  for (int b = 0; b < n_blocks; ++b) acc += partials[((int64_t)b * (C + 7) + row) * d + c];
+  if (c < d)
+    for (int b = sl; b < n_blocks; b += 16) acc += partials[((int64_t)b * (C + 7) + row) * d + c];
+  part[sl][col] = acc;
+  __syncthreads();
+  if (sl != 0 || c >= d) return;
+  acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc += part[k][col];
   if (row < C) { if (g_cat && row != 0) g_cat[(int64_t)row * d + c] += acc; }   // padding_idx = 0: no gradient (models.py:22)
   else if (row < C + 4) { if (g_box_w) g_box_w[(int64_t)c * 4 + (row - C)] += acc; }  // box_w is (d,4)
   else if (row == C + 4) { if (g_box_b) g_box_b[c] += acc; }
@@ -742,7 +756,7 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
 }
 
 int64_t embed_bwd_scratch_floats(int64_t n_tokens, int64_t C, int64_t d) {
-  const int64_t blocks = (n_tokens + 127) / 128 > 512 ? 512 : (n_tokens + 127) / 128;
+  const int64_t blocks = (n_tokens + 31) / 32 > 512 ? 512 : (n_tokens + 31) / 32;  // as launch_embed_bwd cuts the tokens
   return (blocks > 0 ? blocks : 1) * (C + 7) * d;
 }
 
@@ -752,13 +766,23 @@ int launch_embed_bwd(const float* dx, const int64_t* categories, const float* bo
   StltProfScope ps(STLT_K_EMBED_BWD, s);
   if (!dx || !categories || !boxes || !scratch) return stlt_set_error(STLT_EINVAL, "embed_bwd: null pointer");
   if (n_tokens == 0) return 0;
-  int64_t blocks = (n_tokens + 127) / 128;
+  int64_t blocks = (n_tokens + 31) / 32;  // short token chunks x channel slices: enough blocks for every CU (round 3: 112 -> 1344 at 64 clips)
   if (blocks > 512) blocks = 512;
   const int64_t tpb = (n_tokens + blocks - 1) / blocks;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dx, categories, boxes, scores, (int)C, n_tokens,
-                     (int)d, tpb, scratch, src_index);
+  const size_t lds = (size_t)C * 256 * sizeof(float);
+  if (lds > 128 * 1024) return stlt_set_error(STLT_EINVAL, "embed_bwd: at most 128 categories (got %lld)", (long long)C);
+  if (lds > 48 * 1024) {
+    static StltPerDeviceOnce lds_once;
+    if (!lds_once.flag()) {
+      if (hipError_t e = hipFuncSetAttribute((const void*)embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); e != hipSuccess)
+        return stlt_set_error((int)e, "embed_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      lds_once.flag() = true;
+    }
+  }
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)blocks, (unsigned)((d + 255) / 256)), dim3(256), lds, s, dx, categories, boxes, scores, (int)C,
+                     n_tokens, (int)d, tpb, scratch, src_index);
   if (int e = stlt_check_launch("embed_bwd_kernel")) return e;
-  hipLaunchKernelGGL(embed_bwd_finalize_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)(C + 7)), dim3(256), 0, s, scratch,
+  hipLaunchKernelGGL(embed_bwd_finalize_kernel, dim3((unsigned)((d + 15) / 16), (unsigned)(C + 7)), dim3(256), 0, s, scratch,
                      (int)blocks, (int)C, (int)d, scores ? 1 : 0, g_cat, g_box_w, g_box_b, g_score_w, g_score_b);
   return stlt_check_launch("embed_bwd_finalize_kernel");
 }
