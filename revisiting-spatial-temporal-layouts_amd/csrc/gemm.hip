@@ -44,6 +44,7 @@
 // over work items; split s writes its partial product to C + s*slab_stride (summed by reduce_slabs_kernel:
 // deterministic, no atomics).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -156,6 +157,8 @@ __device__ __forceinline__ float half_wave_sum(float x) {  // over the 32 lanes 
 // [P[x], P[x+1]), cut into ranges of S[x] steps for its workgroups in turn (per-XCD lengths: room for clock-weighted
 // ranges; equal today).  dp_rounds = 0: the plain stream-K assignment (G equal ranges over every tile).
 struct SkPlan { int dp_rounds; int P[9]; int S[8]; };
+struct SkNone {};
+template <bool B, class T> auto karg(const T& t) { if constexpr (B) return t; else return SkNone{}; }
 
 // GROUP (with SK and WS): the launch walks the tiles of several products (StltGemmGroup, by value in the kernel arguments:
 // a wave reads the fields of the product its current tile belongs to with scalar loads); X / W / R / Y / M / N / K of the
@@ -169,8 +172,14 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
                                                                   int64_t slab_stride, int M, int N, int K,
                                                                   int tiles_m, int tiles_n, int n_split,
                                                                   float* __restrict__ partials,
-                                                                  unsigned long long* __restrict__ dbg, const SkPlan plan,
-                                                                  const StltGemmGroup grp, const StltGemmEpi epi) {
+                                                                  unsigned long long* __restrict__ dbg,
+                                                                  const std::conditional_t<SK, SkPlan, SkNone> plan_in,
+                                                                  const std::conditional_t<GROUP, StltGemmGroup, SkNone> grp_in,
+                                                                  const std::conditional_t<ACT == STLT_ACT_GELU_BWD, StltGemmEpi, SkNone> epi_in) {
+  SkPlan plan{}; StltGemmGroup grp{}; StltGemmEpi epi{};
+  if constexpr (SK) plan = plan_in;
+  if constexpr (GROUP) grp = grp_in;
+  if constexpr (ACT == STLT_ACT_GELU_BWD) epi = epi_in;
   static_assert(!GROUP || (SK && WS), "grouped launches are stream-K launches of the loader-wave build");
   static_assert(ACT != STLT_ACT_GELU_BWD || (ADD && !GROUP), "the fused GELU backward reads u through the add-source");
   constexpr int prio = STLT_GEMM_PRIO_MODE;
@@ -1131,7 +1140,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
         if (make_sk_plan(n_tiles, nk, G, xcd_weights(), weighted, plan, tail)) fix_tiles = tail;
         else plan = SkPlan{};
       }
-#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan, StltGemmGroup{}, epi)
+#define LAUNCH_SK1(ACTV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, false, TAV, TBV, ADDV, true, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, 1, P, nullptr, plan, SkNone{}, karg<(ACTV) == STLT_ACT_GELU_BWD>(epi))
 #define LAUNCH_SK(ACTV, TAV, TBV, ADDV) do { if (ws_sk) LAUNCH_SK1(ACTV, TAV, TBV, ADDV, true, dim3(GEMM_THREADS_WS)); else LAUNCH_SK1(ACTV, TAV, TBV, ADDV, false, block); } while (0)
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
       else if (transB && act == STLT_ACT_GELU_BWD) LAUNCH_SK(STLT_ACT_GELU_BWD, false, true, true);
@@ -1157,7 +1166,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   // wave-specialised build (4 DMA-only waves beside the 8 MFMA waves) unless STLT_GEMM_WS=0 (A/B measurements)
   static const bool ws = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
   const dim3 block_ws(GEMM_THREADS_WS);
-#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf, SkPlan{}, StltGemmGroup{}, epi)
+#define LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, WSV, BLK) hipLaunchKernelGGL((gemm_nt_kernel<ACTV, STAMPV, TAV, TBV, ADDV, false, WSV>), grid, BLK, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, n_split, (float*)nullptr, g_stlt_debug_buf, SkNone{}, SkNone{}, karg<(ACTV) == STLT_ACT_GELU_BWD>(epi))
 #define LAUNCH(ACTV, STAMPV, TAV, TBV, ADDV) do { if (ws) LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, true, block_ws); else LAUNCH1(ACTV, STAMPV, TAV, TBV, ADDV, false, block); } while (0)
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB && act == STLT_ACT_GELU_BWD) LAUNCH(STLT_ACT_GELU_BWD, false, false, true, true);
@@ -1214,7 +1223,7 @@ int launch_weight_grad_group(const StltWeightGradItem* items, int n_items, hipSt
   float* P = t_gemm_scratch;
   hipLaunchKernelGGL((gemm_nt_kernel<STLT_ACT_NONE, false, true, true, true, true, true, true>), dim3((unsigned)G), dim3(GEMM_THREADS_WS), 0, s,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, (int64_t)0,
-                     (float*)nullptr, (int64_t)0, (int64_t)0, 0, 0, BK, 0, 0, 1, P, (unsigned long long*)nullptr, SkPlan{}, grp, StltGemmEpi{StltDrop{0u, 1.0f, 0ull}, 0u, nullptr, nullptr});
+                     (float*)nullptr, (int64_t)0, (int64_t)0, 0, 0, BK, 0, 0, 1, P, (unsigned long long*)nullptr, SkPlan{}, grp, SkNone{});
   if (int e = stlt_check_launch("gemm_nt_kernel(grouped stream-k)")) return e;
   hipLaunchKernelGGL(gemm_fixup_group_kernel, dim3((unsigned)(tiles * FIXUP_CHUNKS)), dim3(256), 0, s, P, S, grp);
   return stlt_check_launch("gemm_fixup_group_kernel");
