@@ -152,6 +152,7 @@ SIGNATURES = {
     "stlt_eval_max_clips": (C.c_int64, []),
     "stlt_eval_store_sigmoid": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int64, _vp]),
     "stlt_debug_buffer_bytes": (C.c_size_t, []),
+    "stlt_set_gemm_split_bf16": (C.c_int, [C.c_int]),
     "stlt_eval_average_precision": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp]),
     "stlt_grad_norm": (C.c_int, [_vp, C.c_int64, C.c_float, _vp, _vp, _vp]),
     "stlt_adamw_step": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),

@@ -1272,6 +1272,9 @@ int launch_reduce_slabs3(const float* slabs, int64_t stride, int n_slabs, float*
 
 int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, int act, hipStream_t s) {
+  bool taken = false;  // opt-in split-bf16 build of the same product (gemm_bf16x3.hip); off unless STLT_GEMM_SPLIT_BF16=6
+  if (int e = launch_linear_bf16x3(x, ldx, w, K, bias, nullptr, 0, y, ldy, M, N, K, act, s, &taken)) return e;
+  if (taken) return 0;
   return launch_gemm(0, 0, x, ldx, w, K, bias, nullptr, 0, y, ldy, 0, M, N, K, 1, act, s);
 }
 
@@ -1279,5 +1282,8 @@ int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias
 // storing the product and adding r in the LayerNorm pass: the accumulators start from b, r is added last)
 int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y,
                       int64_t ldy, int64_t M, int64_t N, int64_t K, hipStream_t s) {
+  bool taken = false;
+  if (int e = launch_linear_bf16x3(x, ldx, w, K, bias, r, ldr, y, ldy, M, N, K, STLT_ACT_NONE, s, &taken)) return e;
+  if (taken) return 0;
   return launch_gemm(0, 0, x, ldx, w, K, bias, r, ldr, y, ldy, 0, M, N, K, 1, STLT_ACT_NONE, s);
 }
