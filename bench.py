@@ -413,6 +413,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step; default 1024 for the forward (every cfg2 GEMM is then a whole "
                                                            "number of 256-tile rounds), 64 for --mode train (the reference's batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-bf16", action="store_true", help="do not time the opt-in split-bf16 GEMM variant after the main measurement (profiling runs)")
     ap.add_argument("--no-skip-padding", action="store_true", help="do not time the opt-in skip-padding variant after the main measurement (profiling runs)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the bounded sub-measurements of the default line (train_step, cfg4, small_batch, cfg5)")
     ap.add_argument("--side-legs", action="store_true", help="run the sub-measurements at any --batch (they ride on the default cfg2 / 1024-clip line only otherwise)")
@@ -609,6 +610,46 @@ def main():
                                        "logit_max_abs_diff_vs_padded": float((sk_logits - logits).abs().max())}
             except Exception as exc:  # the secondary legs must never cost the main line
                 out["skip_padding"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and not args.no_split_bf16:
+            try:
+                # Same workload with the forward products on the BF16 matrix cores as six bf16 piece products per f32 product
+                # (csrc/gemm_bf16x3.hip, opt-in, f32-equivalent: error vs fp64 at or below the f32 kernel's).  Reported beside
+                # `value`, never as `value`: `value` is the f32-MFMA schedule's.
+                pkg.ops.set_gemm_split_bf16(6)
+                n_x3 = min(args.steps, 20)
+                for _ in range(min(args.warmup, 5)):
+                    step()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(n_x3):
+                    x3_logits = step()
+                torch.cuda.synchronize(dev)
+                x3_s = (time.perf_counter() - t1) / n_x3
+                pkg.ops.prof_enable(True)  # a second, event-timed pass for the products' own time
+                pkg.ops.prof_collect()
+                pkg.ops.prof_take_gemm_flops()
+                n_x3 = min(n_x3, 5)
+                for _ in range(n_x3):
+                    step()
+                torch.cuda.synchronize(dev)
+                x3_k = pkg.ops.prof_collect()
+                x3_fl = pkg.ops.prof_take_gemm_flops()
+                pkg.ops.prof_enable(False)
+                x3_ms = x3_k.get("gemm", (0.0, 0))[0]
+                out["split_bf16"] = {"value": round(B / x3_s, 2), "unit": "clips/s", "ms_per_step": round(x3_s * 1e3, 4),
+                                     "gemm_ms_per_step": round(x3_ms / n_x3, 4),
+                                     "gemm_tflops_f32_equivalent": round(x3_fl / (x3_ms * 1e-3) / 1e12, 2) if x3_ms > 0 else None,
+                                     "vs_f32_mfma_peak": round(x3_fl / (x3_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if x3_ms > 0 else None,
+                                     "logit_max_abs_diff_vs_f32_forward": float((x3_logits - logits).abs().max()),
+                                     "note": "opt-in (STLT_GEMM_SPLIT_BF16=6): f32 operands cut into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per f32 product, f32 accumulation; whole-tile launches with fill >= 0.9 only, the rest stay on the f32-MFMA kernel"}
+            except Exception as exc:  # the secondary legs must never cost the main line
+                out["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
+            finally:
+                try:
+                    pkg.ops.set_gemm_split_bf16(0)
+                    pkg.ops.prof_enable(False)
+                except Exception:
+                    pass
         if world == 1 and not args.no_side_legs and args.config == "cfg2" and (B == 1024 or args.side_legs):
             # BASELINE configs 3 / 4 and the reference's default batch on the same clock as the headline line (bounded: a few
             # seconds each); `value` above is untouched.  Each leg frees its buffers before the next one starts.

@@ -79,6 +79,12 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: 
     return out
 
 
+def set_gemm_split_bf16(terms: int) -> None:
+    """Opt-in split-bf16 build of the `linear` forward (include/stlt_hip.h: stlt_set_gemm_split_bf16): 6 = six bf16 MFMA
+    products per f32 product, f32-equivalent results; 0 = the f32-MFMA kernel (default).  Process-wide."""
+    L.check(L.load().stlt_set_gemm_split_bf16(int(terms)), "stlt_set_gemm_split_bf16")
+
+
 class gemm_scratch:
     """Context manager: lend the calling thread's `linear` / `gemm` launches a scratch buffer so that under-filled
     launches run as stream-K (include/stlt_hip.h: stlt_gemm_set_scratch).  The whole-path calls do this themselves."""

@@ -1,0 +1,95 @@
+"""The opt-in split-bf16 forward GEMM (csrc/gemm_bf16x3.hip): f32-equivalent results from six bf16 MFMA products per f32
+product.  Parity bar: its error against an fp64 product is within 1.5x the f32-MFMA kernel's on the same inputs (tolerance
+written below), shapes it does not take give the f32 kernel's bits, and the whole forward's logits agree to 2e-4."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture
+def split(pkg):
+    yield pkg.ops.set_gemm_split_bf16
+    pkg.ops.set_gemm_split_bf16(0)
+
+
+def _operands(M, N, K, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / math.sqrt(K)
+    b = torch.randn(N, device=DEV, generator=g)
+    return x, w, b
+
+
+# whole-tile launches that fill >= 0.9 of the chip's workgroups: (M, N, K, act, bias?)
+SHAPES = [(16347, 507, 96, 0, True),      # ragged last row block and column block (64 x 4 tiles)
+          (10240, 768, 768, 1, True),     # GELU epilogue, 40 x 6 tiles
+          (16384, 512, 64, 2, True),      # ReLU, the shortest contraction the kernel takes (two k-steps)
+          (65536, 256, 3072, 0, False),   # no bias, 256 x 2 tiles = two rounds
+          (13312, 2304, 768, 0, True)]    # an in-projection shape, 52 x 18 tiles = four rounds at fill 0.91
+
+
+@pytest.mark.parametrize("M,N,K,act,with_bias", SHAPES)
+def test_split_bf16_linear_error_vs_fp64_is_the_f32_kernels(pkg, split, M, N, K, act, with_bias):
+    x, w, b = _operands(M, N, K, seed=M + N)
+    bias = b if with_bias else None
+    with pkg.ops.gemm_scratch(DEV):
+        split(0)
+        y0 = pkg.ops.linear(x, w, bias, act=act)
+        split(6)
+        y6 = pkg.ops.linear(x, w, bias, act=act)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    idx = torch.cat([torch.randperm(M, device=DEV, generator=g)[:1500], torch.arange(M - 40, M, device=DEV)])
+    ref = x[idx].double() @ w.double().t()
+    if with_bias:
+        ref = ref + b.double()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    e0 = (y0[idx].double() - ref).abs()
+    e6 = (y6[idx].double() - ref).abs()
+    assert not torch.equal(y0, y6), "the split-bf16 kernel did not run (results are the f32 kernel's bits)"
+    assert e6.max().item() <= 1.5 * e0.max().item() + 1e-7
+    assert e6.mean().item() <= 1.1 * e0.mean().item() + 1e-9
+    assert torch.isfinite(y6).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(12345, 777, 96),    # launch fill 0.67: stream-K stays
+                                   (16384, 512, 32),    # a single k-step
+                                   (300, 130, 64)])
+def test_split_bf16_leaves_other_shapes_to_the_f32_kernel(pkg, split, M, N, K):
+    x, w, b = _operands(M, N, K, seed=7)
+    with pkg.ops.gemm_scratch(DEV):
+        split(0)
+        y0 = pkg.ops.linear(x, w, b, act=1)
+        split(6)
+        y6 = pkg.ops.linear(x, w, b, act=1)
+    assert torch.equal(y0, y6)
+
+
+def test_split_bf16_setter_rejects_other_term_counts(pkg):
+    with pytest.raises(pkg.StltHipError):
+        pkg.ops.set_gemm_split_bf16(3)
+    pkg.ops.set_gemm_split_bf16(0)
+
+
+def test_split_bf16_forward_logits_agree_with_the_f32_forward(pkg, split):
+    """cfg2 (12 layers, d = 768) at 64 clips: every product of the spatial tower — residual-add epilogues included — and the
+    temporal FFN products run split-bf16; logits within 2e-4 of the f32 forward (both are f32-rounding-level from fp64)."""
+    c = pkg.synth.CONFIGS["cfg2"]
+    kw = pkg.synth.model_kwargs("cfg2")
+    model = pkg.Stlt(pkg.StltModelConfig(**kw))
+    model.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234))
+    model.train(False).to(DEV)
+    batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(64, c["T"], c["N"], dataset=c["dataset"], seed=5).items()}
+    with torch.no_grad():
+        split(0)
+        l0 = model(batch)["stlt"].clone()
+        split(6)
+        l6 = model(batch)["stlt"].clone()
+    assert not torch.equal(l0, l6), "the split-bf16 kernel did not run inside the forward"
+    assert (l0 - l6).abs().max().item() <= 2e-4

@@ -20,12 +20,12 @@ python tools/bench_mhsa.py > $O/round3_mhsa_ab.jsonl 2>&1
 # 4. rocprofv3: kernel statistics of the default command, then the separate PMC passes (traffic, utilisation)
 cd /tmp
 rm -rf /tmp/ks /tmp/pf /tmp/pw /tmp/pu
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o o -- python3 $R/bench.py --no-cpu-baseline --no-skip-padding --no-side-legs > $O/round3_bench_under_rocprof_b1024.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o o -- python3 $R/bench.py --no-cpu-baseline --no-skip-padding --no-split-bf16 --no-side-legs > $O/round3_bench_under_rocprof_b1024.log 2>&1
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $O/round3_kernel_stats_b1024.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o o -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-skip-padding --no-side-legs > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o o -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-skip-padding --no-side-legs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o o -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-skip-padding --no-split-bf16 --no-side-legs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o o -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-skip-padding --no-split-bf16 --no-side-legs > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $O/round3_traffic_pmc.json /tmp/pf /tmp/pw
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pu -o o -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-skip-padding --no-side-legs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pu -o o -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-skip-padding --no-split-bf16 --no-side-legs > /dev/null 2>&1
 python3 $R/tools/pmc_util.py $O/round3_util_pmc.json /tmp/pu
 # 5. the training step under the tracer: kernel statistics + the timeline of one step
 rm -rf /tmp/pt
