@@ -16,7 +16,7 @@ from conftest import GOLDEN, PKG_NAME, ROOT, load_golden
 
 def test_library_exports_every_declared_symbol(pkg):
     header = open(os.path.join(ROOT, "include", "stlt_hip.h")).read()
-    declared = set(re.findall(r"\b(stlt_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(stlt_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     lib = pkg._lib.load()
     for name in sorted(declared):
