@@ -23,8 +23,11 @@
 #include <cstdlib>
 #include "common.h"
 
+#ifndef STLT_X3_STAMP
+#define STLT_X3_STAMP 0
+#endif
 #ifndef STLT_X3_EXP
-#define STLT_X3_EXP 0  // timing experiments (wrong results): 4 = producers write uncut bits, 8 = no operand loads after the prologue
+#define STLT_X3_EXP 0  // timing experiments (wrong results): 4 = producers write uncut bits, 8 = no operand loads after the prologue, 16 = one MFMA per block instead of six
 #endif
 
 namespace {
@@ -148,7 +151,7 @@ template <int ACT, bool ADD>
 __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                                       int64_t ldw, const float* __restrict__ bias, const float* __restrict__ R,
                                                                       int64_t ldr, float* __restrict__ Y, int64_t ldy, int M, int N, int K,
-                                                                      int tiles_m, int tiles_n) {
+                                                                      int tiles_m, int tiles_n, unsigned long long* __restrict__ dbg) {
   __shared__ __attribute__((aligned(16))) unsigned char pmem[2 * P_BUF + 2 * BN * 4];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -160,11 +163,23 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
   if (my_tiles <= 0) return;
   const int total_steps = my_tiles * nk;
   float* bias_lds = reinterpret_cast<float*>(pmem + 2 * P_BUF);
+#if STLT_X3_STAMP  // diagnostic build: per-wave shader-clock totals -> dbg[(workgroup * 12 + wave) * 4 + {total, at the barrier, steps}]
+  unsigned long long t_bar = 0, t_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0}, t_last = t_begin;  // producer phases: [0] other (scalar, waits for operands), [1] cut, [2] plane stores, [3] load issue
+#define X3_T(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_n = __builtin_amdgcn_s_memtime(); t_ph[k] += t_n - t_last; t_last = t_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define X3_BARRIER() do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_a = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); const unsigned long long t_b = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_bar += t_b - t_a; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define X3_FINISH() do { if (dbg && lane == 0) { unsigned long long* o = dbg + ((size_t)blockIdx.x * 12 + wave) * 4; o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_bar; o[2] = (unsigned long long)total_steps; if (wave >= X_WAVES) { unsigned long long* e = dbg + 256 * 12 * 4 + ((size_t)blockIdx.x * 4 + (wave - X_WAVES)) * 4; e[0] = t_ph[0]; e[1] = t_ph[1]; e[2] = t_ph[2]; e[3] = t_ph[3]; unsigned long long* f = dbg + 256 * 12 * 4 + 256 * 16 + ((size_t)blockIdx.x * 4 + (wave - X_WAVES)) * 2; f[0] = t_ph[4]; f[1] = t_ph[5]; } } } while (0)
+#else
+#define X3_T(k) do { } while (0)
+#define X3_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define X3_FINISH() do { } while (0)
+#endif
 
   if (wave >= X_WAVES) {
-    // ---- producer waves: wave p owns X rows [64p, 64p+64) (8 loads of 8 rows x 128 B per k-step) and W rows [32p, 32p+32) (4)
+    // ---- producer waves: wave p owns X rows [64p, 64p+64) and W rows [32p, 32p+32); a lane holds 8 consecutive k of a row
+    // (two 16-byte loads), so that each of its plane pieces is one 16-byte LDS store: 4 + 2 items of 16 rows per k-step
     const int p = wave - X_WAVES;
-    const int prow = lane >> 3, pch = lane & 7;
+    const int prow = lane >> 2, pch = lane & 3;
     // operand loads = buffer loads: a per-tile descriptor in scalar registers (base = the tile's first row, extent = the rows
     // left in the matrix: rows past the edge read as zeros, no clamping), one lane-constant VGPR offset per operand, the
     // 8-row piece stride added per load and the k offset in the scalar offset field: no 64-bit lane addresses at all
@@ -178,24 +193,25 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
       rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)n0 * ldw), 0, extent(N - n0, ldw), 0x27000);
     };
     const int ldx4 = (int)ldx * 4, ldw4 = (int)ldw * 4;
-    const int vA = (p * 64 + prow) * ldx4 + pch * 16, vB = (p * 32 + prow) * ldw4 + pch * 16;
-    auto load_piece = [&](int j, int kt) {
-      const auto v = j < 8 ? __builtin_amdgcn_raw_buffer_load_b128(rA, vA + j * 8 * ldx4, kt * (BK * 4), 0)
-                           : __builtin_amdgcn_raw_buffer_load_b128(rB, vB + (j - 8) * 8 * ldw4, kt * (BK * 4), 0);
+    const int vA = (p * 64 + prow) * ldx4 + pch * 32, vB = (p * 32 + prow) * ldw4 + pch * 32;
+    auto load_piece = [&](int j, int kt) {  // piece j = half (j & 1) of item j >> 1
+      const int q = j >> 1, h16 = (j & 1) * 16;
+      const auto v = q < 4 ? __builtin_amdgcn_raw_buffer_load_b128(rA, vA + q * 16 * ldx4 + h16, kt * (BK * 4), 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rB, vB + (q - 4) * 16 * ldw4 + h16, kt * (BK * 4), 0);
       return __builtin_bit_cast(f32x4, v);
     };
     // bias strip: wave p carries columns [32p, 32p+32) of the NEXT tile's strip in one register, loaded every step and stored
     // (into the strip buffer the MFMA waves are not reading) one step later — no branch and no wait of its own in this wave's
     // load stream, so the counted waits the compiler derives for the operand registers stay exact.  The store of a tile's first
     // step still carries the previous strip; the later steps overwrite it (K >= 2 k-steps, the launcher's condition)
-    auto bias_load = [&](int it) {
+    auto bias_col = [&](int it) {  // this lane's column of tile it's strip (clamped to the matrix); two scalar divisions: once per tile
       it = it < my_tiles ? it : my_tiles - 1;
       int m0, n0;
       walk.origin(it, m0, n0);
-      int n = n0 + 32 * p + (lane & 31);
-      n = n < N ? n : N - 1;
-      return bias ? bias[n] : 0.f;
+      const int n = n0 + 32 * p + (lane & 31);
+      return n < N ? n : N - 1;
     };
+    auto bias_load = [&](int n) { return bias ? bias[n] : 0.f; };
     auto bias_store = [&](int it, float v) { bias_lds[(it & 1) * BN + 32 * p + (lane & 31)] = v; };
     int l_it = 0, l_kt = 0;
     auto load_step = [&](f32x4 (&S)[12]) {
@@ -207,31 +223,38 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     // cut the step held in S into plane buffer `buf`, refilling every 16-byte register group with the same piece of the step
     // two k-steps later the moment it has been cut: ~92 KB of operands in flight per workgroup on 96 registers per lane
     auto cut_step = [&](f32x4 (&S)[12], int buf, bool reload) {
-      unsigned char* base = pmem + buf * P_BUF + prow * 64 + (pch & 1) * 8;
+      unsigned char* base = pmem + buf * P_BUF + prow * 64;
       if (reload && l_kt == 0 && l_it < my_tiles) set_tile(l_it);  // past the last step: the last tile's k-steps again (never read)
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        u32x2 p0, p1, p2;
+      for (int q = 0; q < 6; ++q) {
+        u32x2 a0, a1, a2, b0, b1, b2;
 #if STLT_X3_EXP & 4  // timing experiment: producers write uncut bits
-        p0 = u32x2{__builtin_bit_cast(unsigned, S[j][0]), __builtin_bit_cast(unsigned, S[j][1])}; p1 = u32x2{__builtin_bit_cast(unsigned, S[j][2]), __builtin_bit_cast(unsigned, S[j][3])}; p2 = p0;
+        a0 = u32x2{__builtin_bit_cast(unsigned, S[2 * q][0]), __builtin_bit_cast(unsigned, S[2 * q][1])}; a1 = u32x2{__builtin_bit_cast(unsigned, S[2 * q][2]), __builtin_bit_cast(unsigned, S[2 * q][3])}; a2 = a0;
+        b0 = u32x2{__builtin_bit_cast(unsigned, S[2 * q + 1][0]), __builtin_bit_cast(unsigned, S[2 * q + 1][1])}; b1 = u32x2{__builtin_bit_cast(unsigned, S[2 * q + 1][2]), __builtin_bit_cast(unsigned, S[2 * q + 1][3])}; b2 = b0;
 #else
-        split4(S[j], p0, p1, p2);
+        X3_T(0);
+        split4(S[2 * q], a0, a1, a2);
+        split4(S[2 * q + 1], b0, b1, b2);
+        X3_T(1);
 #endif
-        const int grp = ((pch >> 1) ^ (j & 3)) * 16;  // (row >> 3) & 3 == j & 3 for both operands
-        unsigned char* d = (j < 8 ? base + (p * 64 + j * 8) * 64 : base + P_B_BASE + (p * 32 + (j - 8) * 8) * 64) + grp;
-        const int ps = j < 8 ? P_A_PLANE : P_B_PLANE;
-        *reinterpret_cast<u32x2*>(d) = p0;
-        *reinterpret_cast<u32x2*>(d + ps) = p1;
-        *reinterpret_cast<u32x2*>(d + 2 * ps) = p2;
+        const int grp = (pch ^ ((2 * q + (lane >> 5)) & 3)) * 16;  // (row >> 3) & 3 for both operands' rows
+        unsigned char* d = (q < 4 ? base + (p * 64 + q * 16) * 64 : base + P_B_BASE + (p * 32 + (q - 4) * 16) * 64) + grp;
+        const int ps = q < 4 ? P_A_PLANE : P_B_PLANE;
+        *reinterpret_cast<u32x4*>(d) = u32x4{a0[0], a0[1], b0[0], b0[1]};
+        *reinterpret_cast<u32x4*>(d + ps) = u32x4{a1[0], a1[1], b1[0], b1[1]};
+        *reinterpret_cast<u32x4*>(d + 2 * ps) = u32x4{a2[0], a2[1], b2[0], b2[1]};
+        X3_T(2);
 #if !(STLT_X3_EXP & 8)  // timing experiment: no operand loads after the first two steps
-        if (reload) S[j] = load_piece(j, l_kt);
+        if (reload) { S[2 * q] = load_piece(2 * q, l_kt); S[2 * q + 1] = load_piece(2 * q + 1, l_kt); }
 #endif
+        X3_T(3);
       }
       if (reload) { if (++l_kt == nk) { ++l_it; l_kt = 0; } }
     };
     f32x4 S0[12], S1[12];
-    bias_store(0, bias_load(0));
-    float b_next = bias_load(1);
+    bias_store(0, bias_load(bias_col(0)));
+    int n_next = bias_col(1);
+    float b_next = bias_load(n_next);
     load_step(S0);
     load_step(S1);
     cut_step(S0, 0, true);  // step 0 -> buffer 0; S0 <- step 2
@@ -239,18 +262,21 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     __builtin_amdgcn_s_barrier();
     int w_it = 0, w_kt = 0;
     auto iter = [&](int i, f32x4 (&S)[12]) {  // while the MFMA waves multiply step i: cut step i + 1, load step i + 3
+      X3_T(0);
       bias_store(w_it + 1, b_next);
-      b_next = bias_load(w_it + 1);
+      X3_T(4);
+      b_next = bias_load(n_next);
+      X3_T(5);
       cut_step(S, (i + 1) & 1, true);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (++w_kt == nk) { ++w_it; w_kt = 0; }
+      X3_BARRIER();
+      if (++w_kt == nk) { ++w_it; w_kt = 0; n_next = bias_col(w_it + 1); }
     };
     for (int i = 0; i < total_steps; i += 2) {
       iter(i, S1);
       if (i + 1 >= total_steps) break;
       iter(i + 1, S0);
     }
+    X3_FINISH();
     return;
   }
 
@@ -287,6 +313,9 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     f.p2 = *reinterpret_cast<const u32x4*>(s + 2 * ps);
     return f;
   };
+#if STLT_X3_EXP & 16  // timing experiment: one product per block instead of six
+  auto six = [&](f32x16& d, const Planes& w, const Planes& x) { d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0 ^ w.p1 ^ w.p2), as_bf(x.p0 ^ x.p1 ^ x.p2), d, 0, 0, 0); };
+#else
   auto six = [&](f32x16& d, const Planes& w, const Planes& x) {
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p2), as_bf(x.p0), d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0), as_bf(x.p2), d, 0, 0, 0);
@@ -295,6 +324,7 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0), as_bf(x.p1), d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0), as_bf(x.p0), d, 0, 0, 0);
   };
+#endif
 
   __builtin_amdgcn_s_barrier();
   init_acc(0);
@@ -310,8 +340,7 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
       six(acc[1][0], wb0, xa1);
       six(acc[1][1], wb1, xa1);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    X3_BARRIER();
     if (++c_kt < nk) continue;
     int m0, n0;
     walk.origin(c_it, m0, n0);
@@ -320,6 +349,7 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     ++c_it;
     c_kt = 0;
   }
+  X3_FINISH();
 }
 
 int g_split_bf16 = -1;  // -1: read STLT_GEMM_SPLIT_BF16 once; 0 off; 6 on
@@ -349,7 +379,7 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
   const dim3 grid((unsigned)cus), block(X_THREADS);
-#define XL(ACTV, ADDV) hipLaunchKernelGGL((gemm_nt_bf16x3p_kernel<ACTV, ADDV>), grid, block, 0, s, x, ldx, w, ldw, bias, r, ldr, y, ldy, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n)
+#define XL(ACTV, ADDV) hipLaunchKernelGGL((gemm_nt_bf16x3p_kernel<ACTV, ADDV>), grid, block, 0, s, x, ldx, w, ldw, bias, r, ldr, y, ldy, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, g_stlt_debug_buf)
   if (r) XL(STLT_ACT_NONE, true);
   else if (act == STLT_ACT_GELU) XL(STLT_ACT_GELU, false);
   else if (act == STLT_ACT_RELU) XL(STLT_ACT_RELU, false);

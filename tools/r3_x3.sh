@@ -1,3 +1,5 @@
 #!/bin/bash
-mkdir -p gpurun_out/x3
-timeout 900 python -m pytest tests/test_gemm_bf16x3_gpu.py tests/test_kernels_gpu.py -x -q 2>&1 | tail -5
+for v in x3slp x3stamp0; do
+echo "== $v"
+STLT_HIP_LIB=build/variants/libstlt_hip_$v.so timeout 300 python tools/x3_stamps.py 2>&1 | grep -v "wave  [1235679]\|wave 1[01]\|amdgpu.ids"
+done
