@@ -17,6 +17,11 @@ done
 python tools/bench_gemm_train.py > $O/round3_gemm_train_shapes_b64.txt 2>&1
 python tools/bench_gemm.py --batch 1024 --iters 10 > $O/round3_gemm_shapes_b1024.txt 2>&1
 python tools/bench_mhsa.py > $O/round3_mhsa_ab.jsonl 2>&1
+python tools/bench_gemm_bf16x3.py > $O/round3_gemm_bf16x3.txt 2>&1
+if [ -f build/variants/libstlt_hip_x3stamp.so ]; then
+  STLT_HIP_LIB=build/variants/libstlt_hip_x3stamp.so python tools/x3_stamps.py > $O/round3_gemm_bf16x3_stamps.txt 2>&1
+  STLT_HIP_LIB=build/variants/libstlt_hip_x3stamp.so python tools/x3_stamps.py 229376 2304 768 >> $O/round3_gemm_bf16x3_stamps.txt 2>&1
+fi
 # 4. rocprofv3: kernel statistics of the default command, then the separate PMC passes (traffic, utilisation)
 cd /tmp
 rm -rf /tmp/ks /tmp/pf /tmp/pw /tmp/pu
@@ -27,6 +32,12 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o o --
 python3 $R/tools/pmc_traffic.py $O/round3_traffic_pmc.json /tmp/pf /tmp/pw
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pu -o o -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-skip-padding --no-split-bf16 --no-side-legs > /dev/null 2>&1
 python3 $R/tools/pmc_util.py $O/round3_util_pmc.json /tmp/pu
+# 4b. the same forward with the opt-in split-bf16 products, under the tracer (kernel statistics only)
+rm -rf /tmp/kx
+export STLT_GEMM_SPLIT_BF16=6
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kx -o o -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-skip-padding --no-split-bf16 --no-side-legs > $O/round3_bench_split_bf16_under_rocprof_b1024.log 2>&1
+unset STLT_GEMM_SPLIT_BF16
+cp $(find /tmp/kx -name '*kernel_stats.csv' | head -1) $O/round3_kernel_stats_split_bf16_b1024.csv
 # 5. the training step under the tracer: kernel statistics + the timeline of one step
 rm -rf /tmp/pt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o o -- python3 $R/bench.py --mode train --no-cpu-baseline --steps 6 --warmup 2 > $O/round3_train_under_rocprof.log 2>&1
