@@ -268,7 +268,10 @@ static bool fused_mhsa() {
 // qkv projection + attention core of a layer: ctx (M,d) from x (M,d)
 static int qkv_attention(const stlt_layer_params& lp, int64_t d, int64_t H, const float* x, int64_t M, int64_t S, int64_t L,
                          const uint8_t* kpm, int causal, int kid, float* qkv, float* ctx, hipStream_t s) {
-  if (causal && L == 32 && d == H * 64 && fused_mhsa()) return launch_mhsa_fused(x, lp.in_proj_w, lp.in_proj_b, kpm, S, L, H, d, ctx, s);
+  // with the opt-in split-bf16 products on, a temporal in-projection they take is faster as its own launch (+ the attention core)
+  // than inside the fused f32-MFMA kernel
+  if (causal && L == 32 && d == H * 64 && fused_mhsa() && !stlt_split_bf16_takes(M, 3 * d, d, d, d))
+    return launch_mhsa_fused(x, lp.in_proj_w, lp.in_proj_b, kpm, S, L, H, d, ctx, s);
   if (int e = launch_linear(x, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s)) return e;
   return launch_attn(qkv, kpm, causal, S, L, H, d / H, ctx, kid, s);
 }

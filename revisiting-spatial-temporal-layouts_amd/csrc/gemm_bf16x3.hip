@@ -363,19 +363,27 @@ extern "C" int stlt_set_gemm_split_bf16(int terms) {
 }
 
 // *taken = true when the product was launched on the BF16 matrix cores; false: not enabled / not a shape of this kernel
+// does the split-bf16 kernel take this nn.Linear forward (when it is switched on)?  Whole-tile launches of a contraction of at
+// least two k-steps that fill >= 0.9 of the chip's workgroups; everything else keeps gemm.hip's kernel (stream-K)
+bool stlt_split_bf16_takes(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
+  if (g_split_bf16 < 0) { const char* e = getenv("STLT_GEMM_SPLIT_BF16"); g_split_bf16 = (e && atoi(e) == 6) ? 6 : 0; }
+  if (g_split_bf16 != 6) return false;
+  if (K % BK != 0 || K < 2 * BK || ldx % 4 != 0 || ldw % 4 != 0 || ldx >= (1 << 21) || ldw >= (1 << 21) || M <= 0 || N <= 0 || M > 0x7fffff00LL || N > 0x7fffff00LL) return false;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
+  const int64_t cus = stlt_device_cus();
+  if ((cus & 7) != 0 || n_tiles > 0x7fffffffLL) return false;
+  const int64_t rounds = (n_tiles + cus - 1) / cus;
+  return (double)n_tiles / (double)(rounds * cus) >= 0.9;
+}
+
 int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
                          int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken) {
   *taken = false;
-  if (g_split_bf16 < 0) { const char* e = getenv("STLT_GEMM_SPLIT_BF16"); g_split_bf16 = (e && atoi(e) == 6) ? 6 : 0; }
-  if (g_split_bf16 != 6) return 0;
-  if (K % BK != 0 || K < 2 * BK || ldx % 4 != 0 || ldw % 4 != 0 || ldx >= (1 << 21) || ldw >= (1 << 21) || M <= 0 || N <= 0 || M > 0x7fffff00LL || N > 0x7fffff00LL) return 0;
+  if (!stlt_split_bf16_takes(M, N, K, ldx, ldw)) return 0;
   if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU) return 0;
   if (r && act != STLT_ACT_NONE) return 0;
-  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, n_tiles = tiles_m * tiles_n;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int64_t cus = stlt_device_cus();
-  if ((cus & 7) != 0 || n_tiles > 0x7fffffffLL) return 0;
-  const int64_t rounds = (n_tiles + cus - 1) / cus;
-  if ((double)n_tiles / (double)(rounds * cus) < 0.9) return 0;  // under-filled launches keep gemm.hip's stream-K
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
   const dim3 grid((unsigned)cus), block(X_THREADS);
