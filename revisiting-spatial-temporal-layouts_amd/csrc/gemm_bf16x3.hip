@@ -26,6 +26,9 @@
 #ifndef STLT_X3_STAMP
 #define STLT_X3_STAMP 0
 #endif
+#ifndef STLT_X3_MFMA16
+#define STLT_X3_MFMA16 1  // 1: v_mfma_f32_16x16x32_bf16 blocks (one MFMA spans the 32-k step), 0: 32x32x16 blocks
+#endif
 #ifndef STLT_X3_EXP
 #define STLT_X3_EXP 0  // timing experiments (wrong results): 4 = producers write uncut bits, 8 = no operand loads after the prologue, 16 = one MFMA per block instead of six
 #endif
@@ -99,6 +102,43 @@ __device__ __forceinline__ void store_block(const f32x16 (&acc)[2][2], int m0, i
       f32x4 val;
 #pragma unroll
       for (int j = 0; j < 4; ++j) val[j] = acc[a][g >> 2][4 * (g & 3) + j];
+      if (vec_ok) {
+        if (ADD) val += *reinterpret_cast<const f32x4*>(R + (int64_t)m * ldr + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ACT == STLT_ACT_GELU) val[j] = gelu_bfree(val[j]);
+          if (ACT == STLT_ACT_RELU) val[j] = fmaxf(val[j], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(Y + (int64_t)m * ldy + n) = val;
+      } else if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n + j < N) {
+            float x = val[j];
+            if (ADD) x += R[(int64_t)m * ldr + n + j];
+            if (ACT == STLT_ACT_GELU) x = gelu_bfree(x);
+            if (ACT == STLT_ACT_RELU) x = fmaxf(x, 0.f);
+            Y[(int64_t)m * ldy + n + j] = x;
+          }
+        }
+      }
+    }
+  }
+}
+
+// the same 64 x 64 block held as 4 x 4 blocks of 16 x 16 (v_mfma_f32_16x16x32_bf16, transposed: lane = output row lane & 15,
+// its four registers = columns 4 (lane >> 4) .. + 3 of the block)
+template <int ACT, bool ADD>
+__device__ __forceinline__ void store_block16(const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lr16, int kq, const float* __restrict__ R,
+                                              int64_t ldr, float* __restrict__ Y, int64_t ldy, int M, int N) {
+  const bool vec_ok = (m0 + BM <= M) && (n0 + BN <= N) && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0 && (!ADD || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0));
+#pragma unroll
+  for (int bm = 0; bm < 4; ++bm) {
+    const int m = m0 + wm * 64 + bm * 16 + lr16;
+#pragma unroll
+    for (int bn = 0; bn < 4; ++bn) {
+      const int n = n0 + wn * 64 + bn * 16 + 4 * kq;
+      f32x4 val = acc[bn][bm];
       if (vec_ok) {
         if (ADD) val += *reinterpret_cast<const f32x4*>(R + (int64_t)m * ldr + n);
 #pragma unroll
@@ -237,7 +277,11 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
         split4(S[2 * q + 1], b0, b1, b2);
         X3_T(1);
 #endif
+#if STLT_X3_MFMA16
+        const int grp = (pch ^ ((0 - (prow >> 2)) & 3)) * 16;     // the 16x16x32 fragment layout's swizzle: group ^ T[(row >> 2) & 3], T = {0, 3, 2, 1}
+#else
         const int grp = (pch ^ ((2 * q + (lane >> 5)) & 3)) * 16;  // (row >> 3) & 3 for both operands' rows
+#endif
         unsigned char* d = (q < 4 ? base + (p * 64 + q * 16) * 64 : base + P_B_BASE + (p * 32 + (q - 4) * 16) * 64) + grp;
         const int ps = q < 4 ? P_A_PLANE : P_B_PLANE;
         *reinterpret_cast<u32x4*>(d) = u32x4{a0[0], a0[1], b0[0], b0[1]};
@@ -282,6 +326,68 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
 
   // ---- MFMA waves
   const int wm = wave >> 1, wn = wave & 1;
+#if STLT_X3_MFMA16
+  // 16 blocks of 16 x 16 per wave; lane (r = lane & 15, kq = lane >> 4) holds k = 8 kq .. + 7 of row r of a fragment: one
+  // ds_read_b128 per plane, one MFMA per piece pair and k-step.  The row's four 16-byte groups sit at kq ^ T[(row >> 2) & 3],
+  // T = {0, 3, 2, 1}: every 16-lane group of ds_read_b128 ({0-3, 12-15, 20-27}, ...) then covers the bank row's 16 slots once.
+  // (In bare MFMA loops the 16x16x32 form delivers ~1.15x the FLOP/s of 32x32x16 at the same cycles per FLOP — it draws less
+  // power, MI355X_MICROARCH.md — and this kernel is power-bound.)
+  const int lr16 = lane & 15, kq = lane >> 4;
+  const int sw16 = (kq ^ ((0 - (lr16 >> 2)) & 3)) * 16;
+  const int a_off = (wm * 64 + lr16) * 64 + sw16, b_off = P_B_BASE + (wn * 64 + lr16) * 64 + sw16;
+  f32x4 acc[4][4];  // [bn][bm]
+  auto init_acc = [&](int it) {
+#pragma unroll
+    for (int bn = 0; bn < 4; ++bn) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (bias) v = *reinterpret_cast<const f32x4*>(bias_lds + (it & 1) * BN + wn * 64 + bn * 16 + 4 * kq);
+#pragma unroll
+      for (int bm = 0; bm < 4; ++bm) acc[bn][bm] = v;
+    }
+  };
+  auto read_planes = [&](int buf, int off, int ps) {
+    const unsigned char* s = pmem + buf * P_BUF + off;
+    Planes f;
+    f.p0 = *reinterpret_cast<const u32x4*>(s);
+    f.p1 = *reinterpret_cast<const u32x4*>(s + ps);
+    f.p2 = *reinterpret_cast<const u32x4*>(s + 2 * ps);
+    return f;
+  };
+  auto six = [&](f32x4& d, const Planes& w, const Planes& x) {
+#if !(STLT_X3_EXP & 16)
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w.p2), as_bf(x.p0), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w.p0), as_bf(x.p2), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w.p1), as_bf(x.p1), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w.p1), as_bf(x.p0), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w.p0), as_bf(x.p1), d, 0, 0, 0);
+#endif
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w.p0), as_bf(x.p0), d, 0, 0, 0);
+  };
+
+  __builtin_amdgcn_s_barrier();
+  init_acc(0);
+  int c_it = 0, c_kt = 0;
+  for (int step = 0; step < total_steps; ++step) {
+    const int buf = step & 1;
+    Planes wf[4];
+#pragma unroll
+    for (int bn = 0; bn < 4; ++bn) wf[bn] = read_planes(buf, b_off + bn * 16 * 64, P_B_PLANE);
+#pragma unroll
+    for (int bm = 0; bm < 4; ++bm) {
+      const Planes xf = read_planes(buf, a_off + bm * 16 * 64, P_A_PLANE);
+#pragma unroll
+      for (int bn = 0; bn < 4; ++bn) six(acc[bn][bm], wf[bn], xf);
+    }
+    X3_BARRIER();
+    if (++c_kt < nk) continue;
+    int m0, n0;
+    walk.origin(c_it, m0, n0);
+    store_block16<ACT, ADD>(acc, m0, n0, wm, wn, lr16, kq, R, ldr, Y, ldy, M, N);
+    if (c_it + 1 < my_tiles) init_acc(c_it + 1);
+    ++c_it;
+    c_kt = 0;
+  }
+#else
   const int sw = (lr >> 3) & 3;
   const int a_off = (wm * 64 + lr) * 64, b_off = P_B_BASE + (wn * 64 + lr) * 64;
   f32x16 acc[2][2];
@@ -349,6 +455,7 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     ++c_it;
     c_kt = 0;
   }
+#endif
   X3_FINISH();
 }
 
