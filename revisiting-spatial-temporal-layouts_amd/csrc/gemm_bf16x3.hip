@@ -5,29 +5,26 @@
 // bits of a - a0, a2 = a - a0 - a1 rounded to bf16: 24 significand bits in all, the subtractions are exact) and a product a·b
 // is taken as the six piece products whose weight is at least 2^-24 of it,
 //     a0·b0 + a0·b1 + a1·b0 + a1·b1 + a0·b2 + a2·b0,
-// each a v_mfma_f32_32x32x16_bf16 accumulating in f32 (smallest terms first): products of bf16 pieces are exact in f32, the
+// each a v_mfma_f32_16x16x32_bf16 accumulating in f32 (smallest terms first): products of bf16 pieces are exact in f32, the
 // dropped terms (a1·b2, a2·b1, a2·b2) are below 2^-24 |a·b| — the rounding an f32 multiply makes anyway.  Measured error
 // against an fp64 product: at or below the f32-MFMA kernel's on every forward shape (profiles/round3_gemm_bf16x3.txt).
 // The bf16 MFMA issues 16x the FLOPs of the f32 one per cycle, six of them make one f32-equivalent product: 2.7x on paper
-// (419 TFLOP/s-equivalent); the MFMA waves alone sustain ≈ 255 of that here (operands ready in LDS, nothing else running).
+// (419 TFLOP/s-equivalent).  Measured 215-235 = 1.62-1.79x the f32 kernel: the chip is power-bound under bf16 MFMAs (it runs
+// this kernel at ~1.5 GHz) and after that the producer waves set the k-step; DESIGN.md section 3 has the numbers.
 //
-// Structure: 256 x 128 x 32 tiles, 8 MFMA waves (4 x 2 of 64 x 64, transposed accumulators, bias as their initial value) and
-// 4 PRODUCER waves, persistent workgroups walking gemm.hip's XCD-contiguous band-major tile order, one barrier per k-step.
-// The producers load the f32 operands with buffer loads into registers (two k-steps ahead, ~92 KB in flight per workgroup),
-// cut every element ONCE per workgroup and write three bf16 plane images to LDS; the MFMA waves read ready bf16 fragments and
-// issue nothing but ds_read_b128 and MFMAs.  (First build, kept in the history: operands by LDS-DMA as f32, every MFMA wave
-// cutting its own fragments in registers — each X fragment cut twice and each W fragment four times per workgroup, 352 VALU
-// issues per wave and k-step beside 48 MFMAs, 175-188 TFLOP/s whether or not the cut was interleaved with the MFMAs by
-// sched_group_barrier; without the cut 250-268: the vector issue port was the bound.)
+// Structure: 256 x 128 x 32 tiles, 8 MFMA waves (4 x 2 of 64 x 64 = 4 x 4 blocks of 16 x 16, transposed accumulators, bias as
+// their initial value) and 4 PRODUCER waves, persistent workgroups walking gemm.hip's XCD-contiguous band-major tile order,
+// one barrier per k-step.  The producers load the f32 operands with buffer loads into registers (two k-steps ahead, ~92 KB in
+// flight per workgroup), cut every element ONCE per workgroup and write three bf16 plane images to LDS; the MFMA waves read
+// ready bf16 fragments and issue nothing but ds_read_b128 and MFMAs.  History (git): every MFMA wave cutting its own fragments
+// in registers (f750abb: 175-188 TFLOP/s, vector-issue bound); 32 x 32 x 16 blocks (180-199, power-bound: that MFMA form draws
+// more per FLOP); a four-slot ring of 16-k steps (profiles/round3_gemm_bf16x3_ring_build.patch: no gain).
 // Forward (NT) layout only, whole-tile launches only (no stream-K): shapes the launcher does not take keep gemm.hip's kernel.
 #include <cstdlib>
 #include "common.h"
 
 #ifndef STLT_X3_STAMP
 #define STLT_X3_STAMP 0
-#endif
-#ifndef STLT_X3_MFMA16
-#define STLT_X3_MFMA16 1  // 1: v_mfma_f32_16x16x32_bf16 blocks (one MFMA spans the 32-k step), 0: 32x32x16 blocks
 #endif
 #ifndef STLT_X3_EXP
 #define STLT_X3_EXP 0  // timing experiments (wrong results): 4 = producers write uncut bits, 8 = no operand loads after the prologue, 16 = one MFMA per block instead of six
@@ -88,45 +85,7 @@ struct TileWalk {
   }
 };
 
-// the 64 x 64 block of MFMA wave (wm, wn), transposed accumulators (lane = output row, registers = 4-column groups)
-template <int ACT, bool ADD>
-__device__ __forceinline__ void store_block(const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lr, int lh, const float* __restrict__ R,
-                                            int64_t ldr, float* __restrict__ Y, int64_t ldy, int M, int N) {
-  const bool vec_ok = (m0 + BM <= M) && (n0 + BN <= N) && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0 && (!ADD || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0));
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int m = m0 + wm * 64 + a * 32 + lr;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int n = n0 + wn * 64 + (g >> 2) * 32 + 8 * (g & 3) + 4 * lh;
-      f32x4 val;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) val[j] = acc[a][g >> 2][4 * (g & 3) + j];
-      if (vec_ok) {
-        if (ADD) val += *reinterpret_cast<const f32x4*>(R + (int64_t)m * ldr + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (ACT == STLT_ACT_GELU) val[j] = gelu_bfree(val[j]);
-          if (ACT == STLT_ACT_RELU) val[j] = fmaxf(val[j], 0.f);
-        }
-        *reinterpret_cast<f32x4*>(Y + (int64_t)m * ldy + n) = val;
-      } else if (m < M) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (n + j < N) {
-            float x = val[j];
-            if (ADD) x += R[(int64_t)m * ldr + n + j];
-            if (ACT == STLT_ACT_GELU) x = gelu_bfree(x);
-            if (ACT == STLT_ACT_RELU) x = fmaxf(x, 0.f);
-            Y[(int64_t)m * ldy + n + j] = x;
-          }
-        }
-      }
-    }
-  }
-}
-
-// the same 64 x 64 block held as 4 x 4 blocks of 16 x 16 (v_mfma_f32_16x16x32_bf16, transposed: lane = output row lane & 15,
+// the 64 x 64 block of MFMA wave (wm, wn) held as 4 x 4 blocks of 16 x 16 (v_mfma_f32_16x16x32_bf16, transposed: lane = output row lane & 15,
 // its four registers = columns 4 (lane >> 4) .. + 3 of the block)
 template <int ACT, bool ADD>
 __device__ __forceinline__ void store_block16(const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lr16, int kq, const float* __restrict__ R,
@@ -164,8 +123,8 @@ __device__ __forceinline__ void store_block16(const f32x4 (&acc)[4][4], int m0, 
 }
 
 // LDS: two plane buffers of 72 KB (X planes 3 x 256 rows x 64 B, W planes 3 x 128 rows x 64 B; a row's four 16-byte groups
-// at positions g ^ ((row >> 3) & 3): the 16-lane groups of ds_read_b128 — lanes {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md
-// LDS table) — then cover the 16 slots of the 256-byte bank row once each at a 64-byte row pitch) + the bias strips.
+// at positions g ^ T[(row >> 2) & 3], T = {0, 3, 2, 1}: the 16-lane groups of ds_read_b128 — lanes {0-3, 12-15, 20-27}, ...
+// (MI355X_MICROARCH.md LDS table) — then cover the 16 slots of the 256-byte bank row once each) + the bias strips.
 constexpr int P_A_PLANE = BM * 64, P_B_PLANE = BN * 64;       // bytes of one plane image of one k-step
 constexpr int P_B_BASE = 3 * P_A_PLANE;
 constexpr int P_BUF = 3 * (P_A_PLANE + P_B_PLANE);            // 73728
@@ -196,7 +155,6 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31, lh = lane >> 5;
   const int nk = K / BK;
   const TileWalk walk(tiles_m, tiles_n);
   const int my_tiles = walk.my_tiles;
@@ -277,11 +235,7 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
         split4(S[2 * q + 1], b0, b1, b2);
         X3_T(1);
 #endif
-#if STLT_X3_MFMA16
-        const int grp = (pch ^ ((0 - (prow >> 2)) & 3)) * 16;     // the 16x16x32 fragment layout's swizzle: group ^ T[(row >> 2) & 3], T = {0, 3, 2, 1}
-#else
-        const int grp = (pch ^ ((2 * q + (lane >> 5)) & 3)) * 16;  // (row >> 3) & 3 for both operands' rows
-#endif
+        const int grp = (pch ^ ((0 - (prow >> 2)) & 3)) * 16;  // the fragment layout's swizzle: group ^ T[(row >> 2) & 3], T = {0, 3, 2, 1}
         unsigned char* d = (q < 4 ? base + (p * 64 + q * 16) * 64 : base + P_B_BASE + (p * 32 + (q - 4) * 16) * 64) + grp;
         const int ps = q < 4 ? P_A_PLANE : P_B_PLANE;
         *reinterpret_cast<u32x4*>(d) = u32x4{a0[0], a0[1], b0[0], b0[1]};
@@ -326,7 +280,6 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
 
   // ---- MFMA waves
   const int wm = wave >> 1, wn = wave & 1;
-#if STLT_X3_MFMA16
   // 16 blocks of 16 x 16 per wave; lane (r = lane & 15, kq = lane >> 4) holds k = 8 kq .. + 7 of row r of a fragment: one
   // ds_read_b128 per plane, one MFMA per piece pair and k-step.  The row's four 16-byte groups sit at kq ^ T[(row >> 2) & 3],
   // T = {0, 3, 2, 1}: every 16-lane group of ds_read_b128 ({0-3, 12-15, 20-27}, ...) then covers the bank row's 16 slots once.
@@ -387,75 +340,6 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     ++c_it;
     c_kt = 0;
   }
-#else
-  const int sw = (lr >> 3) & 3;
-  const int a_off = (wm * 64 + lr) * 64, b_off = P_B_BASE + (wn * 64 + lr) * 64;
-  f32x16 acc[2][2];
-  auto init_acc = [&](int it) {
-    if (bias) {
-      const float* src = bias_lds + (it & 1) * BN + wn * 64 + 4 * lh;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + b * 32 + 8 * q);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { acc[0][b][4 * q + j] = v[j]; acc[1][b][4 * q + j] = v[j]; }
-        }
-    } else {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    }
-  };
-  auto read_planes = [&](int buf, int kb, int off, int ps) {
-    const unsigned char* s = pmem + buf * P_BUF + off + (((2 * kb + lh) ^ sw) * 16);
-    Planes f;
-    f.p0 = *reinterpret_cast<const u32x4*>(s);
-    f.p1 = *reinterpret_cast<const u32x4*>(s + ps);
-    f.p2 = *reinterpret_cast<const u32x4*>(s + 2 * ps);
-    return f;
-  };
-#if STLT_X3_EXP & 16  // timing experiment: one product per block instead of six
-  auto six = [&](f32x16& d, const Planes& w, const Planes& x) { d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0 ^ w.p1 ^ w.p2), as_bf(x.p0 ^ x.p1 ^ x.p2), d, 0, 0, 0); };
-#else
-  auto six = [&](f32x16& d, const Planes& w, const Planes& x) {
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p2), as_bf(x.p0), d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0), as_bf(x.p2), d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p1), as_bf(x.p1), d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p1), as_bf(x.p0), d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0), as_bf(x.p1), d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w.p0), as_bf(x.p0), d, 0, 0, 0);
-  };
-#endif
-
-  __builtin_amdgcn_s_barrier();
-  init_acc(0);
-  int c_it = 0, c_kt = 0;
-  for (int step = 0; step < total_steps; ++step) {
-    const int buf = step & 1;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const Planes xa0 = read_planes(buf, kb, a_off, P_A_PLANE), wb0 = read_planes(buf, kb, b_off, P_B_PLANE);
-      const Planes wb1 = read_planes(buf, kb, b_off + 32 * 64, P_B_PLANE), xa1 = read_planes(buf, kb, a_off + 32 * 64, P_A_PLANE);
-      six(acc[0][0], wb0, xa0);
-      six(acc[0][1], wb1, xa0);
-      six(acc[1][0], wb0, xa1);
-      six(acc[1][1], wb1, xa1);
-    }
-    X3_BARRIER();
-    if (++c_kt < nk) continue;
-    int m0, n0;
-    walk.origin(c_it, m0, n0);
-    store_block<ACT, ADD>(acc, m0, n0, wm, wn, lr, lh, R, ldr, Y, ldy, M, N);
-    if (c_it + 1 < my_tiles) init_acc(c_it + 1);
-    ++c_it;
-    c_kt = 0;
-  }
-#endif
   X3_FINISH();
 }
 
