@@ -642,7 +642,7 @@ def main():
                                      "vs_f32_mfma_peak": round(x3_fl / (x3_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if x3_ms > 0 else None,
                                      "logit_max_abs_diff_vs_f32_forward": float((x3_logits - logits).abs().max()),
                                      "logit_max_abs_diff_vs_oracle": None,  # filled by the cpu_baseline leg (same 32-clip oracle sample as `logit_max_abs_diff`)
-                                     "note": "opt-in (STLT_GEMM_SPLIT_BF16=6): f32 operands cut into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per f32 product, f32 accumulation; whole-tile launches with fill >= 0.9 only, the rest stay on the f32-MFMA kernel"}
+                                     "note": "opt-in (STLT_GEMM_SPLIT_BF16=6): f32 operands cut into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 per f32 product, f32 accumulation; whole-tile launches filling at least half of the workgroups, the rest stay on the f32-MFMA stream-K kernel"}
             except Exception as exc:  # the secondary legs must never cost the main line
                 out["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
             finally:

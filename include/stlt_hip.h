@@ -443,7 +443,7 @@ size_t stlt_debug_buffer_bytes(void);  /* (54 * compute units of the current dev
 /* Opt-in "split-bf16" build of the nn.Linear forward (csrc/gemm_bf16x3.hip): every f32 operand element is cut in registers into
  * three bf16 pieces and a product is the six piece products of weight >= 2^-24 on v_mfma_f32_16x16x32_bf16, accumulated in f32 —
  * the dropped terms are below the rounding of an f32 multiply.  terms = 6 turns it on for whole-tile forward launches
- * (K % 32 == 0, launch fill >= 0.9; everything else keeps the f32-MFMA kernel), 0 turns it off; the STLT_GEMM_SPLIT_BF16=6
+ * (K % 32 == 0, K >= 64, rounds of whole tiles filling at least half of the workgroups; everything else keeps the f32-MFMA kernel), 0 turns it off; the STLT_GEMM_SPLIT_BF16=6
  * environment variable is the initial value.  Not the default: results agree with the f32 kernel's to f32 rounding but are
  * not bit-identical to it, and bench.py never reports it as `value` (it is a side object of the JSON line).  STLT_EINVAL
  * for other values. */

@@ -355,7 +355,9 @@ extern "C" int stlt_set_gemm_split_bf16(int terms) {
 
 // *taken = true when the product was launched on the BF16 matrix cores; false: not enabled / not a shape of this kernel
 // does the split-bf16 kernel take this nn.Linear forward (when it is switched on)?  Whole-tile launches of a contraction of at
-// least two k-steps that fill >= 0.9 of the chip's workgroups; everything else keeps gemm.hip's kernel (stream-K)
+// least two k-steps whose rounds of whole tiles fill at least half of the chip's workgroups (STLT_X3_MIN_FILL, default 0.5:
+// measured on the cfg2 forward at 16 / 64 / 256 clips and cfg4 at 64, thresholds 0.3 - 0.6 are within 1 % of each other, 0.9
+// and 0.15 lose 10 - 20 %); below that gemm.hip's stream-K kernel keeps the launch
 bool stlt_split_bf16_takes(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
   if (g_split_bf16 < 0) { const char* e = getenv("STLT_GEMM_SPLIT_BF16"); g_split_bf16 = (e && atoi(e) == 6) ? 6 : 0; }
   if (g_split_bf16 != 6) return false;
@@ -364,7 +366,8 @@ bool stlt_split_bf16_takes(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t
   const int64_t cus = stlt_device_cus();
   if ((cus & 7) != 0 || n_tiles > 0x7fffffffLL) return false;
   const int64_t rounds = (n_tiles + cus - 1) / cus;
-  return (double)n_tiles / (double)(rounds * cus) >= 0.9;
+  static const double min_fill = [] { const char* e = getenv("STLT_X3_MIN_FILL"); return e ? atof(e) : 0.5; }();
+  return (double)n_tiles / (double)(rounds * cus) >= min_fill;
 }
 
 int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
