@@ -173,6 +173,23 @@ def side_forward_leg(pkg, torch, dev, config, B, steps, warmup):
     at = _attn_rooflines(k_ms, B, T, N, d)
     fused = mhsa_fused_roofline(k_ms, B, T, d, c["num_attention_heads"])
     extra = {"roofline_mhsa_fused": fused} if fused else {}
+    try:  # the same leg with the opt-in split-bf16 products (beside the leg's numbers, as on the main line)
+        ref_logits = step().clone()
+        pkg.ops.set_gemm_split_bf16(6)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            x3 = step()
+        torch.cuda.synchronize(dev)
+        x3_sec = (time.perf_counter() - t0) / steps
+        extra["split_bf16"] = {"value": round(B / x3_sec, 2), "unit": "clips/s", "ms_per_step": round(x3_sec * 1e3, 4),
+                               "logit_max_abs_diff_vs_f32_forward": float((x3 - ref_logits).abs().max())}
+    except Exception as exc:
+        extra["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        pkg.ops.set_gemm_split_bf16(0)
     return {**extra, "workload": f"{config}: STLT forward, T={T}, N={N}, d={d}, {c['num_classes']} classes", "per_gpu_batch": B, "steps": steps, "warmup": warmup,
             "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
