@@ -94,3 +94,25 @@ def test_split_bf16_forward_logits_agree_with_the_f32_forward(pkg, split):
         l6 = model(batch)["stlt"].clone()
     assert not torch.equal(l0, l6), "the split-bf16 kernel did not run inside the forward"
     assert (l0 - l6).abs().max().item() <= 2e-4
+
+
+def test_split_bf16_wide_dynamic_range(pkg, split):
+    """Rows of X scaled over 24 decades and columns of W over 12: the error relative to sum |x||w| (what an f32 dot product
+    guarantees) stays within 1.5x the f32 kernel's — the three pieces follow each element's own exponent."""
+    M, N, K = 16384, 512, 256
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(M, K, device=DEV, generator=g) * torch.pow(10.0, torch.rand(M, 1, device=DEV, generator=g) * 24 - 12)
+    w = torch.randn(N, K, device=DEV, generator=g) * torch.pow(10.0, torch.rand(N, 1, device=DEV, generator=g) * 12 - 6)
+    with pkg.ops.gemm_scratch(DEV):
+        split(0)
+        y0 = pkg.ops.linear(x, w, None)
+        split(6)
+        y6 = pkg.ops.linear(x, w, None)
+    idx = torch.randperm(M, device=DEV, generator=g)[:1024]
+    ref = x[idx].double() @ w.double().t()
+    cond = x[idx].double().abs() @ w.double().abs().t()
+    e0 = ((y0[idx].double() - ref).abs() / cond).max().item()
+    e6 = ((y6[idx].double() - ref).abs() / cond).max().item()
+    assert not torch.equal(y0, y6)
+    assert torch.isfinite(y6).all()
+    assert e6 <= 1.5 * e0 and e6 < 2e-6, (e0, e6)
