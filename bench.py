@@ -274,7 +274,24 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
     k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    return {"workload": f"{config}: STLT optimisation step (forward with tape, loss, reverse sweep, clip 5.0, AdamW), dropout 0.1", "per_gpu_batch": B,
+    x3 = {}
+    try:  # the same step with the forward products on the opt-in split-bf16 kernel (the backward products stay f32 MFMA)
+        pkg.ops.set_gemm_split_bf16(6)
+        for _ in range(warmup):
+            tr.step(batch)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r3 = tr.step(batch)
+        torch.cuda.synchronize(dev)
+        x3_sec = (time.perf_counter() - t0) / steps
+        x3 = {"split_bf16": {"value": round(B / x3_sec, 2), "unit": "clips/s", "ms_per_step": round(x3_sec * 1e3, 4), "loss": float(r3["loss"]),
+                             "note": "forward products only; loss and gradients of one step agree with the f32 step to rounding (tests/test_gemm_bf16x3_gpu.py)"}}
+    except Exception as exc:
+        x3 = {"split_bf16": {"error": f"{type(exc).__name__}: {exc}"}}
+    finally:
+        pkg.ops.set_gemm_split_bf16(0)
+    return {**x3, "workload": f"{config}: STLT optimisation step (forward with tape, loss, reverse sweep, clip 5.0, AdamW), dropout 0.1", "per_gpu_batch": B,
             "steps": steps, "warmup": warmup, "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4),
             "roofline": {"kernel": "gemm_nt_kernel, forward + dX + dW products", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4),
