@@ -275,7 +275,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     x3 = {}
-    try:  # the same step with the forward products on the opt-in split-bf16 kernel (the backward products stay f32 MFMA)
+    try:  # the same step with the forward and dX products on the opt-in split-bf16 kernel (the weight gradients stay f32 MFMA)
         pkg.ops.set_gemm_split_bf16(6)
         for _ in range(warmup):
             tr.step(batch)
@@ -286,7 +286,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
         torch.cuda.synchronize(dev)
         x3_sec = (time.perf_counter() - t0) / steps
         x3 = {"split_bf16": {"value": round(B / x3_sec, 2), "unit": "clips/s", "ms_per_step": round(x3_sec * 1e3, 4), "loss": float(r3["loss"]),
-                             "note": "forward products only; loss and gradients of one step agree with the f32 step to rounding (tests/test_gemm_bf16x3_gpu.py)"}}
+                             "note": "forward and input-gradient (dX) products; weight-gradient products stay f32 MFMA; loss and gradients of one step agree with the f32 step to rounding (tests/test_gemm_bf16x3_gpu.py)"}}
     except Exception as exc:
         x3 = {"split_bf16": {"error": f"{type(exc).__name__}: {exc}"}}
     finally:

@@ -115,6 +115,39 @@ static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k
   return launch_reduce_slabs(sc.slabs, n_out * k_in, split, g_w, n_out * k_in, 1, s);
 }
 
+// W (n_out, k_in) -> Wt (k_in, n_out): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, int n_out, int k_in, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, k = k0 + tx;
+    if (n < n_out && k < k_in) tile[ty + 8 * i][tx] = w[(int64_t)n * k_in + k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i, n = n0 + tx;
+    if (n < n_out && k < k_in) wt[(int64_t)k * n_out + n] = tile[tx][ty + 8 * i];
+  }
+}
+
+// C (rows, k_in) = dY (rows, n_out)·W (n_out, k_in) (+ R): the input gradient of a Linear.  With the opt-in split-bf16 products
+// switched on and a launch they take, W is transposed into the (then unused) split-K slab buffer — 5-10 us for 0.6-2.4 M
+// elements — and the product runs as the NT form the split-bf16 kernel has (gemm_bf16x3.hip); otherwise the f32-MFMA NN kernel.
+static int dx_product(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
+                      int64_t ldc, int64_t rows, const Scratch& sc, hipStream_t s) {
+  if (sc.sk && (size_t)(n_out * k_in) <= sc.slab_floats && stlt_split_bf16_takes(rows, k_in, n_out, ld_dy, n_out)) {
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)((k_in + 31) / 32), (unsigned)((n_out + 31) / 32)), dim3(256), 0, s, w, (int)n_out, (int)k_in, sc.slabs);
+    TRY(stlt_check_launch("weight_transpose_kernel"));
+    bool taken = false;
+    TRY(launch_linear_bf16x3(dy, ld_dy, sc.slabs, n_out, nullptr, r, ldr, c, ldc, rows, k_in, n_out, STLT_ACT_NONE, s, &taken));
+    if (taken) return 0;
+  }
+  return launch_gemm(0, 1, dy, ld_dy, w, k_in, nullptr, r, ldr, c, ldc, 0, rows, k_in, n_out, 1, STLT_ACT_NONE, s);
+}
+
 // The weight gradients of a layer as ONE grouped stream-K launch (gemm.hip: launch_weight_grad_group) when stream-K
 // scratch is lent, else product by product.  Every CU gets an equal share of the four products' k-steps: one pipeline
 // fill, at most two partial tiles per workgroup and one fix-up for the layer instead of four of each.
@@ -137,12 +170,12 @@ static int weight_grad_all(const StltWeightGradItem* items, int n, const Scratch
 static int ffn_hidden_backward(const float* df, const float* lin2_w, const float* u, float* du, int64_t rows, int64_t d, float* g_lin1_b,
                                const Scratch& sc, StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s) {
   static const bool fused = [] { const char* e = getenv("STLT_FUSE_GELU_BWD"); return e ? atoi(e) != 0 : true; }();
-  if (fused && g_lin1_b) {
+  if (fused && g_lin1_b && !(sc.sk && stlt_split_bf16_takes(rows, 4 * d, d, d, d))) {  // (the split-bf16 product has no GELU-backward epilogue)
     const StltGemmEpi epi{dr, site, drop_rows, sc.red};
     TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi));
     return launch_reduce_slabs(sc.red, 4 * d, (int)((rows + 255) / 256 * 16), g_lin1_b, 4 * d, 1, s);
   }
-  TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, nullptr, 0, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_NONE, s));  // dh
+  TRY(dx_product(df, d, lin2_w, d, 4 * d, nullptr, 0, du, 4 * d, rows, sc, s));  // dh
   if (g_lin1_b) return launch_gelu_bwd_colsum(du, u, du, rows, 4 * d, g_lin1_b, sc.red, s, dr, site, drop_rows);  // du; lin1_b += colsum(du)
   return launch_gelu_bwd(du, u, du, rows * 4 * d, s, dr, site, drop_rows, 4 * d);
 }
@@ -169,17 +202,17 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
   // h = drop(gelu(u)): bufH = du = drop(df·W2) ∘ gelu'(u); lin1_b += colsum(du)
   TRY(ffn_hidden_backward(df, lp.lin2_w, t.u, bufH, M, d, G(&stlt_layer_params::lin1_b), sc, dr, site0 + 2, nullptr, s));
   // u = x1·W1ᵀ + b1
-  TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, M, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
+  TRY(dx_product(bufH, 4 * d, lp.lin1_w, 4 * d, d, bufB, d, bufC, d, M, sc, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x + drop(a))
   TRY(launch_ln_bwd(bufC, d, t.x, d, t.a, d, lp.norm1_w, 1e-5f, M, d, ds1, d, G(&stlt_layer_params::norm1_w),
                     G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufE, 0,
                     G(&stlt_layer_params::out_proj_b)));                                           // ds1, da; out_proj_b += colsum(da)
   // a = ctx·Woᵀ + bo
-  TRY(launch_gemm(0, 1, da, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, M, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx
+  TRY(dx_product(da, d, lp.out_proj_w, d, d, nullptr, 0, bufC, d, M, sc, s));  // bufC = dctx
   // ctx = attention(qkv) with dropout on the probabilities
   TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv; in_proj_b += colsum(dqkv)
   // qkv = x·Winᵀ + bin
-  TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, ds1, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
+  TRY(dx_product(bufQ, 3 * d, lp.in_proj_w, 3 * d, d, ds1, d, bufA, d, M, sc, s));  // bufA = dx = dqkv·Win + ds1
   // the four weight gradients (off the dX chain): one grouped launch
   const StltWeightGradItem items[4] = {{df, d, t.h, 4 * d, Mp, G(&stlt_layer_params::lin2_w)},
                                        {bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w)},
@@ -255,7 +288,7 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   TRY(launch_ln_bwd(dy, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, n, d, bufB, d, G(&stlt_layer_params::norm2_w),
                     G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0, G(&stlt_layer_params::lin2_b), rows));
   TRY(ffn_hidden_backward(df, lp.lin2_w, t.u, bufH, n, d, G(&stlt_layer_params::lin1_b), sc, dr, site0 + 2, rows, s));  // bufH = du
-  TRY(launch_gemm(0, 1, bufH, 4 * d, lp.lin1_w, d, nullptr, bufB, d, bufC, d, 0, n, d, 4 * d, 1, STLT_ACT_NONE, s));  // bufC = dx1 = du·W1 + ds2
+  TRY(dx_product(bufH, 4 * d, lp.lin1_w, 4 * d, d, bufB, d, bufC, d, n, sc, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x[rows] + drop(a)), a = ctx[rows]·Woᵀ + bo: gather the two inputs again (bufQ is free until the attention backward)
   float* g_x = bufQ;
   float* g_ctx = bufQ + np * d;
@@ -263,7 +296,7 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   TRY(launch_gather_rows(t.ctx, d, rows, n, d, g_ctx, s));
   TRY(launch_ln_bwd(bufC, d, g_x, d, t.a, d, lp.norm1_w, 1e-5f, n, d, ds1, d, G(&stlt_layer_params::norm1_w),
                     G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufE, 0, G(&stlt_layer_params::out_proj_b), rows));  // ds1, da
-  TRY(launch_gemm(0, 1, da, d, lp.out_proj_w, d, nullptr, nullptr, 0, bufC, d, 0, n, d, d, 1, STLT_ACT_NONE, s));  // bufC = dctx of the picked rows
+  TRY(dx_product(da, d, lp.out_proj_w, d, d, nullptr, 0, bufC, d, n, sc, s));  // bufC = dctx of the picked rows
   // the weight gradients of the three Linears that ran on the picked rows: one grouped launch, before bufH / bufQ are reused
   const StltWeightGradItem items[3] = {{df, d, t.h, 4 * d, np, G(&stlt_layer_params::lin2_w)},
                                        {bufH, 4 * d, t.x1, d, np, G(&stlt_layer_params::lin1_w)},
@@ -274,7 +307,7 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   TRY(launch_attn_bwd(t.qkv, bufH, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv
   TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
   TRY(launch_scatter_rows(ds1, rows, n, d, bufC, M, s));                                            // residual path: ds1 on the picked rows only
-  TRY(launch_gemm(0, 1, bufQ, 3 * d, lp.in_proj_w, d, nullptr, bufC, d, bufA, d, 0, M, d, 3 * d, 1, STLT_ACT_NONE, s));  // bufA = dx = dqkv·Win + ds1
+  TRY(dx_product(bufQ, 3 * d, lp.in_proj_w, 3 * d, d, bufC, d, bufA, d, M, sc, s));  // bufA = dx = dqkv·Win + ds1
   // the 4d-wide view of bufH lost its zero rows past M to the dctx image only below M*d floats: nothing to restore
   return 0;
 }

@@ -119,9 +119,10 @@ def test_split_bf16_wide_dynamic_range(pkg, split):
 
 
 def test_split_bf16_training_forward_gives_the_same_loss_and_gradients(pkg, split):
-    """cfg2 / 64 clips, dropout 0.1 (counter-based masks: the same in both runs): with the forward products of the training
-    step on the split-bf16 kernel, the loss and every parameter gradient agree with the f32 run to rounding level (the
-    backward products stay on the f32 kernel and consume the split forward's tape)."""
+    """cfg2 / 64 clips, dropout 0.1 (counter-based masks: the same in both runs): with the forward and
+    input-gradient products of the step on the split-bf16 kernel (train.hip: dx_product transposes the weight and runs the NT
+    form), the loss and every parameter gradient agree with the f32 run to rounding level; the weight-gradient products stay
+    on the f32 kernel."""
     c = pkg.synth.CONFIGS["cfg2"]
     kw = dict(pkg.synth.model_kwargs("cfg2"), hidden_dropout_prob=0.1)
     batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(64, c["T"], c["N"], dataset=c["dataset"], seed=9).items()}
