@@ -235,7 +235,25 @@ def side_fusion_leg(pkg, torch, dev, B, steps, warmup):
     k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    return {"workload": "cfg5: CACNF forward (layout branch T=32, N=7, d=768 + appearance features (B,2048,2,4,4) -> 33 tokens, cross-modal fusion layers, "
+    x3 = {}
+    try:  # the same call with the opt-in split-bf16 products
+        ref = {k: v.clone() for k, v in out.items()}
+        pkg.ops.set_gemm_split_bf16(6)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o3 = step()
+        torch.cuda.synchronize(dev)
+        x3_sec = (time.perf_counter() - t0) / steps
+        x3 = {"split_bf16": {"value": round(B / x3_sec, 2), "unit": "clips/s", "ms_per_step": round(x3_sec * 1e3, 4),
+                             "logit_max_abs_diff_vs_f32_forward": max(float((o3[k] - ref[k]).abs().max()) for k in ref)}}
+    except Exception as exc:
+        x3 = {"split_bf16": {"error": f"{type(exc).__name__}: {exc}"}}
+    finally:
+        pkg.ops.set_gemm_split_bf16(0)
+    return {**x3, "workload": "cfg5: CACNF forward (layout branch T=32, N=7, d=768 + appearance features (B,2048,2,4,4) -> 33 tokens, cross-modal fusion layers, "
                         "4 logit heads), precomputed appearance features", "per_gpu_batch": B, "steps": steps, "warmup": warmup,
             "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4), "finite": bool(all(torch.isfinite(v).all() for v in out.values())),
             "roofline": {"kernel": "gemm_nt_kernel launches of the call (the fused MHSA kernel of the layout branch is timed apart)", "bound": "mfma",
