@@ -17,7 +17,8 @@ struct BlockScratch {
   char* lin;        // stlt_linear_bwd's scratch (stream-K partial tiles + column-sum partials)
   size_t lin_bytes;
   float *ds, *da, *dctx, *dq, *dkv, *dh, *red;
-  size_t total;
+  float* wt;        // 4 d^2 floats: a transposed weight for the opt-in split-bf16 input-gradient products
+  size_t wt_floats, total;
 };
 
 // rows = the larger of the query-side and key-side row counts
@@ -37,6 +38,8 @@ BlockScratch block_scratch(char* base, int64_t rows, int64_t d) {
   int64_t red = ln_bwd_scratch_floats(d);
   if (512 * 4 * d > red) red = 512 * 4 * d;
   b.red = (float*)take((size_t)red * f);
+  b.wt_floats = (size_t)4 * d * d;
+  b.wt = (float*)take(b.wt_floats * f);
   b.total = off;
   return b;
 }
@@ -69,7 +72,9 @@ int linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64
                float* db, DwList& dws, const BlockScratch& sc, hipStream_t s) {
   if (dx && M > 0) {
     StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
-    TRY(launch_gemm(0, 1, dy, N, w, K, nullptr, add, K, dx, K, 0, M, K, N, 1, STLT_ACT_NONE, s));
+    bool taken = false;
+    if ((size_t)(N * K) <= sc.wt_floats) TRY(launch_input_grad_bf16x3(dy, N, w, N, K, add, K, dx, K, M, sc.wt, s, &taken));
+    if (!taken) TRY(launch_gemm(0, 1, dy, N, w, K, nullptr, add, K, dx, K, 0, M, K, N, 1, STLT_ACT_NONE, s));
   }
   dws.add(dy, N, x, K, M, dw);
   if (db && M > 0) return launch_colsum_acc(dy, N, M, N, db, sc.red, s);

@@ -343,6 +343,25 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
   X3_FINISH();
 }
 
+// W (n_out, k_in) -> Wt (k_in, n_out): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, int n_out, int k_in, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, k = k0 + tx;
+    if (n < n_out && k < k_in) tile[ty + 8 * i][tx] = w[(int64_t)n * k_in + k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i, n = n0 + tx;
+    if (n < n_out && k < k_in) wt[(int64_t)k * n_out + n] = tile[tx][ty + 8 * i];
+  }
+}
+
+
 int g_split_bf16 = -1;  // -1: read STLT_GEMM_SPLIT_BF16 once; 0 off; 6 on
 
 }  // namespace
@@ -389,4 +408,16 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
 #undef XL
   *taken = true;
   return stlt_check_launch("gemm_nt_bf16x3p_kernel");
+}
+
+// input gradient of a Linear, C (rows, k_in) = dY (rows, n_out)·W (n_out, k_in) (+ R), on the split-bf16 kernel: W is transposed
+// into wt_scratch (n_out * k_in floats; 5-10 us for 0.6-2.4 M elements) and the product runs as the NT form above.
+// *taken = false (nothing launched) when the switch is off or the launch does not qualify.
+int launch_input_grad_bf16x3(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
+                             int64_t ldc, int64_t rows, float* wt_scratch, hipStream_t s, bool* taken) {
+  *taken = false;
+  if (!wt_scratch || !stlt_split_bf16_takes(rows, k_in, n_out, ld_dy, n_out)) return 0;
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)((k_in + 31) / 32), (unsigned)((n_out + 31) / 32)), dim3(256), 0, s, w, (int)n_out, (int)k_in, wt_scratch);
+  if (int e = stlt_check_launch("weight_transpose_kernel")) return e;
+  return launch_linear_bf16x3(dy, ld_dy, wt_scratch, n_out, nullptr, r, ldr, c, ldc, rows, k_in, n_out, STLT_ACT_NONE, s, taken);
 }

@@ -115,34 +115,14 @@ static int weight_grad(const float* dy, int64_t n_out, const float* x, int64_t k
   return launch_reduce_slabs(sc.slabs, n_out * k_in, split, g_w, n_out * k_in, 1, s);
 }
 
-// W (n_out, k_in) -> Wt (k_in, n_out): 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, int n_out, int k_in, float* __restrict__ wt) {
-  __shared__ float tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + ty + 8 * i, k = k0 + tx;
-    if (n < n_out && k < k_in) tile[ty + 8 * i][tx] = w[(int64_t)n * k_in + k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = k0 + ty + 8 * i, n = n0 + tx;
-    if (n < n_out && k < k_in) wt[(int64_t)k * n_out + n] = tile[tx][ty + 8 * i];
-  }
-}
-
 // C (rows, k_in) = dY (rows, n_out)·W (n_out, k_in) (+ R): the input gradient of a Linear.  With the opt-in split-bf16 products
-// switched on and a launch they take, W is transposed into the (then unused) split-K slab buffer — 5-10 us for 0.6-2.4 M
-// elements — and the product runs as the NT form the split-bf16 kernel has (gemm_bf16x3.hip); otherwise the f32-MFMA NN kernel.
+// switched on and a launch they take, W is transposed into the (then unused) split-K slab buffer and the product runs as the
+// NT form the split-bf16 kernel has (gemm_bf16x3.hip: launch_input_grad_bf16x3); otherwise the f32-MFMA NN kernel.
 static int dx_product(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
                       int64_t ldc, int64_t rows, const Scratch& sc, hipStream_t s) {
-  if (sc.sk && (size_t)(n_out * k_in) <= sc.slab_floats && stlt_split_bf16_takes(rows, k_in, n_out, ld_dy, n_out)) {
-    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)((k_in + 31) / 32), (unsigned)((n_out + 31) / 32)), dim3(256), 0, s, w, (int)n_out, (int)k_in, sc.slabs);
-    TRY(stlt_check_launch("weight_transpose_kernel"));
+  if (sc.sk && (size_t)(n_out * k_in) <= sc.slab_floats) {
     bool taken = false;
-    TRY(launch_linear_bf16x3(dy, ld_dy, sc.slabs, n_out, nullptr, r, ldr, c, ldc, rows, k_in, n_out, STLT_ACT_NONE, s, &taken));
+    TRY(launch_input_grad_bf16x3(dy, ld_dy, w, n_out, k_in, r, ldr, c, ldc, rows, sc.slabs, s, &taken));
     if (taken) return 0;
   }
   return launch_gemm(0, 1, dy, ld_dy, w, k_in, nullptr, r, ldr, c, ldc, 0, rows, k_in, n_out, 1, STLT_ACT_NONE, s);

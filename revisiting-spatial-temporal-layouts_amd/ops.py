@@ -336,7 +336,7 @@ class DropoutFn(torch.autograd.Function):
     """nn.Dropout in train mode with the library's counter-based mask (one seed per call from torch's CPU generator, so
     torch.manual_seed makes a run repeatable); the backward applies the same mask to the gradient."""
 
-    _site = 0x200000  # site ids of their own, apart from AttnFn's
+    _site = 0x200000  # a site id of its own, apart from AttnFn's; every call draws its own seed, so the id can be constant
 
     @staticmethod
     def forward(ctx, x, p):
@@ -344,7 +344,7 @@ class DropoutFn(torch.autograd.Function):
         x = x.contiguous()
         p = float(p)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        DropoutFn._site = site = 0x200000 | ((DropoutFn._site + 1) & 0xfffff)
+        site = DropoutFn._site
         y = torch.empty_like(x)
         L.check(lib.stlt_dropout(_p(x), _p(y), x.numel(), p, seed, site, _stream()), "stlt_dropout")
         ctx.meta = (p, seed, site)
@@ -372,7 +372,7 @@ class AttnFn(torch.autograd.Function):
     row stride (views of a packed projection are fine).  kpm (S,Lk) over the keys or None.  dropout_p > 0: train-mode
     dropout of the attention probabilities with a counter-based mask (seed drawn from torch's CPU generator)."""
 
-    _site = 0x100  # a site id of its own per call keeps the masks of different attention calls apart
+    _site = 0x100  # constant: the per-call seed keeps the masks of different attention calls apart, and a forward stays repeatable under torch.manual_seed
 
     @staticmethod
     def forward(ctx, q, k, v, kpm, causal, heads, dropout_p=0.0):
@@ -388,7 +388,7 @@ class AttnFn(torch.autograd.Function):
         ctxt = torch.empty(S, Lq, d, device=q.device, dtype=torch.float32)
         p = float(dropout_p)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
-        AttnFn._site = site = (AttnFn._site + 1) & 0xffffff if p > 0 else 0
+        site = AttnFn._site if p > 0 else 0
         L.check(lib.stlt_attn_fwd_dropout(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), _p(kpm8), int(bool(causal)),
                                           S, Lq, Lk, heads, d // heads, p, seed, site, _p(ctxt), _stream()), "stlt_attn_fwd_dropout")
         ctx.save_for_backward(q, k, v, kpm8)
@@ -462,7 +462,6 @@ class GeluFn(torch.autograd.Function):
         return du
 
 
-_BLOCK_SITE = [0x400000]
 _SK_SCRATCH = {}
 
 
@@ -477,12 +476,13 @@ def _sk_scratch(device) -> torch.Tensor:
 
 
 def _block_dropout(p: float):
-    """(p, seed, site0) of a block call: one seed per call from torch's CPU generator, two consecutive site ids."""
+    """(p, seed, site0) of a block call: one seed per call from torch's CPU generator, site ids site0 and site0 + 1."""
     p = float(p)
     if p <= 0.0:
         return 0.0, 0, 0
-    _BLOCK_SITE[0] = 0x400000 | ((_BLOCK_SITE[0] + 2) & 0xfffff)
-    return p, int(torch.randint(0, 2 ** 62, (1,)).item()), _BLOCK_SITE[0]
+    # every call draws its own 62-bit seed, so the site ids only have to tell the call's two dropout sites apart: a constant
+    # pair keeps a forward repeatable under torch.manual_seed whatever ran before it in the process
+    return p, int(torch.randint(0, 2 ** 62, (1,)).item()), 0x400000
 
 
 def grad_targets(ws, needs):
