@@ -465,6 +465,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU per step; default 1024 for the forward (every cfg2 GEMM is then a whole "
                                                            "number of 256-tile rounds), 64 for --mode train (the reference's batch size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-bf16-main", action="store_true", help="PROFILING ONLY: run the timed region itself with the opt-in split-bf16 products (the line's metric says so; never the driver's command)")
     ap.add_argument("--no-split-bf16", action="store_true", help="do not time the opt-in split-bf16 GEMM variant after the main measurement (profiling runs)")
     ap.add_argument("--no-skip-padding", action="store_true", help="do not time the opt-in skip-padding variant after the main measurement (profiling runs)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the bounded sub-measurements of the default line (train_step, cfg4, small_batch, cfg5)")
@@ -505,6 +506,8 @@ def main():
     if dist is not None:
         dist.barrier()
     pkg = importlib.import_module(PKG)
+    # `value` is the f32-MFMA schedule's whatever STLT_GEMM_SPLIT_BF16 says in the environment: the switch is set explicitly
+    pkg.ops.set_gemm_split_bf16(6 if args.split_bf16_main else 0)
     if args.mode == "train":
         out = bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin)
         if rank == 0:
@@ -615,7 +618,7 @@ def main():
                                                            tj.get("attn_spatial_avg_bytes_per_launch"))
             traffic_mhsa = tj.get("mhsa_fused_avg_bytes_per_launch")
         out = {
-            "metric": "clips/s STLT forward (T=32, N_obj=7, d=768)" if args.config == "cfg2" else f"clips/s STLT forward ({args.config})",
+            "metric": ("clips/s STLT forward (T=32, N_obj=7, d=768)" if args.config == "cfg2" else f"clips/s STLT forward ({args.config})") + (" [PROFILING RUN: split-bf16 products in the timed region]" if args.split_bf16_main else ""),
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -662,7 +665,7 @@ def main():
                                        "logit_max_abs_diff_vs_padded": float((sk_logits - logits).abs().max())}
             except Exception as exc:  # the secondary legs must never cost the main line
                 out["skip_padding"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if world == 1 and not args.no_split_bf16:
+        if world == 1 and not args.no_split_bf16 and not args.split_bf16_main:
             try:
                 # Same workload with the forward products on the BF16 matrix cores as six bf16 piece products per f32 product
                 # (csrc/gemm_bf16x3.hip, opt-in, f32-equivalent: error vs fp64 at or below the f32 kernel's).  Reported beside

@@ -34,9 +34,7 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_
 python3 $R/tools/pmc_util.py $O/round3_util_pmc.json /tmp/pu
 # 4b. the same forward with the opt-in split-bf16 products, under the tracer (kernel statistics only)
 rm -rf /tmp/kx
-export STLT_GEMM_SPLIT_BF16=6
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kx -o o -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-skip-padding --no-split-bf16 --no-side-legs > $O/round3_bench_split_bf16_under_rocprof_b1024.log 2>&1
-unset STLT_GEMM_SPLIT_BF16
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kx -o o -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-skip-padding --split-bf16-main --no-side-legs > $O/round3_bench_split_bf16_under_rocprof_b1024.log 2>&1
 cp $(find /tmp/kx -name '*kernel_stats.csv' | head -1) $O/round3_kernel_stats_split_bf16_b1024.csv
 # 5. the training step under the tracer: kernel statistics + the timeline of one step
 rm -rf /tmp/pt
