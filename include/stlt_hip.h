@@ -440,13 +440,17 @@ double stlt_prof_take_gemm_flops(void);
 int stlt_debug_set_buffer(void* dev_buf);
 size_t stlt_debug_buffer_bytes(void);  /* (54 * compute units of the current device + 1024) * 8 */
 
-/* Opt-in "split-bf16" build of the nn.Linear forward (csrc/gemm_bf16x3.hip): every f32 operand element is cut in registers into
- * three bf16 pieces and a product is the six piece products of weight >= 2^-24 on v_mfma_f32_16x16x32_bf16, accumulated in f32 —
- * the dropped terms are below the rounding of an f32 multiply.  terms = 6 turns it on for whole-tile forward launches
- * (K % 32 == 0, K >= 64, rounds of whole tiles filling at least half of the workgroups; everything else keeps the f32-MFMA kernel), 0 turns it off; the STLT_GEMM_SPLIT_BF16=6
- * environment variable is the initial value.  Not the default: results agree with the f32 kernel's to f32 rounding but are
- * not bit-identical to it, and bench.py never reports it as `value` (it is a side object of the JSON line).  STLT_EINVAL
- * for other values. */
+/* Opt-in "split-bf16" products (csrc/gemm_bf16x3.hip): every f32 operand element is cut into three bf16 pieces and a product is
+ * the six piece products of weight >= 2^-24 on v_mfma_f32_16x16x32_bf16, accumulated in f32 — the dropped terms are below the
+ * rounding of an f32 multiply.  terms = 6 turns it on, 0 off; the STLT_GEMM_SPLIT_BF16=6 environment variable is the initial
+ * value.  What then runs on it: every nn.Linear forward of the entry points above (stlt_linear_fwd, the whole-path forwards,
+ * the training forward, the block calls) and the input-gradient products dX = dY·W of stlt_train_backward and the block
+ * backwards (through a transposed copy of W in their scratch), when the launch has whole tiles filling at least half of the
+ * workgroups (STLT_X3_MIN_FILL, default 0.5), K % 32 == 0 and K >= 64; everything else — the weight-gradient products, small
+ * launches — keeps the f32-MFMA kernel.  Not the default: results agree with the f32 kernel's to f32 rounding (error against an
+ * fp64 product at or below the f32 kernel's) but are not bit-identical to it, non-finite inputs give NaN where the f32 kernel
+ * may give an infinity, and bench.py never reports it as `value` (side objects of the JSON line).  Process-wide switch;
+ * STLT_EINVAL for other values. */
 int stlt_set_gemm_split_bf16(int terms);
 
 #ifdef __cplusplus
