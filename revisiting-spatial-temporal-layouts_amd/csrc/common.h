@@ -108,6 +108,7 @@ int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* 
 constexpr int STLT_ACT_GELU_BWD = 3;
 struct StltGemmEpi { StltDrop dr; uint32_t site; const int* drop_rows; float* cs_part; };
 // gemm_bf16x3.hip: the forward product on the BF16 matrix cores with three-piece operands (opt-in); *taken = launched
+float* stlt_gemm_scratch_ptr(size_t* bytes);  // gemm.hip: the calling thread's lent stream-K scratch (nullptr: none)
 bool stlt_split_bf16_takes(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw);  // would it (switched on, shape fits)?
 int launch_input_grad_bf16x3(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
                              int64_t ldc, int64_t rows, float* wt_scratch, hipStream_t s, bool* taken);  // dX = dY·W through a transposed copy of W

@@ -1182,6 +1182,9 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
 }
 
 bool stlt_gemm_has_scratch() { return t_gemm_scratch != nullptr && t_gemm_scratch_bytes >= STLT_GEMM_SCRATCH_BYTES; }
+// the calling thread's lent scratch (stream-K partial tiles; between launches free for other stream-ordered uses such as the
+// split-bf16 kernel's weight planes); nullptr when nothing is lent
+float* stlt_gemm_scratch_ptr(size_t* bytes) { *bytes = t_gemm_scratch ? t_gemm_scratch_bytes : 0; return t_gemm_scratch; }
 
 // g_w_i (n_out_i, k_in_i) += dy_i[:rows_i]ᵀ · x_i[:rows_i] for every item, as ONE stream-K launch + one fix-up: every CU gets
 // an equal share of the group's k-steps, a workgroup's range may cross from one product into the next.  Deterministic

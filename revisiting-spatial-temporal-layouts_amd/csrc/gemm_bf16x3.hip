@@ -16,7 +16,8 @@
 // their initial value) and 4 PRODUCER waves, persistent workgroups walking gemm.hip's XCD-contiguous band-major tile order,
 // one barrier per k-step.  The producers load the f32 operands with buffer loads into registers (two k-steps ahead, ~92 KB in
 // flight per workgroup), cut every element ONCE per workgroup and write three bf16 plane images to LDS; the MFMA waves read
-// ready bf16 fragments and issue nothing but ds_read_b128 and MFMAs.  History (git): every MFMA wave cutting its own fragments
+// ready bf16 fragments and issue nothing but ds_read_b128 and MFMAs.  Long launches cut the weight once for all workgroups in
+// a kernel of their own (w_planes_kernel) and the producers only copy its planes.  History (git): every MFMA wave cutting its own fragments
 // in registers (f750abb: 175-188 TFLOP/s, vector-issue bound); 32 x 32 x 16 blocks (180-199, power-bound: that MFMA form draws
 // more per FLOP); a four-slot ring of 16-k steps (profiles/round3_gemm_bf16x3_ring_build.patch: no gain).
 // Forward (NT) layout only, whole-tile launches only (no stream-K): shapes the launcher does not take keep gemm.hip's kernel.
@@ -146,7 +147,9 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2)
   }
 }
 
-template <int ACT, bool ADD>
+// WPRE: W arrives already cut — three bf16 planes [3][N][K] written by w_planes_kernel (the weight is shared by every row
+// tile: cutting it once per launch takes a third of the cut off the producers) — in `W`, ldw unused
+template <int ACT, bool ADD, bool WPRE>
 __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                                       int64_t ldw, const float* __restrict__ bias, const float* __restrict__ R,
                                                                       int64_t ldr, float* __restrict__ Y, int64_t ldy, int M, int N, int K,
@@ -188,15 +191,24 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
       int m0, n0;
       walk.origin(it, m0, n0);
       rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (int64_t)m0 * ldx), 0, extent(M - m0, ldx), 0x27000);
-      rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)n0 * ldw), 0, extent(N - n0, ldw), 0x27000);
+      if (WPRE) {  // planes [3][N][K] of bf16: the tile's first row of plane 0; rows past N read the next plane or, past the end, zeros
+        const int64_t off = (int64_t)n0 * K * 2, all = (int64_t)3 * N * K * 2;
+        rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(W) + off), 0, (int)(unsigned)(all - off), 0x27000);
+      } else {
+        rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)n0 * ldw), 0, extent(N - n0, ldw), 0x27000);
+      }
     };
     const int ldx4 = (int)ldx * 4, ldw4 = (int)ldw * 4;
     const int vA = (p * 64 + prow) * ldx4 + pch * 32, vB = (p * 32 + prow) * ldw4 + pch * 32;
-    auto load_piece = [&](int j, int kt) {  // piece j = half (j & 1) of item j >> 1
-      const int q = j >> 1, h16 = (j & 1) * 16;
-      const auto v = q < 4 ? __builtin_amdgcn_raw_buffer_load_b128(rA, vA + q * 16 * ldx4 + h16, kt * (BK * 4), 0)
-                           : __builtin_amdgcn_raw_buffer_load_b128(rB, vB + (q - 4) * 16 * ldw4 + h16, kt * (BK * 4), 0);
-      return __builtin_bit_cast(f32x4, v);
+    const int vP = (p * 32 + prow) * (K * 2) + pch * 16, plane_bytes = N * K * 2;  // WPRE: a lane's 8 bf16 of a plane row
+    constexpr int NPC = WPRE ? 14 : 12;  // register pieces per k-step: 8 of X + 4 of W (f32) or 6 of W (2 items x 3 planes, bf16)
+    auto load_piece = [&](int j, int kt) {  // piece j < 8: half (j & 1) of X item j >> 1; then W
+      if (j < 8) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA + (j >> 1) * 16 * ldx4 + (j & 1) * 16, kt * (BK * 4), 0));
+      if (WPRE) {
+        const int it = (j - 8) / 3, pl = (j - 8) % 3;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vP + it * 16 * (K * 2) + pl * plane_bytes, kt * (BK * 2), 0));
+      }
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB + ((j - 8) >> 1) * 16 * ldw4 + (j & 1) * 16, kt * (BK * 4), 0));
     };
     // bias strip: wave p carries columns [32p, 32p+32) of the NEXT tile's strip in one register, loaded every step and stored
     // (into the strip buffer the MFMA waves are not reading) one step later — no branch and no wait of its own in this wave's
@@ -212,19 +224,36 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     auto bias_load = [&](int n) { return bias ? bias[n] : 0.f; };
     auto bias_store = [&](int it, float v) { bias_lds[(it & 1) * BN + 32 * p + (lane & 31)] = v; };
     int l_it = 0, l_kt = 0;
-    auto load_step = [&](f32x4 (&S)[12]) {
+    auto load_step = [&](f32x4 (&S)[NPC]) {
       if (l_kt == 0 && l_it < my_tiles) set_tile(l_it);
 #pragma unroll
-      for (int j = 0; j < 12; ++j) S[j] = load_piece(j, l_kt);
+      for (int j = 0; j < NPC; ++j) S[j] = load_piece(j, l_kt);
       if (++l_kt == nk) { ++l_it; l_kt = 0; }
     };
     // cut the step held in S into plane buffer `buf`, refilling every 16-byte register group with the same piece of the step
     // two k-steps later the moment it has been cut: ~92 KB of operands in flight per workgroup on 96 registers per lane
-    auto cut_step = [&](f32x4 (&S)[12], int buf, bool reload) {
+    auto cut_step = [&](f32x4 (&S)[NPC], int buf, bool reload) {
       unsigned char* base = pmem + buf * P_BUF + prow * 64;
       if (reload && l_kt == 0 && l_it < my_tiles) set_tile(l_it);  // past the last step: the last tile's k-steps again (never read)
+      const int grp = (pch ^ ((0 - (prow >> 2)) & 3)) * 16;  // the fragment layout's swizzle: group ^ T[(row >> 2) & 3], T = {0, 3, 2, 1}
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
+        unsigned char* d = (q < 4 ? base + (p * 64 + q * 16) * 64 : base + P_B_BASE + (p * 32 + (q - 4) * 16) * 64) + grp;
+        const int ps = q < 4 ? P_A_PLANE : P_B_PLANE;
+        if (WPRE && q >= 4) {  // ready planes: straight to LDS
+          const int j0 = 8 + (q - 4) * 3;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(d + pl * ps) = __builtin_bit_cast(u32x4, S[j0 + pl]);
+          X3_T(2);
+#if !(STLT_X3_EXP & 8)
+          if (reload) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) S[j0 + pl] = load_piece(j0 + pl, l_kt);
+          }
+#endif
+          X3_T(3);
+          continue;
+        }
         u32x2 a0, a1, a2, b0, b1, b2;
 #if STLT_X3_EXP & 4  // timing experiment: producers write uncut bits
         a0 = u32x2{__builtin_bit_cast(unsigned, S[2 * q][0]), __builtin_bit_cast(unsigned, S[2 * q][1])}; a1 = u32x2{__builtin_bit_cast(unsigned, S[2 * q][2]), __builtin_bit_cast(unsigned, S[2 * q][3])}; a2 = a0;
@@ -235,9 +264,6 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
         split4(S[2 * q + 1], b0, b1, b2);
         X3_T(1);
 #endif
-        const int grp = (pch ^ ((0 - (prow >> 2)) & 3)) * 16;  // the fragment layout's swizzle: group ^ T[(row >> 2) & 3], T = {0, 3, 2, 1}
-        unsigned char* d = (q < 4 ? base + (p * 64 + q * 16) * 64 : base + P_B_BASE + (p * 32 + (q - 4) * 16) * 64) + grp;
-        const int ps = q < 4 ? P_A_PLANE : P_B_PLANE;
         *reinterpret_cast<u32x4*>(d) = u32x4{a0[0], a0[1], b0[0], b0[1]};
         *reinterpret_cast<u32x4*>(d + ps) = u32x4{a1[0], a1[1], b1[0], b1[1]};
         *reinterpret_cast<u32x4*>(d + 2 * ps) = u32x4{a2[0], a2[1], b2[0], b2[1]};
@@ -249,7 +275,7 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
       }
       if (reload) { if (++l_kt == nk) { ++l_it; l_kt = 0; } }
     };
-    f32x4 S0[12], S1[12];
+    f32x4 S0[NPC], S1[NPC];
     bias_store(0, bias_load(bias_col(0)));
     int n_next = bias_col(1);
     float b_next = bias_load(n_next);
@@ -259,7 +285,7 @@ __global__ __launch_bounds__(X_THREADS, 3) void gemm_nt_bf16x3p_kernel(const flo
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int w_it = 0, w_kt = 0;
-    auto iter = [&](int i, f32x4 (&S)[12]) {  // while the MFMA waves multiply step i: cut step i + 1, load step i + 3
+    auto iter = [&](int i, f32x4 (&S)[NPC]) {  // while the MFMA waves multiply step i: cut step i + 1, load step i + 3
       X3_T(0);
       bias_store(w_it + 1, b_next);
       X3_T(4);
@@ -362,6 +388,20 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
 }
 
 
+// W (N, K) f32 -> three bf16 planes [3][N][K] (the pieces split4 makes), once per launch: 4 k per thread
+__global__ __launch_bounds__(256) void w_planes_kernel(const float* __restrict__ w, int64_t ldw, int N, int K, unsigned char* __restrict__ planes) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (row, group of 4 k)
+  const int kg = K >> 2;
+  if (i >= (int64_t)N * kg) return;
+  const int n = (int)(i / kg), k = (int)(i - (int64_t)n * kg) * 4;
+  u32x2 p0, p1, p2;
+  split4(*reinterpret_cast<const f32x4*>(w + (int64_t)n * ldw + k), p0, p1, p2);
+  const int64_t off = ((int64_t)n * K + k) * 2, pb = (int64_t)N * K * 2;
+  *reinterpret_cast<u32x2*>(planes + off) = p0;
+  *reinterpret_cast<u32x2*>(planes + pb + off) = p1;
+  *reinterpret_cast<u32x2*>(planes + 2 * pb + off) = p2;
+}
+
 int g_split_bf16 = -1;  // -1: read STLT_GEMM_SPLIT_BF16 once; 0 off; 6 on
 
 }  // namespace
@@ -400,7 +440,22 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
   const dim3 grid((unsigned)cus), block(X_THREADS);
-#define XL(ACTV, ADDV) hipLaunchKernelGGL((gemm_nt_bf16x3p_kernel<ACTV, ADDV>), grid, block, 0, s, x, ldx, w, ldw, bias, r, ldr, y, ldy, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, g_stlt_debug_buf)
+  // the weight cut once per launch into the lent stream-K scratch (free between launches, stream-ordered) when the launch is
+  // long enough to pay for the extra 5-10 us kernel: at least four rounds of tiles (STLT_X3_WPRE=0 keeps the producers' own cut).
+  // Measured on the forward shapes at 1024 clips: 227 - 242 TFLOP/s against 221 - 235 (+2.5 %)
+  static const bool wpre_on = [] { const char* e = getenv("STLT_X3_WPRE"); return e ? atoi(e) != 0 : true; }();
+  size_t sbytes = 0;
+  unsigned char* planes = reinterpret_cast<unsigned char*>(stlt_gemm_scratch_ptr(&sbytes));
+  const bool wpre = wpre_on && planes && (size_t)3 * (size_t)N * (size_t)K * 2 <= sbytes && tiles_m * tiles_n >= 4 * cus && !g_stlt_debug_buf &&
+                    (int64_t)3 * N * K * 2 < 0x7fffffffLL;
+  if (wpre) {
+    const int64_t n_thr = N * (K / 4);
+    hipLaunchKernelGGL(w_planes_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, w, ldw, (int)N, (int)K, planes);
+    if (int e = stlt_check_launch("w_planes_kernel")) return e;
+  }
+  const float* wsrc = wpre ? reinterpret_cast<const float*>(planes) : w;
+#define XL(ACTV, ADDV) do { if (wpre) hipLaunchKernelGGL((gemm_nt_bf16x3p_kernel<ACTV, ADDV, true>), grid, block, 0, s, x, ldx, wsrc, ldw, bias, r, ldr, y, ldy, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, g_stlt_debug_buf); \
+  else hipLaunchKernelGGL((gemm_nt_bf16x3p_kernel<ACTV, ADDV, false>), grid, block, 0, s, x, ldx, wsrc, ldw, bias, r, ldr, y, ldy, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, g_stlt_debug_buf); } while (0)
   if (r) XL(STLT_ACT_NONE, true);
   else if (act == STLT_ACT_GELU) XL(STLT_ACT_GELU, false);
   else if (act == STLT_ACT_RELU) XL(STLT_ACT_RELU, false);
