@@ -446,7 +446,7 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
   static const bool wpre_on = [] { const char* e = getenv("STLT_X3_WPRE"); return e ? atoi(e) != 0 : true; }();
   size_t sbytes = 0;
   unsigned char* planes = reinterpret_cast<unsigned char*>(stlt_gemm_scratch_ptr(&sbytes));
-  const bool wpre = wpre_on && planes && (size_t)3 * (size_t)N * (size_t)K * 2 <= sbytes && tiles_m * tiles_n >= 4 * cus && !g_stlt_debug_buf &&
+  const bool wpre = wpre_on && planes && (size_t)3 * (size_t)N * (size_t)K * 2 <= sbytes && tiles_m * tiles_n >= 4 * cus &&
                     (int64_t)3 * N * K * 2 < 0x7fffffffLL;
   if (wpre) {
     const int64_t n_thr = N * (K / 4);

@@ -12,6 +12,8 @@ if len(sys.argv) > 3:
     M, N, K = map(int, sys.argv[1:4])
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
 y = torch.empty(M, N, device="cuda")
+scratch = torch.empty(int(lib.stlt_gemm_scratch_bytes()), dtype=torch.uint8, device="cuda")  # lent as inside the whole-path calls: the weight is then cut once per launch
+pkg._lib.check(lib.stlt_gemm_set_scratch(scratch.data_ptr(), scratch.numel()), "stlt_gemm_set_scratch")
 pkg.ops.set_gemm_split_bf16(6)
 for _ in range(2):
     pkg.ops.linear(x, w, b, out=y)
