@@ -658,8 +658,24 @@ def main():
                     sk_logits = step()
                 torch.cuda.synchronize(dev)
                 sk_s = (time.perf_counter() - t1) / n_sk
+                sk_x3 = None
+                if not args.no_split_bf16 and not args.split_bf16_main:
+                    try:  # both opt-in switches together: real tokens only, products on the split-bf16 kernel
+                        pkg.ops.set_gemm_split_bf16(6)
+                        for _ in range(min(args.warmup, 5)):
+                            step()
+                        torch.cuda.synchronize(dev)
+                        t1 = time.perf_counter()
+                        for _ in range(n_sk):
+                            sk3_logits = step()
+                        torch.cuda.synchronize(dev)
+                        sk3_s = (time.perf_counter() - t1) / n_sk
+                        sk_x3 = {"value": round(B / sk3_s, 2), "unit": "clips/s", "ms_per_step": round(sk3_s * 1e3, 4),
+                                 "logit_max_abs_diff_vs_padded_f32": float((sk3_logits - logits).abs().max())}
+                    finally:
+                        pkg.ops.set_gemm_split_bf16(0)
                 model.backbone.skip_padding = False
-                out["skip_padding"] = {"value": round(B / sk_s, 2), "unit": "clips/s", "ms_per_step": round(sk_s * 1e3, 4),
+                out["skip_padding"] = {"value": round(B / sk_s, 2), "unit": "clips/s", "ms_per_step": round(sk_s * 1e3, 4), "split_bf16": sk_x3,
                                        "real_token_frac": round(real_tok / (B * T * N), 4),
                                        "real_frame_frac": round(float((~cpu_batch["src_key_padding_mask_frames"]).float().mean()), 4),
                                        "logit_max_abs_diff_vs_padded": float((sk_logits - logits).abs().max())}
