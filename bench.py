@@ -32,9 +32,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X f32-input MFMA dense peak (MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak
 
 
-def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only, fused_mhsa=False):
-    """FLOPs the GEMM launches of one forward actually execute (2*M*N*K summed over launches).  With the fused MHSA kernel
-    the temporal in-projections (6 d^2 per frame and layer) belong to that kernel, not to the GEMM launches."""
+def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only, fused_tp_layers=0, fused_sp_layers=0):
+    """FLOPs the GEMM launches of one forward actually execute (2*M*N*K summed over launches).  The in-projections of the layers
+    that run the fused MHSA kernel (6 d^2 per token row and layer) belong to that kernel, not to the GEMM launches."""
     tok, bt = B * T * N, B * T
     per_row = 24.0 * d * d  # qkv 6d^2 + out 2d^2 + ffn 16d^2
     full_sp = n_sp - 1 if (cls_only and N > 1 and n_sp > 0) else n_sp
@@ -46,9 +46,20 @@ def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only, fused_mhsa=Fa
     else:
         f += n_tp * bt * per_row
     f += B * (2.0 * d * d + 2.0 * d * classes)
-    if fused_mhsa:
-        f -= n_tp * bt * 6.0 * d * d
+    f -= fused_tp_layers * bt * 6.0 * d * d + fused_sp_layers * tok * 6.0 * d * d
     return f
+
+
+def fused_mhsa_plan(pkg, B, T, N, d, H, n_sp, n_tp, cls_only):
+    """Which layers of one forward the library runs through the fused in-projection + attention kernel (stlt_fused_mhsa_used: the
+    shape must fill the kernel's 128-row items and the launch the device), with the FLOPs and algorithmic bytes of one launch."""
+    lib = pkg._lib.load()
+    full_sp = n_sp - 1 if (cls_only and N > 1 and n_sp > 0) else n_sp  # the CLS-only last spatial layer projects K/V and Q separately
+    tp = n_tp if lib.stlt_fused_mhsa_used(B, T, d, H, 1) else 0
+    sp = full_sp if lib.stlt_fused_mhsa_used(B * T, N, d, H, 0) else 0
+    w_bytes = 4.0 * (3 * d * d + 3 * d)
+    return {"temporal": {"layers": tp, "flops": B * T * 6.0 * d * d + B * H * 4.0 * T * T * 64, "bytes": B * T * d * 8.0 + w_bytes + B * T},
+            "spatial": {"layers": sp, "flops": B * T * N * 6.0 * d * d + B * T * H * 4.0 * N * N * 64, "bytes": B * T * N * d * 8.0 + w_bytes + B * T * N}}
 
 
 def pin_to_gpu_numa_node(local_rank):
@@ -125,24 +136,47 @@ def _attn_rooflines(k_ms, B, T, N, d):
     return out
 
 
-def mhsa_fused_roofline(k_ms, B, T, d, H):
-    """MFMA roofline of the fused in-projection + attention kernel from the library's per-launch events (None when the forward did not run it)."""
-    ms, n = k_ms.get("mhsa_fused", (0.0, 0))
+def mhsa_fused_roofline(k_ms, plan, tower="temporal"):
+    """MFMA roofline of the fused in-projection + attention kernel from the library's per-launch events (None when the forward did
+    not run it for this tower).  FLOPs per launch = 6 d^2 per token row + 4 L^2 64 per sequence and head (QK^T and PV, dense)."""
+    ms, n = k_ms.get("mhsa_fused" if tower == "temporal" else "mhsa_fused_spatial", (0.0, 0))
     if n == 0 or ms <= 0:
         return None
-    fl = B * T * 6.0 * d * d + B * H * 4.0 * T * T * 64  # in-projection + QK^T and PV of every clip and head, per launch
-    tf = fl * n / (ms * 1e-3) / 1e12
-    return {"kernel": "mhsa_fused_kernel (temporal in-projection + causal softmax(QK^T)V in one launch, packed QKV never in HBM)", "bound": "mfma",
+    tf = plan[tower]["flops"] * n / (ms * 1e-3) / 1e12
+    what = "temporal in-projection + causal" if tower == "temporal" else "spatial in-projection + key-padded"
+    return {"kernel": f"mhsa16_kernel ({what} softmax(QK^T)V in one launch, packed QKV never in HBM)", "bound": "mfma",
             "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "launches_per_step": n,
-            "us_per_launch": round(ms / n * 1e3, 2), "algorithmic_bytes_per_launch": int(B * T * d * 8 + 4 * (3 * d * d + 3 * d) + B * T)}
+            "us_per_launch": round(ms / n * 1e3, 2), "algorithmic_bytes_per_launch": int(plan[tower]["bytes"])}
 
 
-def side_forward_leg(pkg, torch, dev, config, B, steps, warmup):
-    """A bounded forward measurement of another workload (cfg4, or cfg2 at the reference's default batch) for the default
-    line's sub-objects: wall-clock ms per step, clips/s, and the GEMM / attention rooflines from the library's events."""
-    c = pkg.synth.CONFIGS[config]
+def standalone_temporal_attention(pkg, torch, dev, model, kpm_frames, B, T, d, H, n_layers, reps=20):
+    """The temporal attention core alone against HBM when the forward itself runs the fused kernel: the core kernel of the
+    two-launch path, timed behind its in-projection on a packed-QKV buffer of this batch (library events).  -> (ms per step, launches)"""
+    lw = model.backbone.transformer.layers[0].self_attn
+    xin = torch.rand(B * T, d, device=dev) * 2 - 1
+    qkv = torch.empty(B * T, 3 * d, device=dev)
+    pkg.ops.prof_enable(True)
+    try:
+        pkg.ops.prof_collect()
+        for _ in range(reps):  # the core reads the QKV its in-projection just wrote
+            pkg.ops.linear(xin, lw.in_proj_weight, lw.in_proj_bias, out=qkv)
+            pkg.ops.attn_core(qkv.view(B, T, 3 * d), kpm_frames, True, H)
+        torch.cuda.synchronize(dev)
+        ms, n = pkg.ops.prof_collect()["attn_temporal"]
+    finally:
+        pkg.ops.prof_enable(False)
+    return ((ms / n * n_layers, n_layers) if n else (0.0, 0))
+
+
+def side_forward_leg(pkg, torch, dev, config, B, steps, warmup, shape=None, split_bf16=True):
+    """A bounded forward measurement of another workload (cfg4, cfg2 at the reference's default batch, the reference's real layouts)
+    for the default line's sub-objects: wall-clock ms per step, clips/s, and the GEMM / attention / fused-MHSA rooflines from the
+    library's events.  shape: (T, N) overriding the config's (same weights: the model takes any T <= 256, any N)."""
+    c = dict(pkg.synth.CONFIGS[config])
+    if shape is not None:
+        c["T"], c["N"] = shape
     model, _ = _build_model(pkg, torch, dev, config)
-    T, N, d = c["T"], c["N"], c["hidden_size"]
+    T, N, d, H = c["T"], c["N"], c["hidden_size"], c["num_attention_heads"]
     batch = {k: v.to(dev) for k, v in pkg.synth.make_batch(B, T, N, dataset=c["dataset"], seed=2000).items()}
 
     def step():
@@ -170,32 +204,48 @@ def side_forward_leg(pkg, torch, dev, config, B, steps, warmup):
     k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    plan = fused_mhsa_plan(pkg, B, T, N, d, H, c["num_spatial_layers"], c["num_temporal_layers"], True)
+    extra = {}
+    for tower in ("temporal", "spatial"):
+        fused = mhsa_fused_roofline(k_ms, plan, tower)
+        if fused:
+            extra["roofline_mhsa_fused" + ("" if tower == "temporal" else "_spatial")] = fused
+    note = {}
+    if k_ms.get("attn_temporal", (0.0, 0))[1] == 0 and k_ms.get("mhsa_fused", (0.0, 0))[1] > 0:
+        try:  # the forward ran the fused kernel: time the temporal attention core by itself, as the main line does
+            k_ms["attn_temporal"] = standalone_temporal_attention(pkg, torch, dev, model, batch["src_key_padding_mask_frames"], B, T, d, H,
+                                                                  c["num_temporal_layers"])
+            note = {"note": "core kernel of the two-launch path (STLT_FUSED_MHSA=0), timed behind its in-projection on this batch: the forward itself runs roofline_mhsa_fused"}
+        except Exception as exc:
+            note = {"note": f"stand-alone timing failed: {type(exc).__name__}: {exc}"}
     at = _attn_rooflines(k_ms, B, T, N, d)
-    fused = mhsa_fused_roofline(k_ms, B, T, d, c["num_attention_heads"])
-    extra = {"roofline_mhsa_fused": fused} if fused else {}
-    try:  # the same leg with the opt-in split-bf16 products (beside the leg's numbers, as on the main line)
-        ref_logits = step().clone()
-        pkg.ops.set_gemm_split_bf16(6)
-        for _ in range(warmup):
-            step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            x3 = step()
-        torch.cuda.synchronize(dev)
-        x3_sec = (time.perf_counter() - t0) / steps
-        extra["split_bf16"] = {"value": round(B / x3_sec, 2), "unit": "clips/s", "ms_per_step": round(x3_sec * 1e3, 4),
-                               "logit_max_abs_diff_vs_f32_forward": float((x3 - ref_logits).abs().max())}
-    except Exception as exc:
-        extra["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
-    finally:
-        pkg.ops.set_gemm_split_bf16(0)
+    if split_bf16:
+        try:  # the same leg with the opt-in split-bf16 products (beside the leg's numbers, as on the main line)
+            ref_logits = step().clone()
+            pkg.ops.set_gemm_split_bf16(6)
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                x3 = step()
+            torch.cuda.synchronize(dev)
+            x3_sec = (time.perf_counter() - t0) / steps
+            extra["split_bf16"] = {"value": round(B / x3_sec, 2), "unit": "clips/s", "ms_per_step": round(x3_sec * 1e3, 4),
+                                   "logit_max_abs_diff_vs_f32_forward": float((x3 - ref_logits).abs().max())}
+        except Exception as exc:
+            extra["split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            pkg.ops.set_gemm_split_bf16(0)
+    dense = pkg.synth.flops_per_clip(T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"])
     return {**extra, "workload": f"{config}: STLT forward, T={T}, N={N}, d={d}, {c['num_classes']} classes", "per_gpu_batch": B, "steps": steps, "warmup": warmup,
-            "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4),
+            "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4), "flops_per_clip_dense": dense,
+            "dense_equivalent_tflops": round(dense * B / sec / 1e12, 2),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                          "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
-            "roofline_attn_temporal": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **at["attn_temporal"]),
-            "roofline_attn_spatial": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **at["attn_spatial"])}
+            "roofline_attn_temporal": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **at["attn_temporal"], **note),
+            "roofline_attn_spatial": dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", **at["attn_spatial"]),
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items() if v[1] > 0}}
 
 
 def side_fusion_leg(pkg, torch, dev, B, steps, warmup):
@@ -573,9 +623,13 @@ def main():
         for name in ("gemm", "attn_temporal", "attn_spatial"):
             k_ms.setdefault(name, (0.0, 0))
         gemm_ms, gemm_n = k_ms["gemm"]
-        fused = bool(pkg._lib.load().stlt_fused_mhsa_active(T, d, c["num_attention_heads"])) and k_ms.get("mhsa_fused", (0.0, 0))[1] > 0
+        H = c["num_attention_heads"]
+        plan = fused_mhsa_plan(pkg, B, T, N, d, H, c["num_spatial_layers"], c["num_temporal_layers"], not args.no_cls_only)
+        fused_tp = plan["temporal"]["layers"] if k_ms.get("mhsa_fused", (0.0, 0))[1] > 0 else 0
+        fused_sp = plan["spatial"]["layers"] if k_ms.get("mhsa_fused_spatial", (0.0, 0))[1] > 0 else 0
+        fused = fused_tp > 0
         gflops = gemm_flops_per_step(B, T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"],
-                                     not args.no_cls_only, fused)
+                                     not args.no_cls_only, fused_tp, fused_sp)
         gemm_tflops = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         attn_temporal_note = ""
         if fused and k_ms["attn_temporal"][1] == 0:
@@ -583,22 +637,11 @@ def main():
             # The attention core alone is still reported against HBM: the same kernel the two-launch path runs, timed
             # here on a packed-QKV buffer of this batch (library events, stand-alone launches).
             try:
-                lw = model.backbone.transformer.layers[0].self_attn
-                xin = torch.rand(B * T, d, device=dev) * 2 - 1
-                qkv = torch.empty(B * T, 3 * d, device=dev)
-                pkg.ops.prof_enable(True)
-                for _ in range(20):  # the two-launch form of a temporal layer's first half: the core reads the QKV its in-projection just wrote
-                    pkg.ops.linear(xin, lw.in_proj_weight, lw.in_proj_bias, out=qkv)
-                    pkg.ops.attn_core(qkv.view(B, T, 3 * d), batch["src_key_padding_mask_frames"], True, c["num_attention_heads"])
-                torch.cuda.synchronize(dev)
-                ms, n = pkg.ops.prof_collect()["attn_temporal"]
-                pkg.ops.prof_enable(False)
-                k_ms["attn_temporal"] = (ms / n * c["num_temporal_layers"], c["num_temporal_layers"]) if n else (0.0, 0)
+                k_ms["attn_temporal"] = standalone_temporal_attention(pkg, torch, dev, model, batch["src_key_padding_mask_frames"], B, T, d, H,
+                                                                      c["num_temporal_layers"])
                 attn_temporal_note = ("the forward itself runs the fused kernel (roofline_mhsa_fused): this is the core kernel of the two-launch path "
                                       "(STLT_FUSED_MHSA=0), timed behind its in-projection on this batch, 20 launches; ")
-                del qkv, xin
             except Exception as exc:
-                pkg.ops.prof_enable(False)
                 print(f"[bench] stand-alone attention timing failed: {type(exc).__name__}: {exc}", file=sys.stderr)
         at_ms, at_n = k_ms["attn_temporal"]
         at_bytes = B * (16.0 * T * d + T)  # per launch: read packed QKV, write ctx, kpm byte
@@ -610,7 +653,7 @@ def main():
         # collected from inside the process); the summary is committed under profiles/ and only quoted when it was
         # taken on this workload.
         traffic_gemm = traffic_attn = traffic_attn_sp = traffic_mhsa = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"round{r}_traffic_pmc.json") for r in (3, 2)) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"round{r}_traffic_pmc.json") for r in (4, 3, 2)) if os.path.exists(q)), "")
         if args.config == "cfg2" and B == 1024 and not args.no_cls_only and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
@@ -630,7 +673,8 @@ def main():
             "roofline": {"kernel": "gemm_nt_kernel (f32 MFMA nn.Linear)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                          "note": "the out-proj / FFN2 products carry the layers' residual adds in their epilogues (STLT_FUSE_RESIDUAL, default on: LayerNorm passes read one tensor); with the adds in the LayerNorm pass the products alone measure about 0.006 higher",
-                         "traffic": traffic_gemm, "traffic_note": "avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), from the committed rocprofv3 --pmc passes of this command: " + os.path.basename(tpath), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4)},
+                         "traffic": traffic_gemm, "traffic_note": "QUOTED, not measured in this run: avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), from the committed rocprofv3 --pmc passes of this command (counters cannot be read from inside the process): " + os.path.basename(tpath), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4),
+                         "flops_per_step": gflops},
             "roofline_attn_temporal": {"kernel": "attn16_kernel<NB, FULL, CAUSAL=true> for T <= 64 (16-row tiles), attn_core_kernel beyond", "bound": "hbm", "achieved": round(at_gbs, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(at_gbs / HBM_PEAK_GBS, 4),
                                        "traffic": traffic_attn, "traffic_note": attn_temporal_note + "bytes/launch of the temporal kernel (its own symbol: the CAUSAL=true instantiation), L2 memory-side, " + os.path.basename(tpath) + "; algorithmic " + str(int(at_bytes)), "launches_per_step": at_n, "us_per_launch": round(at_ms / max(at_n, 1) * 1e3, 2)},
@@ -640,8 +684,55 @@ def main():
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()}, "ranks": ranks,
         }
         if fused:
-            out["roofline_mhsa_fused"] = mhsa_fused_roofline(k_ms, B, T, d, c["num_attention_heads"])
+            out["roofline_mhsa_fused"] = mhsa_fused_roofline(k_ms, plan, "temporal")
             out["roofline_mhsa_fused"]["traffic"] = traffic_mhsa
+        if fused_sp:
+            out["roofline_mhsa_fused_spatial"] = mhsa_fused_roofline(k_ms, plan, "spatial")
+        if world == 1 and not args.no_cls_only and not args.no_side_legs:
+            # The dense schedule beside `value`: every layer on every token (`--no-cls-only`), same batch, same weights.  `value` runs the
+            # exact elision of rows nobody reads (CLS-only last spatial layer, last-row-only last temporal layer: identical logits, both
+            # golden-tested); this leg shows how much of the headline is that elision and how much is kernel speed.
+            try:
+                model.backbone.cls_only_last_spatial = model.backbone.last_row_only_temporal = False
+                n_d = min(args.steps, 10)
+                for _ in range(3):
+                    dense_logits = step()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(n_d):
+                    step()
+                torch.cuda.synchronize(dev)
+                d_s = (time.perf_counter() - t1) / n_d
+                pkg.ops.prof_enable(True)
+                pkg.ops.prof_collect()
+                for _ in range(n_d):
+                    step()
+                torch.cuda.synchronize(dev)
+                dprof = pkg.ops.prof_collect()
+                pkg.ops.prof_enable(False)
+                dk = {k: (ms / n_d, int(n / n_d)) for k, (ms, n) in dprof.items()}
+                dplan = fused_mhsa_plan(pkg, B, T, N, d, H, c["num_spatial_layers"], c["num_temporal_layers"], False)
+                dfl = gemm_flops_per_step(B, T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"], False,
+                                          dplan["temporal"]["layers"] if dk.get("mhsa_fused", (0, 0))[1] else 0,
+                                          dplan["spatial"]["layers"] if dk.get("mhsa_fused_spatial", (0, 0))[1] else 0)
+                dg_ms, dg_n = dk.get("gemm", (0.0, 0))
+                dtf = dfl / (dg_ms * 1e-3) / 1e12 if dg_ms > 0 else 0.0
+                dense_fl = pkg.synth.flops_per_clip(T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"])
+                out["dense_schedule"] = {"value": round(B / d_s, 2), "unit": "clips/s", "ms_per_step": round(d_s * 1e3, 4), "steps": n_d,
+                                         "value_over_dense": round(clips_per_s / (B / d_s), 4),
+                                         "dense_tflops": round(dense_fl * B / d_s / 1e12, 2),
+                                         "logit_max_abs_diff_vs_value_schedule": float((dense_logits - logits).abs().max()),
+                                         "roofline": {"bound": "mfma", "achieved": round(dtf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                      "frac": round(dtf / MFMA_F32_PEAK_TFLOPS, 4), "launches_per_step": dg_n, "ms_per_step": round(dg_ms, 4)},
+                                         "note": "--no-cls-only: the last spatial layer on every object token and the last temporal layer on every frame, as the reference computes them; `value` skips rows nobody reads (bit-identical logits for the rows that are read)"}
+            except Exception as exc:  # the secondary legs must never cost the main line
+                out["dense_schedule"] = {"error": f"{type(exc).__name__}: {exc}"}
+            finally:
+                model.backbone.cls_only_last_spatial = model.backbone.last_row_only_temporal = True
+                try:
+                    pkg.ops.prof_enable(False)
+                except Exception:
+                    pass
         if world == 1 and not args.no_skip_padding:
             try:
                 # Same workload with STLT_FLAG_SKIP_PADDING (opt-in: only the real tokens / frames of the padded batch are
@@ -672,15 +763,22 @@ def main():
                         sk3_s = (time.perf_counter() - t1) / n_sk
                         sk_x3 = {"value": round(B / sk3_s, 2), "unit": "clips/s", "ms_per_step": round(sk3_s * 1e3, 4),
                                  "logit_max_abs_diff_vs_padded_f32": float((sk3_logits - logits).abs().max())}
+                    except Exception as exc:
+                        sk_x3 = {"error": f"{type(exc).__name__}: {exc}"}
                     finally:
                         pkg.ops.set_gemm_split_bf16(0)
-                model.backbone.skip_padding = False
                 out["skip_padding"] = {"value": round(B / sk_s, 2), "unit": "clips/s", "ms_per_step": round(sk_s * 1e3, 4), "split_bf16": sk_x3,
                                        "real_token_frac": round(real_tok / (B * T * N), 4),
                                        "real_frame_frac": round(float((~cpu_batch["src_key_padding_mask_frames"]).float().mean()), 4),
                                        "logit_max_abs_diff_vs_padded": float((sk_logits - logits).abs().max())}
             except Exception as exc:  # the secondary legs must never cost the main line
                 out["skip_padding"] = {"error": f"{type(exc).__name__}: {exc}"}
+            finally:  # the legs below time the padded f32 schedule again, whatever happened here
+                model.backbone.skip_padding = False
+                try:
+                    pkg.ops.set_gemm_split_bf16(0)
+                except Exception:
+                    pass
         if world == 1 and not args.no_split_bf16 and not args.split_bf16_main:
             try:
                 # Same workload with the forward products on the BF16 matrix cores as six bf16 piece products per f32 product
@@ -728,6 +826,10 @@ def main():
             for key, fn in (("train_step", lambda: side_train_leg(pkg, torch, dev, "cfg2", 64, 10, 3)),
                             ("cfg4", lambda: side_forward_leg(pkg, torch, dev, "cfg4", 64, 10, 3)),
                             ("small_batch", lambda: side_forward_leg(pkg, torch, dev, "cfg2", 64, 20, 5)),
+                            # the layouts the reference's StltDataset really emits (T = layout_num_frames + 1, datasets.py:97-113;
+                            # utils/parser.py:62-66): the released checkpoints' 32 + 1 frames x 8 slots, and the parser's default 16 + 1 x 5
+                            ("cfg2p", lambda: side_forward_leg(pkg, torch, dev, "cfg2p", B, 8, 2, split_bf16=False)),
+                            ("ref_default", lambda: side_forward_leg(pkg, torch, dev, "refdef", B, 8, 2, split_bf16=False)),
                             ("cfg5", lambda: side_fusion_leg(pkg, torch, dev, 256, 5, 2))):
                 try:
                     out[key] = fn()

@@ -97,16 +97,29 @@ int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* ds
 int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal,
                        int64_t S, int64_t L, int64_t H, int64_t dh, float* ctx, stlt_stream_t stream);
 
-/* Fused multi-head self-attention of the temporal tower (the north star's "fused MHSA"): the in-projection of
- * nn.MultiheadAttention (models.py:118-124: in_proj_weight (3d,d) rows [q;k;v], in_proj_bias) and the causal attention core
- * (mask of utils/model_utils.py:4-7 + src_key_padding_mask_frames, models.py:142-150) in ONE kernel: x (S*L, d) -> ctx (S*L, d),
- * the packed QKV tensor never goes to memory.  Only L == 32 frames per clip and 64-channel heads (d == 64*H); other shapes
- * return STLT_EINVAL (callers use stlt_linear_fwd + stlt_attn_core_fwd).  Same result as that pair to fp32 rounding. */
+/* Fused multi-head self-attention (the north star's "fused MHSA"): the in-projection of nn.MultiheadAttention
+ * (models.py:46-52,118-124: in_proj_weight (3d,d) rows [q;k;v], in_proj_bias) and the attention core in ONE kernel:
+ * x (S*L, d) -> ctx (S*L, d), the packed QKV tensor never goes to memory.  stlt_mhsa_fused_fwd is the temporal tower's form
+ * (causal mask of utils/model_utils.py:4-7 + src_key_padding_mask_frames, models.py:142-150).  Sequences of 1 <= L <= 64 tokens
+ * (the reference's layouts are T = layout_num_frames + 1 = 17 / 33, datasets.py:97-113; Action Genome 64) and 64-channel heads
+ * (d == 64*H); other shapes return STLT_EINVAL (callers use stlt_linear_fwd + stlt_attn_core_fwd).  Same result as that pair to
+ * fp32 rounding. */
 int stlt_mhsa_fused_fwd(const float* x, const float* in_proj_w, const float* in_proj_b, const uint8_t* kpm, int64_t S, int64_t L,
                         int64_t H, int64_t d, float* ctx, stlt_stream_t stream);
-/* 1 when stlt_forward / stlt_backbone_forward run their temporal layers through the fused kernel for this shape
- * (32 frames, 64-channel heads; STLT_FUSED_MHSA=0 in the environment switches back to the two launches). */
+/* The same kernel with every option: causal = 0 is the spatial tower's form (key-padding mask only, models.py:68-71; L up to
+ * ~36 tokens); qkv_out != NULL also writes the packed projections (S*L, 3d) — what a training forward keeps for the reverse
+ * sweep; dropout_p > 0 (needs qkv_out) drops attention probabilities with the library's counter mask at `site`, element index
+ * ((query token * H + head) << 8) | key position, exactly as stlt_attn_core_fwd_train does, so stlt_attn_core_bwd regenerates it. */
+int stlt_mhsa_fused_fwd_ex(const float* x, const float* in_proj_w, const float* in_proj_b, const uint8_t* kpm, int causal, int64_t S,
+                           int64_t L, int64_t H, int64_t d, float dropout_p, uint64_t seed, uint32_t site, float* ctx, float* qkv_out,
+                           stlt_stream_t stream);
+/* 1 when stlt_forward / stlt_backbone_forward / stlt_train_forward run their temporal layers through the fused kernel for this
+ * shape at batches that fill the device (64-channel heads, T <= 64 frames whose whole clips fill at least 112 of a work item's
+ * 128 rows: T = 17, 32, 64 do, T = 33 does not and keeps the two launches; STLT_FUSED_MHSA=0 in the environment switches the
+ * fused kernel off).  stlt_fused_mhsa_used answers for one launch of S sequences of L tokens (causal: temporal tower, else the
+ * spatial tower): it also weighs how well S fills the last round of workgroups. */
 int stlt_fused_mhsa_active(int64_t T, int64_t d, int64_t H);
+int stlt_fused_mhsa_used(int64_t S, int64_t L, int64_t d, int64_t H, int causal);
 /* Cross-attention core (CrossAttentionLayer of CAF/CACNF, models.py:362-382; also self-attention on unpacked buffers):
  * queries q (S*Lq rows, stride ldq floats) attend to keys k / values v (S*Lk rows, stride ldkv).  kpm: (S*Lk) bytes over
  * the KEY tokens (pass zeros for no padding mask).  ctx: (S*Lq, H*dh).  causal requires Lq == Lk. */
@@ -263,7 +276,10 @@ int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, cons
  * + s*0xD1B54A32D192ED03), element idx of site s is kept iff the keyed 32-bit mixer of csrc/common.h (stlt_keep_k: two
  * multiply-xorshift rounds over idx + key_lo, key_hi folded in between) is >= p*2^32; kept values are scaled by 1/(1-p).
  * The backward recomputes the masks from (p, seed): pass the same values to both calls.  p = 0 disables it.
- * Attention backward supports sequences of up to 256 tokens (the position table). */
+ * Attention backward supports sequences of up to 256 tokens (the position table).  At most STLT_TRAIN_MAX_CATEGORIES object
+ * categories (the embedding-gradient kernel keeps per-category sums in LDS; the reference's vocabularies have 4 and 38):
+ * stlt_train_scratch_bytes returns 0 and stlt_train_forward / _backward return STLT_EINVAL above it, before anything runs. */
+#define STLT_TRAIN_MAX_CATEGORIES 128
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);
 size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories);
 /* flags: 0, or STLT_FLAG_SKIP_PADDING (the same value in both calls of a step): forward and reverse sweep run over the
@@ -420,8 +436,9 @@ int stlt_eval_average_precision(const float* scores, const float* truths, int64_
 #define STLT_K_EMBED_BWD 10    /* embedding / frames-embedding backward */
 #define STLT_K_OPTIM 11        /* criterion, gradient norm, AdamW */
 #define STLT_K_MISC 12         /* row gathers / scatters, column sums, ragged index, the head's small products */
-#define STLT_K_MHSA_FUSED 13    /* fused in-projection + causal attention core (stlt_mhsa_fused_fwd) */
-#define STLT_K_COUNT 14
+#define STLT_K_MHSA_FUSED 13    /* fused in-projection + causal attention core (stlt_mhsa_fused_fwd): temporal tower */
+#define STLT_K_MHSA_FUSED_SPATIAL 14  /* the same kernel's non-causal launches (spatial tower) */
+#define STLT_K_COUNT 15
 /* The switch is process-wide; the records (and both calls below) belong to the device that is CURRENT when they are made: a
  * process driving several GPUs collects once per device (with that device current) before it switches timing off, or the
  * other devices' records stay queued. */

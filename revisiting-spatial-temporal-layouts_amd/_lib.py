@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STLT_HIP_LIB") or os.path.join(HERE, "libstlt_hip.so")  # env override: A/B experiments only
 
 K_NAMES = ("embed", "gemm", "attn_spatial", "attn_temporal", "add_layernorm", "frames_embed", "gather_last", "ln_bwd", "attn_bwd",
-           "gelu", "embed_bwd", "optim", "misc", "mhsa_fused")
+           "gelu", "embed_bwd", "optim", "misc", "mhsa_fused", "mhsa_fused_spatial")
 FLAG_CLS_ONLY_LAST_SPATIAL = 1
 FLAG_LAST_ROW_ONLY_TEMPORAL = 2
 FLAG_SKIP_PADDING = 4
@@ -95,6 +95,9 @@ SIGNATURES = {
     "stlt_attn_core_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_mhsa_fused_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_fused_mhsa_active": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
+    "stlt_fused_mhsa_used": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "stlt_mhsa_fused_fwd_ex": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_uint64, C.c_uint32,
+                                         _vp, _vp, _vp]),
     "stlt_attn_cross_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_attn_ragged_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp, _vp]),

@@ -48,7 +48,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "stlt_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "stlt_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -80,7 +80,10 @@ def _compile_one(src_name: str, flags, verbose: bool) -> str:
 
 
 def _link(objs, out: str, verbose: bool) -> str:
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", out + f".{os.getpid()}.tmp"]
+    # the dynamic symbol table holds the C-ABI only (csrc/exports.map: `stlt_*` — the launchers shared between the sources have
+    # C++ linkage and mangled names, which the pattern does not match; tests/test_host_cpu.py compares the table with the header)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}",
+           *objs, "-o", out + f".{os.getpid()}.tmp"]
     if verbose:
         print("[stlt build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -89,7 +89,16 @@ void stlt_prof_end(int kid, hipStream_t s) {
 }
 
 unsigned long long* g_stlt_debug_buf = nullptr;
-static bool fused_mhsa();  // defined with the whole-path orchestration below
+
+// Layers whose sequences have at most 64 tokens (and 64-channel heads) run the in-projection and the attention core as ONE kernel
+// (mhsa.hip: the packed QKV tensor never reaches HBM).  Round 3 had this for 32-frame clips only; round 4's kernel takes the
+// reference's real layouts (T = 17 / 33, datasets.py:97-113), cfg4's 64 frames and the training forward.  STLT_FUSED_MHSA=0
+// restores the two launches everywhere, STLT_FUSED_MHSA_SPATIAL=0 for the spatial tower's (non-causal) layers only (A/B runs).
+bool stlt_fused_mhsa_on(int causal) {
+  static const bool on = [] { const char* e = getenv("STLT_FUSED_MHSA"); return e ? atoi(e) != 0 : true; }();
+  static const bool spatial = [] { const char* e = getenv("STLT_FUSED_MHSA_SPATIAL"); return e ? atoi(e) != 0 : true; }();
+  return on && (causal || spatial);
+}
 
 extern "C" {
 
@@ -175,11 +184,18 @@ int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal, int64_t
                      (hipStream_t)stream);
 }
 
-int stlt_fused_mhsa_active(int64_t T, int64_t d, int64_t H) { return (T == 32 && H > 0 && d == H * 64 && fused_mhsa()) ? 1 : 0; }
+int stlt_fused_mhsa_active(int64_t T, int64_t d, int64_t H) { return (stlt_fused_mhsa_on(1) && stlt_mhsa_fused_pays(1 << 20, T, H, d, 1)) ? 1 : 0; }
+int stlt_fused_mhsa_used(int64_t S, int64_t L, int64_t d, int64_t H, int causal) { return (stlt_fused_mhsa_on(causal) && stlt_mhsa_fused_pays(S, L, H, d, causal)) ? 1 : 0; }
 
 int stlt_mhsa_fused_fwd(const float* x, const float* in_proj_w, const float* in_proj_b, const uint8_t* kpm, int64_t S, int64_t L, int64_t H,
                         int64_t d, float* ctx, stlt_stream_t stream) {
   return launch_mhsa_fused(x, in_proj_w, in_proj_b, kpm, S, L, H, d, ctx, (hipStream_t)stream);
+}
+
+int stlt_mhsa_fused_fwd_ex(const float* x, const float* in_proj_w, const float* in_proj_b, const uint8_t* kpm, int causal, int64_t S, int64_t L,
+                           int64_t H, int64_t d, float dropout_p, uint64_t seed, uint32_t site, float* ctx, float* qkv_out, stlt_stream_t stream) {
+  if (dropout_p < 0.f || dropout_p >= 1.f) return stlt_set_error(STLT_EINVAL, "stlt_mhsa_fused_fwd_ex: dropout_p must be in [0, 1)");
+  return launch_mhsa_fused(x, in_proj_w, in_proj_b, kpm, S, L, H, d, ctx, (hipStream_t)stream, causal, qkv_out, stlt_drop_make(dropout_p, seed), site);
 }
 
 int stlt_attn_cross_fwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm, int causal,
@@ -257,21 +273,13 @@ static bool fuse_residual() {
   return on;
 }
 
-// Temporal layers with 32-frame clips and 64-channel heads run the in-projection and the attention core as ONE kernel
-// (mhsa.hip: the packed QKV tensor never reaches HBM) — measured faster than the two launches at every batch size tried
-// (stand-alone 64 / 256 / 1024 clips: 81.8 / 226.7 / 896.8 us against 101.0 / 282.5 / 919.7).  STLT_FUSED_MHSA=0
-// restores the two launches (A/B runs).
-static bool fused_mhsa() {
-  static const bool on = [] { const char* e = getenv("STLT_FUSED_MHSA"); return e ? atoi(e) != 0 : true; }();
-  return on;
-}
 // qkv projection + attention core of a layer: ctx (M,d) from x (M,d)
 static int qkv_attention(const stlt_layer_params& lp, int64_t d, int64_t H, const float* x, int64_t M, int64_t S, int64_t L,
                          const uint8_t* kpm, int causal, int kid, float* qkv, float* ctx, hipStream_t s) {
   // with the opt-in split-bf16 products on, a temporal in-projection they take is faster as its own launch (+ the attention core)
   // than inside the fused f32-MFMA kernel
-  if (causal && L == 32 && d == H * 64 && fused_mhsa() && !stlt_split_bf16_takes(M, 3 * d, d, d, d))
-    return launch_mhsa_fused(x, lp.in_proj_w, lp.in_proj_b, kpm, S, L, H, d, ctx, s);
+  if (stlt_fused_mhsa_on(causal) && stlt_mhsa_fused_pays(S, L, H, d, causal) && !stlt_split_bf16_takes(M, 3 * d, d, d, d))
+    return launch_mhsa_fused(x, lp.in_proj_w, lp.in_proj_b, kpm, S, L, H, d, ctx, s, causal);
   if (int e = launch_linear(x, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s)) return e;
   return launch_attn(qkv, kpm, causal, S, L, H, d / H, ctx, kid, s);
 }

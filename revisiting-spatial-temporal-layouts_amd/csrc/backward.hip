@@ -122,6 +122,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// The same for rows of 1025 .. 2048 channels (no shape of the path: every released model has d = 768; kept so that the training
+// entry points take what the forward takes).  With such a row and its three accumulator rows in registers the kernel above needed
+// 512 VGPRs, 659 spilled registers and 728 B of scratch per lane; here the per-wave partial rows live in dynamic LDS
+// (4 waves x 3 x d floats) and a wave walks its row four times (mean, variance, the two gradient sums, the output), re-reading it
+// from the cache instead of holding it.  Rows in row order per wave, waves in wave order per block: a fixed summation order.
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ a, int64_t lda,
+                                                          const float* __restrict__ b2, int64_t ldb, const float* __restrict__ w, float eps, int64_t M,
+                                                          int d, float* __restrict__ ds, int64_t ldds, float* __restrict__ partials, StltDrop dr,
+                                                          uint32_t site_b2, float* __restrict__ ds_drop, uint32_t site_dy,
+                                                          const int* __restrict__ drop_rows) {
+  extern __shared__ __attribute__((aligned(16))) float lds_acc[];  // [wave][dw | db | colsum][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t gw = (int64_t)blockIdx.x * RW_WAVES + wave;
+  const int64_t n_waves = (int64_t)gridDim.x * RW_WAVES;
+  float* acc = lds_acc + wave * 3 * d;
+#pragma unroll 1
+  for (int e = lane * 4; e < 3 * d; e += 256) *reinterpret_cast<f32x4*>(acc + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float inv_d = 1.0f / (float)d;
+  for (int64_t row = gw; row < M; row += n_waves) {
+    const uint64_t drow = (dr.thr && drop_rows) ? (uint64_t)drop_rows[row] : (uint64_t)row;
+    auto load_s = [&](int e) {  // the LayerNorm input a + drop(b2)
+      f32x4 v = *reinterpret_cast<const f32x4*>(a + row * lda + e);
+      if (b2) {
+        f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + row * ldb + e);
+        if (dr.thr && site_b2) bv = stlt_drop4(dr, site_b2, drow * d + e, bv);
+        v += bv;
+      }
+      return v;
+    };
+    auto load_g = [&](int e) {  // the output gradient behind the dropout on the LN output
+      f32x4 v = *reinterpret_cast<const f32x4*>(dy + row * lddy + e);
+      if (dr.thr && site_dy) v = stlt_drop4(dr, site_dy, drow * d + e, v);
+      return v;
+    };
+    float sum = 0.f;
+#pragma unroll 1
+    for (int e = lane * 4; e < d; e += 256) { const f32x4 v = load_s(e); sum += (v.x + v.y) + (v.z + v.w); }
+    const float mean = wave_sum(sum) * inv_d;
+    float q = 0.f;
+#pragma unroll 1
+    for (int e = lane * 4; e < d; e += 256) { const f32x4 v = load_s(e) - mean; q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll 1
+    for (int e = lane * 4; e < d; e += 256) {
+      const f32x4 xh = (load_s(e) - mean) * rstd;
+      f32x4 g = load_g(e);
+      *reinterpret_cast<f32x4*>(acc + d + e) += g;
+      *reinterpret_cast<f32x4*>(acc + e) += g * xh;
+      g *= *reinterpret_cast<const f32x4*>(w + e);
+      sg += (g.x + g.y) + (g.z + g.w);
+      sgx += (g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w);
+    }
+    const float mg = wave_sum(sg) * inv_d, mgx = wave_sum(sgx) * inv_d;
+#pragma unroll 1
+    for (int e = lane * 4; e < d; e += 256) {
+      const f32x4 xh = (load_s(e) - mean) * rstd;
+      const f32x4 g = load_g(e) * *reinterpret_cast<const f32x4*>(w + e);
+      const f32x4 o = (g - mg - xh * mgx) * rstd;
+      *reinterpret_cast<f32x4*>(ds + row * ldds + e) = o;
+      if (ds_drop) {
+        const f32x4 od = stlt_drop4(dr, site_b2, drow * d + e, o);
+        *reinterpret_cast<f32x4*>(ds_drop + row * ldds + e) = od;
+        *reinterpret_cast<f32x4*>(acc + 2 * d + e) += od;
+      } else {
+        *reinterpret_cast<f32x4*>(acc + 2 * d + e) += o;
+      }
+    }
+  }
+  if (partials) {
+    __syncthreads();
+    for (int e = threadIdx.x * 4; e < 3 * d; e += 256 * 4) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(lds_acc + e);
+#pragma unroll
+      for (int w2 = 1; w2 < RW_WAVES; ++w2) t += *reinterpret_cast<const f32x4*>(lds_acc + w2 * 3 * d + e);
+      *reinterpret_cast<f32x4*>(partials + (int64_t)blockIdx.x * 3 * d + e) = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients)
 // partials[blockIdx.y][n] = sum over this block's row range of x[m][n]; 256 threads = 256 consecutive columns.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N,
@@ -610,6 +690,14 @@ inline int nv_for(int64_t d) { return (int)((d + 255) / 256); }
     default: { constexpr int NV = 8; __VA_ARGS__; } break;     \
   }
 
+#define DISPATCH_NV4(nv, ...)                                  \
+  switch (nv) {                                                \
+    case 1: { constexpr int NV = 1; __VA_ARGS__; } break;      \
+    case 2: { constexpr int NV = 2; __VA_ARGS__; } break;      \
+    case 3: { constexpr int NV = 3; __VA_ARGS__; } break;      \
+    default: { constexpr int NV = 4; __VA_ARGS__; } break;     \
+  }
+
 // ds = dLN(dy; s = a (+ b2)); parameter gradients ACCUMULATE into g_w / g_b (either may be null).
 // scratch: >= ln_bwd_scratch_floats(d) floats.
 int64_t ln_bwd_scratch_floats(int64_t d) { return 512 * 3 * d; }
@@ -624,9 +712,21 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   int64_t blocks = (M + 4 * RW_WAVES - 1) / (4 * RW_WAVES);  // ~4 rows per persistent wave until the cap binds
   if (blocks > 512) blocks = 512;  // one partial row set per block (scratch is sized for that)
   StltProfScope ps(STLT_K_LN_BWD, s);
-  DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
-                                            ldb, w, eps, M, (int)d, ds, ldds, scratch, dr, site_b2,
-                                            (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy, drop_rows));
+  if (nv_for(d) > 4) {  // d > 1024: accumulators in LDS (no shape of the path has such rows; kept working without scratch memory)
+    const size_t lds = (size_t)RW_WAVES * 3 * d * sizeof(float);  // <= 96 KB
+    static StltPerDeviceOnce lds_once;
+    if (!lds_once.flag()) {
+      if (hipError_t e = hipFuncSetAttribute((const void*)ln_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RW_WAVES * 3 * 2048 * (int)sizeof(float)); e != hipSuccess)
+        return stlt_set_error((int)e, "ln_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      lds_once.flag() = true;
+    }
+    hipLaunchKernelGGL(ln_bwd_wide_kernel, dim3((unsigned)blocks), dim3(256), lds, s, dy, lddy, a, lda, b2, ldb, w, eps, M, (int)d, ds, ldds, scratch, dr,
+                       site_b2, (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy, drop_rows);
+  } else {
+    DISPATCH_NV4(nv_for(d), hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, a, lda, b2,
+                                               ldb, w, eps, M, (int)d, ds, ldds, scratch, dr, site_b2,
+                                               (dr.thr && site_b2) ? ds_drop : (float*)nullptr, site_dy, drop_rows));
+  }
   if (int e = stlt_check_launch("ln_bwd_kernel")) return e;
   // partial rows are interleaved [block][dw|db|colsum][d]: one strided reduction for the three destinations
   return launch_reduce_slabs3(scratch, 3 * d, (int)blocks, g_w, g_b, g_colsum, d, 1, s);

@@ -157,8 +157,14 @@ int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, i
 int launch_attn_bwd16(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* dqkv,
                       StltDrop dr, uint32_t site, float* scratch, int want_colsum, int* chunks_out, hipStream_t s,
                       bool* taken);  // attn_bwd16.hip; *taken = false: not this kernel's shape
-int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, const uint8_t* kpm, int64_t n_clips, int64_t T, int64_t H,
-                      int64_t d, float* ctx, hipStream_t s);  // mhsa.hip: in-projection + causal attention core, T == 32, 64-channel heads
+// mhsa.hip: in-projection + attention core in one kernel (sequences of <= 64 tokens, 64-channel heads); qkv_out: also write the
+// packed projections (training tape); dr / site: dropout of the probabilities (needs qkv_out)
+bool stlt_mhsa_fused_takes(int64_t L, int64_t H, int64_t d, int causal);           // the kernel has this shape
+bool stlt_mhsa_fused_pays(int64_t S, int64_t L, int64_t H, int64_t d, int causal);  // ... and is the faster form for S sequences (whole-path dispatch)
+bool stlt_fused_mhsa_on(int causal);  // api.hip: the whole-path entry points use the fused kernel (STLT_FUSED_MHSA=0 / STLT_FUSED_MHSA_SPATIAL switch it)
+int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, const uint8_t* kpm, int64_t S, int64_t L, int64_t H,
+                      int64_t d, float* ctx, hipStream_t s, int causal = 1, float* qkv_out = nullptr,
+                      StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 struct AttnBwdRagged;
 int launch_attn_bwd16_ragged(const float* qkv, const float* dctx, const AttnBwdRagged& rg, int causal, int64_t H, float* dqkv, StltDrop dr,
                              uint32_t site, float* scratch, int want_colsum, int* chunks_out, hipStream_t s, bool* taken);  // attn_bwd16.hip, ragged layout

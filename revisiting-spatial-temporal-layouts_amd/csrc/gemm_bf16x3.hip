@@ -435,6 +435,12 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
   if (!stlt_split_bf16_takes(M, N, K, ldx, ldw)) return 0;
   if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU) return 0;
   if (r && act != STLT_ACT_NONE) return 0;
+  // the argument checks launch_gemm makes for the f32 kernel: with the opt-in switch on, a bad call must still come back as
+  // STLT_EINVAL, not as an out-of-bounds device access (pointers, row pitches below the row length)
+  if (!x || !w || !y) return stlt_set_error(STLT_EINVAL, "gemm (split-bf16): null pointer");
+  if (ldx < K || ldw < K || ldy < N || (r && ldr < N))
+    return stlt_set_error(STLT_EINVAL, "gemm (split-bf16): bad leading dimension (ldx=%lld ldw=%lld ldy=%lld ldr=%lld for N=%lld K=%lld)", (long long)ldx,
+                          (long long)ldw, (long long)ldy, (long long)ldr, (long long)N, (long long)K);
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int64_t cus = stlt_device_cus();
   StltProfScope ps(STLT_K_GEMM, s);
@@ -472,6 +478,8 @@ int launch_input_grad_bf16x3(const float* dy, int64_t ld_dy, const float* w, int
                              int64_t ldc, int64_t rows, float* wt_scratch, hipStream_t s, bool* taken) {
   *taken = false;
   if (!wt_scratch || !stlt_split_bf16_takes(rows, k_in, n_out, ld_dy, n_out)) return 0;
+  if (!dy || !w || !c) return stlt_set_error(STLT_EINVAL, "input gradient (split-bf16): null pointer");
+  if (ld_dy < n_out || ldc < k_in || (r && ldr < k_in)) return stlt_set_error(STLT_EINVAL, "input gradient (split-bf16): bad leading dimension");
   hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)((k_in + 31) / 32), (unsigned)((n_out + 31) / 32)), dim3(256), 0, s, w, (int)n_out, (int)k_in, wt_scratch);
   if (int e = stlt_check_launch("weight_transpose_kernel")) return e;
   return launch_linear_bf16x3(dy, ld_dy, wt_scratch, n_out, nullptr, r, ldr, c, ldc, rows, k_in, n_out, STLT_ACT_NONE, s, taken);

@@ -1,22 +1,13 @@
-// Fused in-projection + causal attention core for the temporal tower (SURVEY.md §8 row N1 / the north star's "fused MHSA"):
-//   ctx[b, :, h] = softmax(q_h k_hᵀ / 8 + causal + key padding) v_h   with   [q_h | k_h | v_h] = X_b · W_in[h]ᵀ + b_in[h]
-// for clips of exactly 32 frames and 64-channel heads (nn.MultiheadAttention as configured at models.py:118-124; mask of
-// utils/model_utils.py:4-7).  The packed QKV tensor never goes to HBM: only X is read and ctx written.
+// Fused in-projection + attention core (SURVEY.md §8 row N1 / the north star's "fused MHSA"):
+//   ctx[s, :, h] = softmax(q_h k_hᵀ / 8 + mask) v_h   with   [q_h | k_h | v_h] = X_s · W_in[h]ᵀ + b_in[h]
+// for sequences of up to 64 tokens and 64-channel heads (nn.MultiheadAttention as configured at models.py:46-52,118-124; masks of
+// models.py:68-71 (key padding) and utils/model_utils.py:4-7 + models.py:142-150 (causal + key padding)).  The packed QKV tensor
+// never goes to HBM in inference: only X is read and ctx written.
 //
-// Work item = (group of 4 clips = 128 token rows, head): a 128 x 192 x d product on the f32 MFMA (the 192 output columns
-// are the head's 64 q, k and v channels), then the four 32 x 32 attention problems of the group, all in one workgroup:
-//   * 8 MFMA waves as (clip mb = wave & 3, channel half nh = wave >> 2): a wave owns one clip's 32 rows and channels
-//     [32 nh, 32 nh + 32) of q, k and v — three 32x32 MFMA tiles (48 accumulators), computed transposed (D[channel][token])
-//     like gemm.hip, so a lane owns a token and its registers are channels;
-//   * in that layout the q and k accumulators ARE the MFMA operands of Sᵀ = K Qᵀ over the wave's 32 channels (register r
-//     of both operands is the same channel pair), no data movement; the two channel halves of a clip add their partial
-//     scores through LDS (4 KB each way);
-//   * mask + softmax over a lane's 32 keys in registers (one cross-half shuffle), probabilities stay in registers as the B
-//     operand of Oᵀ = Vᵀ Pᵀ; the wave's v half goes through a private 32x33 LDS tile (the A operand wants lane = channel);
-//   * each lane stores its token's 32 output channels with four 16-byte stores.
-// Operand staging is gemm.hip's: LDS-DMA with the source-side bank swizzle, three 40-KB stages, four DMA-only loader waves
-// running two k-steps ahead with a counted vmcnt, one barrier per k-step, the bias strip DMA'd one item ahead; the loaders
-// keep the next item's first k-steps in flight while the MFMA waves are in the attention phase.
+// Round 3's kernel (32-token sequences only, 32x32 MFMA tiles, a wave = (clip, channel half), partial scores exchanged through
+// LDS) is gone: the kernel below is faster on its own shape (64 / 256 / 1024 clips of 32 frames: 79.2 / 221.0 / 869.0 us against
+// 85.7 / 242.2 / 896.1, profiles/round4_mhsa_fused_ab.txt) and takes every other one.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -26,31 +17,62 @@ constexpr int F_WAVES = 8, F_LOADERS = 4;
 constexpr int F_THREADS = 64 * (F_WAVES + F_LOADERS);
 constexpr int F_NSTAGE = 3;
 constexpr int F_STAGE = (FM + FN) * FK;        // 10240 floats = 40 KB
-constexpr int F_ATT_WAVE = 1088;               // per-wave attention scratch: 16x64 partial scores, then the 32x33 v tile
-constexpr int F_SMEM = F_NSTAGE * F_STAGE + F_WAVES * F_ATT_WAVE + 2 * FN;  // 39808 floats = 159232 B
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-__global__ __launch_bounds__(F_THREADS, 3) void mhsa_fused_kernel(const float* __restrict__ X, const float* __restrict__ Win,
-                                                                  const float* __restrict__ bin, const uint8_t* __restrict__ kpm,
-                                                                  float* __restrict__ ctx, int n_clips, int H, int d, float scale) {
+// Any sequence length up to 64 tokens (the reference's real layouts are T = layout_num_frames + 1 = 17 / 33, datasets.py:97-113;
+// cfg4 has 64 frames), training forwards (probability dropout, packed QKV written for the tape) and — CAUSAL = false — the spatial
+// tower's frames of N objects.
+//
+// Work item = (G = floor(128 / L) whole sequences = G·L <= 128 consecutive token rows, head): a 128 x 192 x d product (the 192
+// output columns are the head's 64 q, k and v channels) on v_mfma_f32_16x16x4_f32, 8 MFMA waves + 4 DMA-only loader waves, with
+// an MFMA wave owning ONE 16-row block and ALL 192 output columns (12 accumulators of
+// 16 channels x 16 tokens, computed transposed: lane = token, registers = 4 consecutive channels).  That makes the attention
+// phase independent of where sequences start inside the item:
+//   * a wave's q accumulators are, as they stand, the B operand of Sᵀ = K·Qᵀ for its 16 queries over all 64 channels (no
+//     partial-score exchange between waves);
+//   * k and v leave the accumulators as 16-byte LDS stores into two 128-row tiles [token][channel] (chunk ^= token & 15): the K
+//     tile lives in the operand stage the item's last k-step retired (the loaders refill it only after the phase's second
+//     barrier), the V tile in 32 KB of its own;
+//   * a query block needs the key blocks from the first row of its first query's sequence to its own block (causal) or to the
+//     last row of its last query's sequence: NKB <= 5 blocks of 16 keys, all scores in registers (attn16.hip's one-pass softmax),
+//     mask = (same sequence) & (key position <= query position) & (key not padded) from one metadata word per key row;
+//   * Oᵀ = Vᵀ·Pᵀ with the probabilities in registers as the B operand; a lane stores 4 consecutive channels of its query per
+//     channel block (16-byte stores), and in TRAIN builds its q / k / v accumulators to the tape's packed QKV rows.
+// Operand staging is gemm.hip's: LDS-DMA with the source-side bank swizzle, three 40-KB stages, the loader waves two k-steps ahead
+// with a counted vmcnt, one barrier per k-step, the bias strip DMA'd one item ahead; the 16-lane x 4-chunk fragment reads are
+// conflict-free under that swizzle (every ds_read_b128 lane group covers all 16 slots of the 256-byte bank row).
+constexpr int G_VT = FM * 64;                                             // V tile: 128 token rows x 64 channels
+constexpr int G_SMEM = F_NSTAGE * F_STAGE + G_VT + 2 * FN + FM;           // + bias strips + key metadata: 39424 floats = 157696 B
+
+struct Mhsa16Args {
+  const float* X; const float* Win; const float* bin; const uint8_t* kpm;
+  float* ctx; float* qkv;   // qkv: TRAIN only (packed rows [q;k;v], 3d floats per token)
+  int n_tokens, L, rows_per_item, n_groups, H, d;
+  float scale;
+  StltDrop dr; uint32_t site;
+};
+
+template <int NKB, bool CAUSAL, bool TRAIN>
+__global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31, lh = lane >> 5;
+  const int d = a.d, H = a.H;
   const int nk = d / FK;
-  const int M = n_clips * 32;
-  const int n_groups = (n_clips + 3) >> 2;
-  const int n_items = n_groups * H;  // head fastest: the 12 heads of a clip group sit on neighbouring workgroups of one XCD
+  const int M = a.n_tokens;
+  const int n_items = a.n_groups * H;  // head fastest: the heads of a row group sit on neighbouring workgroups of one XCD
   const int G = gridDim.x;
   int v = blockIdx.x;
   if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous virtual id (round-robin dispatch)
   const int my_items = (n_items - v + G - 1) / G;
   if (my_items <= 0) return;
   const int total_steps = my_items * nk;
-  float* bias_lds = smem + F_NSTAGE * F_STAGE + F_WAVES * F_ATT_WAVE;
+  float* Vt = smem + F_NSTAGE * F_STAGE;
+  float* bias_lds = Vt + G_VT;
+  int* kmeta = reinterpret_cast<int*>(bias_lds + 2 * FN);
   auto item_of = [&](int it, int& grp, int& head) {
     const int item = v + it * G;
     grp = item / H;
@@ -58,8 +80,8 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa_fused_kernel(const float* _
   };
 
   if (wave >= F_WAVES) {
-    // ---- loader waves: the whole DMA stream of the workgroup.  Loader L issues A rows [32L, 32L+32) and B rows [48L, 48L+48).
-    const int L = wave - F_WAVES;
+    // ---- loader waves: loader Ld issues A rows [32 Ld, 32 Ld + 32) and B rows [48 Ld, 48 Ld + 48); B image row r = (q|k|v = r / 64, channel r % 64)
+    const int Ld = wave - F_WAVES;
     const int drow = lane >> 3, dslot = lane & 7;
     const float* pa[4];
     const float* pb[6];
@@ -68,37 +90,33 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa_fused_kernel(const float* _
       item_of(it, grp, head);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = L * 32 + i * 8 + drow;
-        int gm = grp * FM + r;
-        gm = gm < M ? gm : M - 1;  // a ragged last group re-reads the last row; its stores are guarded
-        pa[i] = X + (int64_t)gm * d + (dslot ^ ((r >> 1) & 7)) * 4;
+        const int r = Ld * 32 + i * 8 + drow;
+        int gm = grp * a.rows_per_item + r;
+        gm = gm < M ? gm : M - 1;  // rows past the batch re-read the last row; nothing of theirs is stored
+        pa[i] = a.X + (int64_t)gm * d + (dslot ^ ((r >> 1) & 7)) * 4;
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const int r = L * 48 + i * 8 + drow;           // image row: (channel half, q|k|v, channel) = (r / 96, (r % 96) / 32, r % 32)
-        const int half = r / 96, rem = r - half * 96, which = rem >> 5, ch = rem & 31;
-        const int wrow = which * d + head * 64 + half * 32 + ch;
-        pb[i] = Win + (int64_t)wrow * d + (dslot ^ ((r >> 1) & 7)) * 4;
+        const int r = Ld * 48 + i * 8 + drow;
+        const int wrow = (r >> 6) * d + head * 64 + (r & 63);
+        pb[i] = a.Win + (int64_t)wrow * d + (dslot ^ ((r >> 1) & 7)) * 4;
       }
     };
     auto dma_bias = [&](int it) {
-      if (L == 0) {
+      if (Ld == 0) {
         int grp, head;
         item_of(it, grp, head);
         float* dst = bias_lds + (it & 1) * FN;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int r = i * 64 + lane;
-          const int half = r / 96, rem = r - half * 96, which = rem >> 5, ch = rem & 31;
-          __builtin_amdgcn_global_load_lds((glb_void_ptr)(bin + which * d + head * 64 + half * 32 + ch), (lds_void_ptr)(dst + i * 64), 4, 0, 0);
-        }
+        for (int i = 0; i < 3; ++i)
+          __builtin_amdgcn_global_load_lds((glb_void_ptr)(a.bin + i * d + head * 64 + lane), (lds_void_ptr)(dst + i * 64), 4, 0, 0);
       }
     };
     int l_it = 0, l_kt = 0, l_stage = 0;
     auto l_step = [&]() {
       if (l_kt == 0) set_item(l_it);
-      float* sa = smem + l_stage * F_STAGE + (L * 32) * FK;
-      float* sb = smem + l_stage * F_STAGE + FM * FK + (L * 48) * FK;
+      float* sa = smem + l_stage * F_STAGE + (Ld * 32) * FK;
+      float* sb = smem + l_stage * F_STAGE + FM * FK + (Ld * 48) * FK;
 #pragma unroll
       for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_void_ptr)(pa[i] + l_kt * FK), (lds_void_ptr)(sa + i * 8 * FK), 16, 0, 0);
 #pragma unroll
@@ -128,159 +146,296 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa_fused_kernel(const float* _
       if (++w_kt == nk) {
         ++w_it;
         w_kt = 0;
-        __builtin_amdgcn_s_barrier();  // the two barriers of the MFMA waves' attention phase
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();  // the MFMA waves' attention phase: K / V tiles written ...
+        __builtin_amdgcn_s_barrier();  // ... and the K tile (= the stage the next l_step refills) read
       }
     }
     return;
   }
 
-  // ---- MFMA waves
-  const int mb = wave & 3, nh = wave >> 2;
-  const int sw = (lr >> 1) & 7;
-  const int a_row = (mb * 32 + lr) * FK;
-  const int b_row = (FM + nh * 96 + lr) * FK;  // + 32*FK per tile (q, k, v)
-  float* att = smem + F_NSTAGE * F_STAGE + wave * F_ATT_WAVE;
-  float* att_partner = smem + F_NSTAGE * F_STAGE + (wave ^ 4) * F_ATT_WAVE;
-  struct Frags { f32x4 a, b0, b1, b2; };
-  auto read_frags = [&](int stage, int c) {
+  // ---- MFMA waves.  Row block of the wave: SIMD partners (waves w and w + 4) get blocks b and 7 - b, whose causal key-block
+  // counts add up to the same number on every SIMD when sequences are block-aligned (L = 32: 1 + 2, L = 64: 1 + 4, 2 + 3)
+  const int rb = wave < 4 ? wave : 11 - wave;
+  const int li_ = lane & 15, lg_ = lane >> 4;
+  const int sw = (li_ >> 1) & 7;  // rows 16 rb + li_ and 16 t + li_ share (row >> 1) & 7
+  const int x_row = (rb * 16 + li_) * FK;
+  const int w_row = (FM + li_) * FK;  // + 16 * FK per 16-channel tile
+  struct Frags { f32x4 x; f32x4 w[6]; };
+  auto read_frags = [&](int stage, int hc) {  // hc = half-chunk 0..3: k-chunk c = hc >> 1 (16 k each), tiles 6 (hc & 1) .. +5
     const float* s = smem + stage * F_STAGE;
-    const int off = ((2 * c + lh) ^ sw) * 4;
+    const int off = ((4 * (hc >> 1) + lg_) ^ sw) * 4;
     Frags f;
-    f.a = *reinterpret_cast<const f32x4*>(s + a_row + off);
-    f.b0 = *reinterpret_cast<const f32x4*>(s + b_row + off);
-    f.b1 = *reinterpret_cast<const f32x4*>(s + b_row + 32 * FK + off);
-    f.b2 = *reinterpret_cast<const f32x4*>(s + b_row + 64 * FK + off);
+    f.x = *reinterpret_cast<const f32x4*>(s + x_row + off);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) f.w[t] = *reinterpret_cast<const f32x4*>(s + w_row + (6 * (hc & 1) + t) * 16 * FK + off);
     return f;
   };
-  f32x16 aq, ak, av;  // D[channel][token]: register r of lane (lr, lh) = channel (r&3) + 8*(r>>2) + 4*lh of token lr
+  f32x4 acc[12];  // tile t = 16 output columns: q channels 16 t .. (t < 4), k (4 <= t < 8), v (t >= 8); lane (li_, lg_): token li_, channels 4 lg_ .. + 3
   auto init_acc = [&](int it) {
-    const float* src = bias_lds + (it & 1) * FN + nh * 96 + 4 * lh;
+    const float* src = bias_lds + (it & 1) * FN + 4 * lg_;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 vq = *reinterpret_cast<const f32x4*>(src + 8 * q);
-      const f32x4 vk = *reinterpret_cast<const f32x4*>(src + 32 + 8 * q);
-      const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 64 + 8 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { aq[4 * q + j] = vq[j]; ak[4 * q + j] = vk[j]; av[4 * q + j] = vv[j]; }
-    }
+    for (int t = 0; t < 12; ++t) acc[t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
   };
-  auto mfma_chunk = [&](const Frags& f) {
+  auto mfma_half = [&](const Frags& f, int half) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b0[e], f.a[e], aq, 0, 0, 0);
-      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b1[e], f.a[e], ak, 0, 0, 0);
-      av = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b2[e], f.a[e], av, 0, 0, 0);
-    }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc[6 * half + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[t][e], f.x[e], acc[6 * half + t], 0, 0, 0);
   };
 
   __builtin_amdgcn_s_barrier();  // the loaders' counted wait + this barrier publish step 0 and the first bias strip
   init_acc(0);
   int c_it = 0, c_kt = 0, stage = 0;
+  unsigned pad_byte = 1u;
   Frags fa = read_frags(0, 0), fb;
   for (int step = 0; step < total_steps; ++step) {
     const int next_stage = stage + 1 == F_NSTAGE ? 0 : stage + 1;
+    if (c_kt == 0) {  // this item's key-padding byte of the wave's row li_: in flight under the whole product
+      int grp, head;
+      item_of(c_it, grp, head);
+      const int g_row = grp * a.rows_per_item + rb * 16 + li_;
+      pad_byte = (rb * 16 + li_ < a.rows_per_item && g_row < M) ? (unsigned)a.kpm[g_row] : 1u;
+    }
     fb = read_frags(stage, 1);
-    mfma_chunk(fa);
+    mfma_half(fa, 0);
     fa = read_frags(stage, 2);
-    mfma_chunk(fb);
+    mfma_half(fb, 1);
     fb = read_frags(stage, 3);
-    mfma_chunk(fa);
+    mfma_half(fa, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own fragment reads of this stage are done
     __builtin_amdgcn_s_barrier();                        // retire the stage; step+1 landed
-    if (step + 1 < total_steps) fa = read_frags(next_stage, 0);
-    mfma_chunk(fb);
+    const bool item_done = c_kt + 1 == nk;
+    if (!item_done) fa = read_frags(next_stage, 0);  // (at the end of an item the attention phase comes first: fewer live registers there)
+    mfma_half(fb, 1);
+    const int dead_stage = stage;
     stage = next_stage;
-    if (++c_kt < nk) continue;
+    ++c_kt;
+    if (!item_done) continue;
 
-    // ---- attention phase of item c_it: this wave holds q, k, v channels [32 nh, 32 nh + 32) of clip mb
+    // ---- attention phase of item c_it
     int grp, head;
     item_of(c_it, grp, head);
-    const int clip = grp * 4 + mb;
-    const bool clip_ok = clip < n_clips;
-    // partial scores over the wave's 32 channels: Sᵀ[key][query] (lane = query, register r = key (r&3) + 8*(r>>2) + 4*lh)
-    f32x16 st;
+    // opaque copies of the lane coordinates: the phase's address arithmetic is recomputed per item (a few dozen VALU) instead of
+    // being hoisted out of the item loop into registers the k-loop cannot spare (it spilled 12 - 51 of them)
+    int li = li_, lg = lg_;
+    asm volatile("" : "+v"(li), "+v"(lg));
+    const int row0 = grp * a.rows_per_item;                                         // first token row of the item
+    const int rows_here = (M - row0) < a.rows_per_item ? (M - row0) : a.rows_per_item;  // whole sequences: a multiple of L
+    const int L = a.L;
+    float* Kt = smem + dead_stage * F_STAGE;
+    const int my_row = rb * 16 + li;
+    const bool row_ok = my_row < rows_here;
+    const int q_seq = my_row / L, q_pos = my_row - q_seq * L;
+    {  // k, v -> LDS tiles; this row's key metadata: -1 = absent / padded, else (sequence in item << 8) | position
+      const int base = my_row * 64;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      for (int cb = 0; cb < 4; ++cb) {
+        const int off = base + (((cb * 4 + lg) ^ li) * 4);
+        *reinterpret_cast<f32x4*>(Kt + off) = acc[4 + cb];
+        *reinterpret_cast<f32x4*>(Vt + off) = acc[8 + cb];
+      }
+      if (lg == 0) kmeta[my_row] = (row_ok && pad_byte == 0u) ? ((q_seq << 8) | q_pos) : -1;
+      if (TRAIN && row_ok) {
+        float* qrow = a.qkv + (int64_t)(row0 + my_row) * (3 * d) + head * 64 + 4 * lg;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[r], aq[r], st, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) att[r * 64 + lane] = st[r];
-    // key padding of this clip: bit j of `kmask` = key j is padded (each of the 32 low lanes looks at its own frame)
-    const unsigned pad_byte = clip_ok ? (unsigned)kpm[clip * 32 + lr] : 1u;
-    const unsigned kmask = (unsigned)__ballot(pad_byte != 0);  // lanes 0..31 = frames 0..31 (lanes 32..63 repeat them)
+        for (int t = 0; t < 12; ++t) *reinterpret_cast<f32x4*>(qrow + (t >> 2) * d + (t & 3) * 16) = acc[t];
+      }
+    }
+    // key blocks of this query block: from the block holding the first row of its first query's sequence ...
+    const int blk_row0 = rb * 16;
+    const bool blk_ok = blk_row0 < rows_here;  // wave-uniform
+    const int first_kb = ((blk_row0 / L) * L) >> 4;
+    int last_kb = rb;  // ... to its own block (causal), or to the block holding the last row of its last query's sequence
+    if (!CAUSAL) {
+      const int r_last = blk_row0 + 15 < rows_here ? blk_row0 + 15 : rows_here - 1;
+      last_kb = ((r_last / L + 1) * L - 1) >> 4;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // attention barrier 1: the partner's partial scores are in LDS
-    float p[16];
-    float m_row = -1e30f;
+    __builtin_amdgcn_s_barrier();  // attention barrier 1: every wave's K / V rows and metadata are in LDS
+    f32x4 st[NKB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float other = att_partner[r * 64 + lane];
-      const float s_full = nh == 0 ? st[r] + other : other + st[r];  // low channel half first in both waves: identical sums
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const bool ok = (j <= lr) & (((kmask >> j) & 1u) == 0u);
-      p[r] = ok ? s_full * scale : -1e30f;
-      m_row = fmaxf(m_row, p[r]);
-    }
-    m_row = fmaxf(m_row, __shfl_xor(m_row, 32, 64));
-    float l_row = 0.f;
+    for (int i = 0; i < NKB; ++i) {
+      st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int kb = first_kb + i;
+      if (blk_ok && kb <= last_kb) {
+        const float* krow = Kt + (kb * 16 + li) * 64;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      p[r] = p[r] > -1e29f ? __expf(p[r] - m_row) : 0.f;
-      l_row += p[r];
+        for (int cb = 0; cb < 4; ++cb) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + (((cb * 4 + lg) ^ li) * 4));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[r], acc[cb][r], st[i], 0, 0, 0);
+        }
+      }
     }
-    l_row += __shfl_xor(l_row, 32, 64);
-    const float inv = l_row > 0.f ? 1.0f / l_row : 0.f;  // fully masked row -> zeros
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // attention barrier 2: both waves of the pair have read the partial scores
-    // v half -> private LDS tile vs[key][channel] (row stride 33): the A operand of Oᵀ = Vᵀ Pᵀ wants lane = channel
+    __builtin_amdgcn_s_barrier();  // attention barrier 2: the K tile is read (the loaders may refill its stage); q, k, v accumulators are dead
+    if (blk_ok) {
+      // mask + softmax: st[i][r] = score of key (first_kb + i) * 16 + 4 lg + r against query li
+      float m = -1e30f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) att[lr * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = av[r];
-    if (c_it + 1 < my_items) init_acc(c_it + 1);  // q, k, v are consumed: the next item's bias strip is published (k-step barrier)
-    f32x16 o;
+      for (int i = 0; i < NKB; ++i) {
+        const int kb = first_kb + i;
+        if (kb <= last_kb) {
+          const int4 km = *reinterpret_cast<const int4*>(kmeta + kb * 16 + 4 * lg);
+          const int meta[4] = {km.x, km.y, km.z, km.w};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // DS operations of a wave complete in order: the tile is written
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = (meta[r] >= 0) & ((meta[r] >> 8) == q_seq) & (!CAUSAL || (meta[r] & 0xff) <= q_pos);
+            st[i][r] = ok ? st[i][r] * a.scale : -1e30f;
+            m = fmaxf(m, st[i][r]);
+          }
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(att[j * 33 + lr], p[r], o, 0, 0, 0);
-    }
-    if (clip_ok) {
-      float* orow = ctx + (int64_t)(clip * 32 + lr) * d + head * 64 + nh * 32 + 4 * lh;
+      for (int i = 0; i < NKB; ++i) {
+        if (first_kb + i <= last_kb) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 val = {o[4 * q] * inv, o[4 * q + 1] * inv, o[4 * q + 2] * inv, o[4 * q + 3] * inv};
-        *reinterpret_cast<f32x4*>(orow + 8 * q) = val;
+          for (int r = 0; r < 4; ++r) {
+            const float p = st[i][r] > -1e29f ? __expf(st[i][r] - m) : 0.f;
+            st[i][r] = p;
+            sum += p;
+          }
+        }
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
+      // TRAIN: dropout of the probabilities, applied where a probability is consumed (attn.hip's element index:
+      // ((query token * H + head) << 8) | key position; an unmasked key is in the query's sequence, so its position is its row minus
+      // the sequence's first row; masked keys have probability 0 either way)
+      const uint64_t drop_key = TRAIN ? stlt_drop_key(a.dr, a.site) : 0ull;
+      const uint64_t qidx = (((uint64_t)(row0 + my_row)) * H + head) << 8;
+      // Oᵀ[channel][query] += Vᵀ·Pᵀ: MFMA step (i, r) sums keys (first_kb + i) * 16 + 4 g + r over g
+      f32x4 o[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) o[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NKB; ++i) {
+        const int kb = first_kb + i;
+        if (kb <= last_kb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = kb * 16 + 4 * lg + r;
+            float pr = st[i][r];
+            if (TRAIN && a.dr.thr) pr = stlt_keep_k(a.dr.thr, drop_key, qidx | (uint64_t)((j - q_seq * L) & 0xff)) ? pr * a.dr.scale : 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+              const float vv = Vt[j * 64 + (((cb * 4 + (li >> 2)) ^ (j & 15)) * 4) + (li & 3)];
+              o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr, o[cb], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (row_ok) {
+        float* dst = a.ctx + (int64_t)(row0 + my_row) * d + head * 64 + 4 * lg;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(dst + 16 * cb) = o[cb] * inv;
       }
     }
     ++c_it;
     c_kt = 0;
+    if (step + 1 < total_steps) {  // next item: accumulators from its bias strip (published by the last k-step's barrier), first fragments
+      init_acc(c_it);
+      fa = read_frags(stage, 0);
+    }
+  }
+}
+
+// largest number of 16-key blocks a 16-query block of an item needs (host side; the kernel's NKB)
+static int mhsa16_key_blocks(int L, int rows_per_item, bool causal) {
+  int worst = 1;
+  for (int b = 0; b * 16 < rows_per_item; ++b) {
+    const int first_kb = ((b * 16 / L) * L) >> 4;
+    int last_kb = b;
+    if (!causal) {
+      const int r_last = b * 16 + 15 < rows_per_item ? b * 16 + 15 : rows_per_item - 1;
+      last_kb = ((r_last / L + 1) * L - 1) >> 4;
+    }
+    if (last_kb - first_kb + 1 > worst) worst = last_kb - first_kb + 1;
+  }
+  return worst;
+}
+
+template <int NKB, bool CAUSAL, bool TRAIN>
+static int launch_mhsa16_as(const Mhsa16Args& a, hipStream_t s) {
+  static StltPerDeviceOnce attr_done;
+  if (!attr_done.flag()) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)mhsa16_kernel<NKB, CAUSAL, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM * (int)sizeof(float)); e != hipSuccess)
+      return stlt_set_error((int)e, "mhsa16: %s", hipGetErrorString(e));
+    attr_done.flag() = true;
+  }
+  const int64_t n_items = (int64_t)a.n_groups * a.H;
+  int64_t G = stlt_device_cus();
+  if (G > n_items) G = n_items;
+  hipLaunchKernelGGL((mhsa16_kernel<NKB, CAUSAL, TRAIN>), dim3((unsigned)G), dim3(F_THREADS), G_SMEM * sizeof(float), s, a);
+  return stlt_check_launch("mhsa16_kernel");
+}
+
+template <bool CAUSAL, bool TRAIN>
+static int launch_mhsa16_nkb(int nkb, const Mhsa16Args& a, hipStream_t s) {
+  switch (nkb) {
+    case 1: return launch_mhsa16_as<1, CAUSAL, TRAIN>(a, s);
+    case 2: return launch_mhsa16_as<2, CAUSAL, TRAIN>(a, s);
+    case 3: return launch_mhsa16_as<3, CAUSAL, TRAIN>(a, s);
+    case 4: return launch_mhsa16_as<4, CAUSAL, TRAIN>(a, s);
+    default: return launch_mhsa16_as<5, CAUSAL, TRAIN>(a, s);
   }
 }
 
 }  // namespace
 
-// ctx (n_clips*32, d) = causal multi-head attention of every 32-frame clip with the in-projection fused in.
-// x (n_clips*32, d), w_in (3d, d) rows [q; k; v], b_in (3d), kpm (n_clips*32) bytes (1 = padded frame).
-int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, const uint8_t* kpm, int64_t n_clips, int64_t T, int64_t H,
-                      int64_t d, float* ctx, hipStream_t s) {
+// Does the fused kernel take this shape?  Sequences of 1..64 tokens, 64-channel heads, d a multiple of the 32-wide k-step, and at
+// most 5 key blocks per query block (always true for causal sequences; non-causal: up to ~36 tokens).
+bool stlt_mhsa_fused_takes(int64_t L, int64_t H, int64_t d, int causal) {
+  if (L < 1 || L > 64 || H <= 0 || H > 65535 || d != H * 64 || d % FK != 0) return false;
+  const int rows = (int)(FM / L * L);
+  return mhsa16_key_blocks((int)L, rows, causal != 0) <= 5;
+}
+
+// Is the fused launch the faster form for S sequences?  The tile holds whole sequences, so a shape whose sequences fill less than
+// 7/8 of the 128 rows loses to the product + attention-core pair (33 tokens: 99 rows -> 1227 against 1031 us at 1024 clips), and so
+// does a launch whose items leave much of the last round of workgroups idle (17 frames x 64 clips: 120 items for 256 CUs, 74.7
+// against 65.8 us; 64 frames x 64 clips: 1.5 rounds, 158.7 against 149.9) — profiles/round4_mhsa_fused_ab.txt.
+bool stlt_mhsa_fused_pays(int64_t S, int64_t L, int64_t H, int64_t d, int causal) {
+  if (!stlt_mhsa_fused_takes(L, H, d, causal)) return false;
+  static const int force = [] { const char* e = getenv("STLT_FUSED_MHSA_FORCE"); return e ? atoi(e) : 0; }();  // A/B runs: 1 = whenever the shape is taken
+  if (force) return true;
+  const int64_t seq_per_item = FM / L;
+  if (seq_per_item * L < 112) return false;
+  const int64_t n_items = (S + seq_per_item - 1) / seq_per_item * H;
+  const int64_t cus = stlt_device_cus();
+  const int64_t rounds = (n_items + cus - 1) / cus;
+  const double fill = (double)n_items / (double)(rounds * cus);
+  return rounds == 1 ? fill >= 0.6 : fill >= 0.8;
+}
+
+// ctx (S*L, d) = multi-head self-attention of S sequences of L tokens with the in-projection fused in.
+// x (S*L, d), w_in (3d, d) rows [q; k; v], b_in (3d), kpm (S*L) bytes (1 = padded key); causal: key position <= query position.
+// qkv_out != nullptr: the packed projections (S*L, 3d) are also written (training tape); dr: dropout of the probabilities.
+int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, const uint8_t* kpm, int64_t S, int64_t L, int64_t H,
+                      int64_t d, float* ctx, hipStream_t s, int causal, float* qkv_out, StltDrop dr, uint32_t site) {
   if (!x || !w_in || !b_in || !kpm || !ctx) return stlt_set_error(STLT_EINVAL, "mhsa_fused: null pointer");
-  if (T != 32 || H <= 0 || d != H * 64 || d % FK != 0)
-    return stlt_set_error(STLT_EINVAL, "mhsa_fused: clips of exactly 32 frames and 64-channel heads (T=%lld, d=%lld, H=%lld)", (long long)T, (long long)d, (long long)H);
-  if (n_clips <= 0) return 0;
-  if (n_clips * 32 * d > 0x7fffffffLL * 4) return stlt_set_error(STLT_EINVAL, "mhsa_fused: batch too large");
-  static StltPerDeviceOnce attr_done;
-  if (!attr_done.flag()) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)mhsa_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM * (int)sizeof(float)); e != hipSuccess)
-      return stlt_set_error((int)e, "mhsa_fused: %s", hipGetErrorString(e));
-    attr_done.flag() = true;
-  }
-  const int64_t n_items = (n_clips + 3) / 4 * H;
-  int64_t G = stlt_device_cus();
-  if (G > n_items) G = n_items;
-  StltProfScope ps(STLT_K_MHSA_FUSED, s);
-  hipLaunchKernelGGL(mhsa_fused_kernel, dim3((unsigned)G), dim3(F_THREADS), F_SMEM * sizeof(float), s, x, w_in, b_in, kpm, ctx, (int)n_clips, (int)H,
-                     (int)d, 0.125f);
-  return stlt_check_launch("mhsa_fused_kernel");
+  if (!stlt_mhsa_fused_takes(L, H, d, causal))
+    return stlt_set_error(STLT_EINVAL, "mhsa_fused: sequences of 1..64 tokens and 64-channel heads (L=%lld, d=%lld, H=%lld, causal=%d)", (long long)L,
+                          (long long)d, (long long)H, causal);
+  if (S <= 0) return 0;
+  if (S * L * 3 * d > 0x7fffffffLL * 4 || S * L > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "mhsa_fused: batch too large");
+  StltProfScope ps(causal ? STLT_K_MHSA_FUSED : STLT_K_MHSA_FUSED_SPATIAL, s);
+  Mhsa16Args a;
+  a.X = x; a.Win = w_in; a.bin = b_in; a.kpm = kpm; a.ctx = ctx; a.qkv = qkv_out;
+  a.n_tokens = (int)(S * L); a.L = (int)L; a.H = (int)H; a.d = (int)d;
+  const int seq_per_item = (int)(FM / L);
+  a.rows_per_item = seq_per_item * (int)L;
+  a.n_groups = (int)((S + seq_per_item - 1) / seq_per_item);
+  a.scale = 0.125f;  // 1 / sqrt(64)
+  a.dr = dr; a.site = site;
+  const int nkb = mhsa16_key_blocks(a.L, a.rows_per_item, causal != 0);
+  const bool train = qkv_out != nullptr || dr.thr != 0;
+  if (train && !qkv_out) return stlt_set_error(STLT_EINVAL, "mhsa_fused: dropout needs the qkv output (training forward)");
+  if (causal) return train ? launch_mhsa16_nkb<true, true>(nkb, a, s) : launch_mhsa16_nkb<true, false>(nkb, a, s);
+  return train ? launch_mhsa16_nkb<false, true>(nkb, a, s) : launch_mhsa16_nkb<false, false>(nkb, a, s);
 }

@@ -201,12 +201,23 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
   return weight_grad_all(items, 4, sc, s);
 }
 
+// in-projection + attention core of a training forward: the packed projections stay in the tape (t.qkv) for the reverse sweep.
+// Padded layout, sequences of <= 64 tokens: one fused launch (mhsa.hip, TRAIN build: dropout of the probabilities from the
+// counter mask, q / k / v written from the accumulators); ragged layout and other shapes: product + attention core.
+static int qkv_attention_train(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
+                               const uint8_t* kpm, int causal, int kid, StltDrop dr, uint32_t site0, hipStream_t s, const int* seg_start,
+                               const int* seg_end) {
+  if (!seg_start && stlt_fused_mhsa_on(causal) && stlt_mhsa_fused_pays(S, L, H, d, causal) && !stlt_split_bf16_takes(M, 3 * d, d, d, d))
+    return launch_mhsa_fused(t.x, lp.in_proj_w, lp.in_proj_b, kpm, S, L, H, d, t.ctx, s, causal, t.qkv, dr, site0);
+  TRY(launch_linear(t.x, d, lp.in_proj_w, lp.in_proj_b, t.qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
+  if (seg_start) return launch_attn_ragged(t.qkv, seg_start, seg_end, causal, M, H, d / H, t.ctx, kid, s, dr, site0);
+  return launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s, dr, site0);
+}
+
 static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
                          const uint8_t* kpm, int causal, int kid, float* y, StltDrop dr, uint32_t site0, hipStream_t s,
                          const int* seg_start = nullptr, const int* seg_end = nullptr) {
-  TRY(launch_linear(t.x, d, lp.in_proj_w, lp.in_proj_b, t.qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
-  if (seg_start) TRY(launch_attn_ragged(t.qkv, seg_start, seg_end, causal, M, H, d / H, t.ctx, kid, s, dr, site0));
-  else TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s, dr, site0));
+  TRY(qkv_attention_train(lp, d, H, t, M, S, L, kpm, causal, kid, dr, site0, s, seg_start, seg_end));
   TRY(launch_linear(t.ctx, d, lp.out_proj_w, lp.out_proj_b, t.a, d, M, d, d, STLT_ACT_NONE, s));
   TRY(launch_add_layernorm(t.a, d, t.x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, t.x1, d, s, dr, site0 + 1));
   TRY(launch_linear(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, 4 * d, M, 4 * d, d, STLT_ACT_NONE, s));
@@ -225,9 +236,7 @@ static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, cons
 static int layer_forward_tail(const stlt_layer_params& lp, int64_t d, int64_t H, const LayerTape& t, int64_t M, int64_t S, int64_t L,
                               const uint8_t* kpm, int causal, int kid, const int* seg_start, const int* seg_end, const int* rows,
                               int64_t n, float* y, StltDrop dr, uint32_t site0, hipStream_t s) {
-  TRY(launch_linear(t.x, d, lp.in_proj_w, lp.in_proj_b, t.qkv, 3 * d, M, 3 * d, d, STLT_ACT_NONE, s));
-  if (seg_start) TRY(launch_attn_ragged(t.qkv, seg_start, seg_end, causal, M, H, d / H, t.ctx, kid, s, dr, site0));
-  else TRY(launch_attn(t.qkv, kpm, causal, S, L, H, d / H, t.ctx, kid, s, dr, site0));
+  TRY(qkv_attention_train(lp, d, H, t, M, S, L, kpm, causal, kid, dr, site0, s, seg_start, seg_end));
   float* g_ctx = t.a + n * d;
   float* g_x = t.x1 + n * d;
   TRY(launch_gather_rows(t.ctx, d, rows, n, d, g_ctx, s));
@@ -300,6 +309,8 @@ static int check_train(const stlt_params* p, const stlt_inputs* in, bool need_he
   if (!in->categories || !in->boxes || !in->kpm_boxes || !in->frame_types || !in->kpm_frames || !in->lengths)
     return stlt_set_error(STLT_EINVAL, "null input tensor");
   if (need_head && (!p->fc1_w || !p->fc2_w || p->n_classes <= 0)) return stlt_set_error(STLT_EINVAL, "prediction head missing");
+  if (p->n_categories > STLT_TRAIN_MAX_CATEGORIES)  // the embedding-gradient kernel keeps per-category sums in LDS (backward.hip: embed_bwd_kernel)
+    return stlt_set_error(STLT_EINVAL, "training supports at most %d object categories (got %lld)", STLT_TRAIN_MAX_CATEGORIES, (long long)p->n_categories);
   return 0;
 }
 
@@ -313,7 +324,7 @@ size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t
 }
 
 size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories) {
-  if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || n_categories <= 0) return 0;
+  if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || n_categories <= 0 || n_categories > STLT_TRAIN_MAX_CATEGORIES) return 0;
   return scratch_layout(nullptr, B, T, N, d, n_categories).bytes;
 }
 

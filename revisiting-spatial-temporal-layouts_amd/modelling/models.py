@@ -535,12 +535,13 @@ class _BackboneTrainFn(torch.autograd.Function):
         if "scores" not in batch:
             skip |= {id(q) for q in le.category_box_embeddings.score_embeddings.parameters()}
         want = [prm for prm in ctx.params if prm.requires_grad and id(prm) not in skip]
-        # parameters whose .grad is bound to a trainer's flat buffer are accumulated into in place (no temporary, autograd gets
-        # None for them); the others get views of a fresh zero buffer that autograd accumulates
+        # inside a Trainer step, parameters whose .grad is bound to the trainer's flat buffer are accumulated into in place (no
+        # temporary, autograd gets None for them); the others — and every parameter outside a Trainer step, e.g. under
+        # torch.autograd.grad() — get views of a fresh zero buffer that autograd accumulates / returns
         direct = {}
         for q in want:
             bound = getattr(q, "_stlt_bound", None)
-            if bound is not None and q.grad is not None and bound.owns(q):
+            if bound is not None and bound.accumulating and q.grad is not None and bound.owns(q):
                 bound.touch(q)
                 direct[id(q)] = q.grad
         layout, off = [], 0

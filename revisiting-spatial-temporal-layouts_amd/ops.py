@@ -164,15 +164,22 @@ def attn_core_bwd(qkv: torch.Tensor, dctx: torch.Tensor, kpm: torch.Tensor, caus
     return (dqkv, gb) if want_bias_grad else dqkv
 
 
-def mhsa_fused(x: torch.Tensor, in_proj_w: torch.Tensor, in_proj_b: torch.Tensor, kpm: torch.Tensor, num_heads: int):
-    """Fused in-projection + causal attention core (temporal tower): x (S,32,d), kpm (S,32) -> ctx (S,32,d)."""
+def mhsa_fused(x: torch.Tensor, in_proj_w: torch.Tensor, in_proj_b: torch.Tensor, kpm: torch.Tensor, num_heads: int, causal: bool = True,
+               want_qkv: bool = False, dropout_p: float = 0.0, seed: int = 0, site: int = 0):
+    """Fused in-projection + attention core: x (S,L,d), kpm (S,L) -> ctx (S,L,d); L <= 64.  want_qkv (or dropout_p > 0): the training
+    form, returns (ctx, qkv) with the packed projections (S,L,3d) the reverse sweep needs."""
     lib = L.load()
     _chk(x, torch.float32, "x"); _chk(in_proj_w, torch.float32, "in_proj_w"); _chk(in_proj_b, torch.float32, "in_proj_b")
     kpm = _mask_u8(kpm, "kpm")
     S, Lq, d = x.shape
     ctx = torch.empty_like(x)
-    L.check(lib.stlt_mhsa_fused_fwd(_p(x), _p(in_proj_w), _p(in_proj_b), _p(kpm), S, Lq, num_heads, d, _p(ctx), _stream()), "stlt_mhsa_fused_fwd")
-    return ctx
+    if not (want_qkv or dropout_p > 0.0) and causal:
+        L.check(lib.stlt_mhsa_fused_fwd(_p(x), _p(in_proj_w), _p(in_proj_b), _p(kpm), S, Lq, num_heads, d, _p(ctx), _stream()), "stlt_mhsa_fused_fwd")
+        return ctx
+    qkv = torch.empty(S, Lq, 3 * d, device=x.device, dtype=torch.float32) if (want_qkv or dropout_p > 0.0) else None
+    L.check(lib.stlt_mhsa_fused_fwd_ex(_p(x), _p(in_proj_w), _p(in_proj_b), _p(kpm), int(bool(causal)), S, Lq, num_heads, d, float(dropout_p), int(seed),
+                                       int(site), _p(ctx), _p(qkv), _stream()), "stlt_mhsa_fused_fwd_ex")
+    return (ctx, qkv) if qkv is not None else ctx
 
 
 def attn_core(qkv: torch.Tensor, kpm: torch.Tensor, causal: bool, num_heads: int):
@@ -466,11 +473,14 @@ _SK_SCRATCH = {}
 
 
 def _sk_scratch(device) -> torch.Tensor:
-    """Per-device stream-K scratch lent to the block-level forward calls (kept for the life of the process: kernels enqueued
-    on the device's streams may still be reading it)."""
-    buf = _SK_SCRATCH.get(device)
+    """Stream-K scratch lent to the block-level forward calls: one buffer per (device, stream) — the grouped stream-K kernels
+    write their partial tiles into it and the split-bf16 path its weight planes, so two streams of one device running block
+    forwards at the same time must not share it (kept for the life of the process: kernels enqueued on the stream may still be
+    reading it)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SK_SCRATCH.get(key)
     if buf is None:
-        _SK_SCRATCH[device] = buf = torch.empty(int(L.load().stlt_gemm_scratch_bytes()), dtype=torch.uint8, device=device)
+        _SK_SCRATCH[key] = buf = torch.empty(int(L.load().stlt_gemm_scratch_bytes()), dtype=torch.uint8, device=device)
     return buf
 
 
@@ -486,15 +496,16 @@ def _block_dropout(p: float):
 
 
 def grad_targets(ws, needs):
-    """Where a block's backward accumulates its parameter gradients.  A parameter whose .grad is a view of a trainer's flat
-    gradient buffer (train.BoundFlatGrads) is accumulated into IN PLACE by the native call (and autograd is handed None for it):
-    no zero-filled temporary, no AccumulateGrad add.  Any other parameter gets a fresh zero tensor that autograd accumulates."""
+    """Where a block's backward accumulates its parameter gradients.  Inside a Trainer step (BoundFlatGrads.accumulating) a
+    parameter whose .grad is a view of the trainer's flat gradient buffer is accumulated into IN PLACE by the native call (and
+    autograd is handed None for it): no zero-filled temporary, no AccumulateGrad add.  Anywhere else — torch.autograd.grad() or a
+    hand-written loop on a Trainer-bound model — every parameter gets a fresh zero tensor that autograd returns / accumulates."""
     targets, returned = [], []
     for w, need in zip(ws, needs):
         bound = getattr(w, "_stlt_bound", None)
         if not need:
             targets.append(None); returned.append(None)
-        elif bound is not None and w.grad is not None and bound.owns(w):
+        elif bound is not None and bound.accumulating and w.grad is not None and bound.owns(w):
             bound.touch(w)
             targets.append(w.grad); returned.append(None)
         else:

@@ -190,6 +190,9 @@ CONFIGS = {
                  num_classes=174, dataset="something"),
     "cfg2p": dict(T=33, N=8, hidden_size=768, num_attention_heads=12, num_spatial_layers=4, num_temporal_layers=8,
                   num_classes=174, dataset="something"),
+    # the reference's defaults: layout_num_frames 16 (+ 1 extract frame), 4 object slots (+ CLS) — utils/parser.py:62-66, datasets.py:97-113
+    "refdef": dict(T=17, N=5, hidden_size=768, num_attention_heads=12, num_spatial_layers=4, num_temporal_layers=8,
+                   num_classes=174, dataset="something"),
     "cfg4": dict(T=64, N=36, hidden_size=768, num_attention_heads=12, num_spatial_layers=4, num_temporal_layers=8,
                  num_classes=157, dataset="action_genome"),
 }

@@ -109,6 +109,10 @@ class FusedAdamW(torch.optim.Optimizer):
         from . import _lib as L
         import ctypes as C
         import numpy as np
+        # a re-bind in the middle of training (another set of parameters received gradients, parameters moved, a second
+        # Trainer) must not lose the step count: the host-side counters go into the per-parameter `step` tensors first, from
+        # which step_flat() re-seeds them below (after load_state_dict() the counters are empty and the loaded tensors stand)
+        self._sync_step_tensors()
         group_of = {id(p): g for g in self.param_groups for p in g["params"]}
         total = max((off + (n + 3) // 4 * 4 for _, off, n in layout), default=0)
         self._m = torch.zeros(total, device=device, dtype=torch.float32)
@@ -208,6 +212,7 @@ class BoundFlatGrads:
         self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self._touched = set()
         self._slot = {}
+        self.accumulating = False  # True only around the Trainer's own backward: the native backwards then add into the views in place
         for p, o, n in self.layout_all:
             p.grad = self.flat[o: o + n].view_as(p)
             p.register_post_accumulate_grad_hook(lambda q, s=self._touched: s.add(id(q)))
@@ -317,7 +322,11 @@ class Trainer:
             l, g = fused_criterion(v, batch["labels"], self.dataset_name, 1.0 / len(heads))
             loss = loss + l
             grads.append(g)
-        torch.autograd.backward(heads, grads)
+        self.bound.accumulating = True
+        try:
+            torch.autograd.backward(heads, grads)
+        finally:
+            self.bound.accumulating = False
         flat = self.bound.flat
         if self.world > 1:
             torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)

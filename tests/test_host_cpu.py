@@ -22,6 +22,11 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/stlt_hip.h but not exported"
     assert declared == set(pkg._lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    # ... and nothing else: the dynamic symbol table is the C-ABI, no internal C++ launcher or template instantiation leaks out
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+    assert exported == declared, f"exported but not declared: {sorted(exported - declared)}; declared but not exported: {sorted(declared - exported)}"
     assert lib.stlt_version() == 100
     # workspace sizing is pure host arithmetic: callable without a GPU
     a = pkg.ops.workspace_bytes(8, 32, 7, 768, 174)

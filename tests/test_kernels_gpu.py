@@ -339,8 +339,10 @@ def test_attention_autograd(pkg, Lq, Lk, causal, packed):
 
 
 @pytest.mark.parametrize("with_res", [True, False])
-def test_add_layernorm_and_gelu_autograd(pkg, with_res):
-    M, d = 77, 768
+@pytest.mark.parametrize("d", [768, 256, 1024, 1028, 1536, 2048])
+def test_add_layernorm_and_gelu_autograd(pkg, with_res, d):
+    """d > 1024 takes the wide-row LayerNorm backward (accumulator rows in LDS: the register form spilled there)."""
+    M = 77 if d == 768 else 1300
     x, r, w, b, g = _rand(M, d, seed=1), _rand(M, d, seed=2), 1 + _rand(d, seed=3, scale=0.1), _rand(d, seed=4, scale=0.1), _rand(M, d, seed=5)
     xd, rd, wd, bd = _leaf(x), _leaf(r), _leaf(w), _leaf(b)
     out = pkg.ops.AddLayerNormFn.apply(xd, rd if with_res else None, wd, bd, 1e-5)
@@ -503,19 +505,25 @@ def test_attn_core_short_sequences_many_items_and_masked_rows(pkg, S, L, causal)
     assert (got.double() - ref).abs().max().item() <= 2e-5
 
 
+def _mhsa_case(S, L, H, seed):
+    d = 64 * H
+    x = _rand(S, L, d, seed=seed, scale=1.5)
+    w = _rand(3 * d, d, seed=seed + 1, scale=2.0 / math.sqrt(d))
+    b = _rand(3 * d, seed=seed + 2, scale=0.5)
+    kpm = torch.rand(S, L, generator=torch.Generator().manual_seed(seed)) < 0.3
+    kpm[:, 0] = False
+    if S > 3:
+        kpm[2, :] = True  # a fully padded sequence
+    return x, w, b, kpm
+
+
 @pytest.mark.parametrize("S,H", [(1, 12), (4, 12), (5, 12), (64, 12), (257, 12), (1030, 12), (9, 4), (130, 2)])
 def test_mhsa_fused_matches_projection_plus_attention_core(pkg, S, H):
     """stlt_mhsa_fused_fwd: in-projection + causal attention of 32-frame clips in one kernel, against the
     fp64 oracle and against the two-launch path (stlt_linear_fwd + stlt_attn_core_fwd); ragged last clip group, a fully
-    padded clip (zeros out), padded frames; other shapes are refused."""
+    padded clip (zeros out), padded frames; sequences of more than 64 tokens are refused."""
     d, L = 64 * H, 32
-    x = _rand(S, L, d, seed=S, scale=1.5)
-    w = _rand(3 * d, d, seed=S + 1, scale=2.0 / math.sqrt(d))
-    b = _rand(3 * d, seed=S + 2, scale=0.5)
-    kpm = torch.rand(S, L, generator=torch.Generator().manual_seed(S)) < 0.3
-    kpm[:, 0] = False
-    if S > 3:
-        kpm[2, :] = True  # a fully padded clip
+    x, w, b, kpm = _mhsa_case(S, L, H, S)
     xd, wd, bd, kd = x.to(DEV), w.to(DEV), b.to(DEV), kpm.to(DEV)
     got = pkg.ops.mhsa_fused(xd, wd, bd, kd, H)
     again = pkg.ops.mhsa_fused(xd, wd, bd, kd, H)
@@ -529,7 +537,81 @@ def test_mhsa_fused_matches_projection_plus_attention_core(pkg, S, H):
     assert (got.cpu().double() - ref).abs().max().item() <= 3e-5
     assert (got - two).abs().max().item() <= 2e-5
     with pytest.raises(pkg._lib.StltHipError):
-        pkg.ops.mhsa_fused(xd[:, :16].contiguous(), wd, bd, kd[:, :16].contiguous(), H)
+        long = torch.zeros(2, 65, d, device=DEV)
+        pkg.ops.mhsa_fused(long, wd, bd, torch.zeros(2, 65, dtype=torch.bool, device=DEV), H)
+
+
+@pytest.mark.parametrize("L", [1, 2, 5, 7, 8, 13, 16, 17, 18, 24, 31, 32, 33, 34, 36, 40, 47, 48, 49, 50, 57, 63, 64])
+@pytest.mark.parametrize("causal", [True, False])
+def test_mhsa_fused_every_sequence_length(pkg, L, causal):
+    """Round 4: the fused kernel on the reference's real layouts (T = 17 / 33, datasets.py:97-113; N = 5 / 8 objects), cfg4's 64 frames /
+    36 objects and everything between: sequences start anywhere inside a 128-row item, the last item is ragged, a sequence is fully
+    padded.  Against the fp64 oracle and the two-launch path.  Non-causal sequences above ~36 tokens need more than 5 key blocks per
+    query block and are refused (the whole-path code then takes the two launches)."""
+    H = 3
+    d = 64 * H
+    S = max(3, min(41, 700 // L)) + 2
+    x, w, b, kpm = _mhsa_case(S, L, H, 1000 + L)
+    xd, wd, bd, kd = x.to(DEV), w.to(DEV), b.to(DEV), kpm.to(DEV)
+    rows = 128 // L * L
+    worst = 1
+    for blk in range(0, rows, 16):
+        first = (blk // L) * L // 16
+        last = blk // 16 if causal else ((min(blk + 15, rows - 1) // L + 1) * L - 1) // 16
+        worst = max(worst, last - first + 1)
+    if worst > 5:
+        with pytest.raises(pkg._lib.StltHipError):
+            pkg.ops.mhsa_fused(xd, wd, bd, kd, H, causal=causal)
+        return
+    got = pkg.ops.mhsa_fused(xd, wd, bd, kd, H, causal=causal)
+    again = pkg.ops.mhsa_fused(xd, wd, bd, kd, H, causal=causal)
+    qkv = pkg.ops.linear(xd.view(S * L, d), wd, bd).view(S, L, 3 * d)
+    two = pkg.ops.attn_core(qkv, kd, causal, H)
+    ref = _attn_ref((x.double().view(S * L, d) @ w.double().t() + b.double()).view(S, L, 3 * d), kpm, causal, H)
+    assert got[2].abs().max().item() == 0.0
+    ref[2] = 0.0
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    assert (got.cpu().double() - ref).abs().max().item() <= 3e-5
+    assert (got - two).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("L,causal", [(17, True), (32, True), (33, True), (64, True), (50, True), (7, False), (5, False), (8, False), (36, False)])
+@pytest.mark.parametrize("p", [0.0, 0.1, 0.5])
+def test_mhsa_fused_training_form_vs_masked_oracle(pkg, L, causal, p):
+    """The TRAIN build of the fused kernel (what stlt_train_forward launches): packed q / k / v written for the tape equal the
+    in-projection product, and the context equals the oracle's attention with the SAME dropout mask on the probabilities (element
+    index ((query token * H + head) << 8) | key position: the mask stlt_attn_core_bwd regenerates); also bit-identical to the two-launch
+    training path's tape, and the backward kernel accepts the tape (gradient vs fp64 autograd)."""
+    H = 2
+    d = 64 * H
+    S = max(3, 300 // L) + 2
+    x, w, b, kpm = _mhsa_case(S, L, H, 2000 + L)
+    xd, wd, bd, kd = x.to(DEV), w.to(DEV), b.to(DEV), kpm.to(DEV)
+    seed, site = 777 + L, 8 * 5
+    ctx, qkv = pkg.ops.mhsa_fused(xd, wd, bd, kd, H, causal=causal, want_qkv=True, dropout_p=p, seed=seed, site=site)
+    ctx2, qkv2 = pkg.ops.mhsa_fused(xd, wd, bd, kd, H, causal=causal, want_qkv=True, dropout_p=p, seed=seed, site=site)
+    assert torch.equal(ctx, ctx2) and torch.equal(qkv, qkv2)
+    qkv_ref = (x.double().view(S * L, d) @ w.double().t() + b.double()).view(S, L, 3 * d)
+    assert (qkv.cpu().double() - qkv_ref).abs().max().item() <= 3e-5
+    xq = qkv_ref.clone().requires_grad_(True)
+    sp = lambda t: t.reshape(S, L, H, 64).transpose(1, 2)
+    sc = sp(xq[..., :d]) @ sp(xq[..., d:2 * d]).transpose(-1, -2) / 8.0
+    masked = kpm[:, None, None, :].expand(S, H, L, L).clone()
+    if causal:
+        masked |= torch.ones(L, L, dtype=torch.bool).triu(1)
+    pr = torch.nan_to_num(torch.softmax(sc.masked_fill(masked, float("-inf")), -1), nan=0.0)
+    if p > 0:
+        pr = pr * _drop_mask(O, p, seed, site, S, H, L)
+    ref = (pr @ sp(xq[..., 2 * d:])).transpose(1, 2).reshape(S, L, d)
+    assert torch.isfinite(ctx).all()
+    assert (ctx.cpu().double() - ref.detach()).abs().max().item() <= 5e-5
+    assert ctx[2].abs().max().item() == 0.0
+    # the reverse sweep's attention backward on this tape
+    g = _rand(S, L, d, seed=L + 7)
+    dqkv = pkg.ops.attn_core_bwd(qkv, g.to(DEV), kd, causal, H, p, seed, site)
+    ref.backward(g.double())
+    scale = max(xq.grad.abs().max().item(), 1e-6)
+    assert (dqkv.cpu().double() - xq.grad).abs().max().item() / scale <= 5e-5
 
 
 @pytest.mark.parametrize("L", [17, 24, 31, 32, 33, 36, 40, 47, 48, 49, 57, 63, 64])

@@ -394,6 +394,56 @@ def test_fused_adamw_resumes_from_a_loaded_state_dict(pkg):
     del snap_ref
 
 
+def test_fused_adamw_keeps_its_step_count_across_a_rebind(pkg):
+    """A re-bind in the middle of training (the layout key changes: other offsets in the flat buffer, a parameter that moved,
+    a second Trainer) must carry the AdamW step count on — exp_avg / exp_avg_sq carry over, so a count that restarts at 1 would
+    scale the bias correction wrongly with no error raised (round-3 advisor finding).  Four steps with the flat layout changed
+    after the second and the third one, against torch.optim.AdamW; the kernel's step argument is checked as well."""
+    T = importlib.import_module("revisiting-spatial-temporal-layouts_amd.train")
+    L = importlib.import_module("revisiting-spatial-temporal-layouts_amd._lib")
+    g0 = torch.Generator().manual_seed(11)
+    shapes = [(48, 20), (20,), (333,)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, generator=g0).to(DEV)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    groups = lambda ps: [{"params": [ps[1]], "weight_decay": 0.0}, {"params": [ps[0], ps[2]], "weight_decay": 1e-2}]
+    ref, ours = torch.optim.AdamW(groups(ref_p), lr=1e-2), T.FusedAdamW(groups(our_p), lr=1e-2)
+
+    def make_layout(order, gap):
+        layout, off = {}, 0
+        for i in order:
+            layout[i] = (our_p[i], off, our_p[i].numel())
+            off += (our_p[i].numel() + 3) // 4 * 4 + gap
+        return [layout[i] for i in range(len(our_p))], off
+
+    seen_steps = []
+    lib = L.load()
+    real = lib.stlt_adamw_step
+
+    def spy(*args):
+        seen_steps.append(int(args[10]))
+        return real(*args)
+
+    lib.stlt_adamw_step = spy
+    try:
+        for step, (order, gap) in enumerate([((0, 1, 2), 0), ((0, 1, 2), 0), ((2, 0, 1), 8), ((1, 2, 0), 4)]):
+            layout, total = make_layout(order, gap)
+            grads = [torch.randn(*s, generator=g0).to(DEV) for s in shapes]
+            for p, g in zip(ref_p, grads):
+                p.grad = g.clone()
+            ref.step()
+            flat = torch.zeros(total, device=DEV)
+            for (p, o, n), g in zip(layout, grads):
+                flat[o:o + n] = g.reshape(-1)
+            ours.step_flat(flat, layout, 0.0)
+            for a, b in zip(our_p, ref_p):
+                assert (a - b).abs().max().item() <= 2e-6, step
+    finally:
+        lib.stlt_adamw_step = real
+    assert seen_steps == [1, 1, 2, 2, 3, 3, 4, 4]  # two parameter groups per step
+    for k, st in ours.state_dict()["state"].items():
+        assert float(st["step"]) == 4.0
+
+
 def test_alternating_batch_shapes_reuse_the_training_buffers_safely(pkg):
     """(B,T,N) = (4,6,4) and (4,5,4) round to the same tape / scratch byte counts with different row layouts: a step with
     the shorter clips after one with the longer ones must not pick up stale gradient rows (dW contracts over the row count

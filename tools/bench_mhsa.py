@@ -2,7 +2,8 @@
 """Row N1 A/B (GPU box only): in-projection + causal attention of a temporal layer as two launches (stlt_linear_fwd +
 stlt_attn_core_fwd: packed QKV through HBM) against the fused kernel (stlt_mhsa_fused_fwd), per clip count.
 
-    python tools/bench_mhsa.py [--clips 64 256 1024] [--iters 50]
+    python tools/bench_mhsa.py [--clips 64 256 1024] [--frames 32 17 33 64] [--iters 50] [--train]
+(STLT_FUSED_MHSA_V1=1 in the environment: the round-3 kernel for 32-frame clips, for A/B runs)
 """
 import argparse, importlib, json, os, sys
 import torch
@@ -28,30 +29,37 @@ def main():
     ap.add_argument("--clips", type=int, nargs="+", default=[64, 256, 1024])
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", choices=("both", "two", "fused"), default="both")
+    ap.add_argument("--frames", type=int, nargs="+", default=[32])
+    ap.add_argument("--noncausal", action="store_true", help="the spatial tower's form (key padding only)")
+    ap.add_argument("--train", action="store_true", help="time the training form too (packed QKV written, dropout 0.1)")
     a = ap.parse_args()
-    dev, H, d, L = "cuda", 12, 768, 32
+    dev, H, d = "cuda", 12, 768
+    causal = not a.noncausal
     g = torch.Generator(device=dev).manual_seed(0)
     w = (torch.rand(3 * d, d, device=dev, generator=g) * 2 - 1) / d ** 0.5
     b = torch.rand(3 * d, device=dev, generator=g) - 0.5
-    for S in a.clips:
+    for L in a.frames:
+      for S in a.clips:
         x = torch.rand(S, L, d, device=dev, generator=g) * 2 - 1
         kpm = torch.rand(S, L, device=dev, generator=g) < 0.25
         kpm[:, 0] = False
         qkv = torch.empty(S * L, 3 * d, device=dev)
-        row = {"clips": S}
+        row = {"frames": L, "clips": S, "causal": causal}
         with pkg.ops.gemm_scratch(dev):
             if a.only in ("both", "two"):
                 def two():
                     pkg.ops.linear(x.view(S * L, d), w, b, out=qkv)
-                    return pkg.ops.attn_core(qkv.view(S, L, 3 * d), kpm, True, H)
+                    return pkg.ops.attn_core(qkv.view(S, L, 3 * d), kpm, causal, H)
                 row["two_launch_us"] = round(timed(two, a.iters), 1)
                 row["qkv_only_us"] = round(timed(lambda: pkg.ops.linear(x.view(S * L, d), w, b, out=qkv), a.iters), 1)
             if a.only in ("both", "fused"):
-                row["fused_us"] = round(timed(lambda: pkg.ops.mhsa_fused(x, w, b, kpm, H), a.iters), 1)
+                row["fused_us"] = round(timed(lambda: pkg.ops.mhsa_fused(x, w, b, kpm, H, causal=causal), a.iters), 1)
+                if a.train:
+                    row["fused_train_us"] = round(timed(lambda: pkg.ops.mhsa_fused(x, w, b, kpm, H, causal=causal, want_qkv=True, dropout_p=0.1, seed=1, site=8), a.iters), 1)
             if a.only == "both":
-                row["max_abs_diff"] = float((two() - pkg.ops.mhsa_fused(x, w, b, kpm, H)).abs().max())
-        fl = 2.0 * S * L * 3 * d * d
-        for k in ("two_launch_us", "qkv_only_us", "fused_us"):
+                row["max_abs_diff"] = float((two() - pkg.ops.mhsa_fused(x, w, b, kpm, H, causal=causal)).abs().max())
+        fl = 2.0 * S * L * 3 * d * d + 4.0 * S * L * L * 64 * H
+        for k in ("two_launch_us", "qkv_only_us", "fused_us", "fused_train_us"):
             if k in row:
                 row[k.replace("_us", "_tflops")] = round(fl / row[k] / 1e6, 1)
         print(json.dumps(row), flush=True)
