@@ -133,6 +133,15 @@ class StltGemmScratch {
   size_t prev_bytes_;
 };
 void stlt_gemm_set_scratch_impl(void* p, size_t bytes);
+class StltGemmWgCap {  // while alive on the calling thread: GEMM launches use at most n workgroups (0 = no cap)
+ public:
+  explicit StltGemmWgCap(int n);
+  ~StltGemmWgCap();
+  StltGemmWgCap(const StltGemmWgCap&) = delete;
+  StltGemmWgCap& operator=(const StltGemmWgCap&) = delete;
+ private:
+  int prev_;
+};
 // Grouped launch: several independent products of the same operand layout walked by ONE persistent stream-K launch (one
 // fix-up instead of one per product; a workgroup's range may run from one product's tiles into the next one's).  Used for
 // the weight gradients of an encoder layer: C_p (M_p, N_p) += A_pᵀ·B_p with A_p (Kc_p, M_p), B_p (Kc_p, N_p) row-major.

@@ -1008,7 +1008,13 @@ __global__ __launch_bounds__(256) void reduce_tall3_kernel(const float* __restri
 
 }  // namespace
 
-static int n_cu() { return stlt_device_cus(); }
+// workgroups a launch may use: the device's CUs, or fewer while a StltGemmWgCap is alive on the calling thread (two persistent
+// launches on two streams can only share the chip if their grids add up to the CU count: one 144-KB workgroup fits a CU)
+thread_local int t_gemm_wg_cap = 0;
+static int n_cu() {
+  const int n = stlt_device_cus();
+  return (t_gemm_wg_cap > 0 && t_gemm_wg_cap < n) ? t_gemm_wg_cap : n;
+}
 
 // Relative XCD speeds for the hybrid launch's tail ranges: STLT_GEMM_XCD_W="w0,...,w7" (experiments) — empty: equal.
 static const double* xcd_weights() {
@@ -1240,6 +1246,8 @@ StltGemmScratch::~StltGemmScratch() {
   t_gemm_scratch = prev_;
   t_gemm_scratch_bytes = prev_bytes_;
 }
+StltGemmWgCap::StltGemmWgCap(int n) : prev_(t_gemm_wg_cap) { t_gemm_wg_cap = n > 0 ? (n + 7) / 8 * 8 : 0; }  // multiples of 8: the XCD-contiguous tile order
+StltGemmWgCap::~StltGemmWgCap() { t_gemm_wg_cap = prev_; }
 void stlt_gemm_set_scratch_impl(void* p, size_t bytes) {
   t_gemm_scratch = static_cast<float*>(p);
   t_gemm_scratch_bytes = p ? bytes : 0;

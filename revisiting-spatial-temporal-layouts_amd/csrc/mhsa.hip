@@ -49,7 +49,7 @@ constexpr int G_SMEM = F_NSTAGE * F_STAGE + G_VT + 2 * FN + FM;           // + b
 struct Mhsa16Args {
   const float* X; const float* Win; const float* bin; const uint8_t* kpm;
   float* ctx; float* qkv;   // qkv: TRAIN only (packed rows [q;k;v], 3d floats per token)
-  int n_tokens, L, rows_per_item, n_groups, H, d;
+  int n_tokens, L, rows_per_item, n_groups, H, d, head_sets;
   float scale;
   StltDrop dr; uint32_t site;
 };
@@ -63,20 +63,41 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
   const int d = a.d, H = a.H;
   const int nk = d / FK;
   const int M = a.n_tokens;
-  const int n_items = a.n_groups * H;  // head fastest: the heads of a row group sit on neighbouring workgroups of one XCD
+  const int n_items = a.n_groups * H;
   const int G = gridDim.x;
-  int v = blockIdx.x;
-  if ((G & 7) == 0) v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous virtual id (round-robin dispatch)
-  const int my_items = (n_items - v + G - 1) / G;
+  // Item order.  head_sets == 1: items head-fastest over XCD-contiguous virtual workgroup ids — an XCD's 32 workgroups then hold
+  // ~3 row groups x all H heads at a time: every X tile is fetched about once, but the H weight slices (3 d^2 floats = 7 MB at d = 768)
+  // do not fit the 4-MB L2 beside the X stream and are re-fetched every round (measured 4.35x the algorithmic bytes, round 3).
+  // head_sets == 4 (H % 4 == 0, full grid): XCD x works on head set x & 3 (H / 4 heads: 1.8 MB of weights, L2-resident for the
+  // whole launch) for one half of the row groups (x >> 2); an X tile is then fetched once per head set: ~4x X, ~1x W.
+  const int sets = a.head_sets;
+  int v = blockIdx.x, Gv = G, hps = H, head0 = 0, grp0 = 0, my_groups = a.n_groups;
+  if (sets > 1) {
+    const int x = blockIdx.x & 7;
+    hps = H / sets;
+    head0 = (x % sets) * hps;
+    const int halves = 8 / sets, half = x / sets;         // XCDs sharing a head set split the row groups
+    const int per = (a.n_groups + halves - 1) / halves;
+    grp0 = half * per;
+    my_groups = a.n_groups - grp0 < per ? a.n_groups - grp0 : per;
+    if (my_groups < 0) my_groups = 0;
+    v = blockIdx.x >> 3;
+    Gv = G >> 3;
+  } else if ((G & 7) == 0) {
+    v = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous virtual id (round-robin dispatch)
+  }
+  const int my_n = sets > 1 ? my_groups * hps : n_items;
+  const int my_items = (my_n - v + Gv - 1) / Gv;
   if (my_items <= 0) return;
   const int total_steps = my_items * nk;
   float* Vt = smem + F_NSTAGE * F_STAGE;
   float* bias_lds = Vt + G_VT;
   int* kmeta = reinterpret_cast<int*>(bias_lds + 2 * FN);
   auto item_of = [&](int it, int& grp, int& head) {
-    const int item = v + it * G;
-    grp = item / H;
-    head = item - grp * H;
+    const int item = v + it * Gv;
+    const int gq = item / hps;
+    grp = grp0 + gq;
+    head = head0 + item - gq * hps;
   };
 
   if (wave >= F_WAVES) {
@@ -371,7 +392,16 @@ static int launch_mhsa16_as(const Mhsa16Args& a, hipStream_t s) {
   const int64_t n_items = (int64_t)a.n_groups * a.H;
   int64_t G = stlt_device_cus();
   if (G > n_items) G = n_items;
-  hipLaunchKernelGGL((mhsa16_kernel<NKB, CAUSAL, TRAIN>), dim3((unsigned)G), dim3(F_THREADS), G_SMEM * sizeof(float), s, a);
+  Mhsa16Args b = a;
+  // head sets per XCD group (see the kernel): only for launches of several rounds on a full grid of 8 x n workgroups.  Measured at
+  // 1024 clips of 32 frames (profiles/round4_mhsa_head_sets.txt): memory-side traffic per launch 907 MB (1 set) -> 668 MB (2 sets) ->
+  // 699 MB (4 sets) at equal speed (930 / 926 / 930 us); the spatial launches (7 objects) are 0.3 % / 5.7 % slower with 2 / 4 sets
+  // and keep one.  STLT_MHSA_HEAD_SETS=1|2|4 forces a value for both towers (A/B runs).
+  static const int env_sets = [] { const char* e = getenv("STLT_MHSA_HEAD_SETS"); return e ? atoi(e) : 0; }();
+  const int want_sets = env_sets ? env_sets : (CAUSAL ? 2 : 1);
+  b.head_sets = 1;
+  if ((want_sets == 2 || want_sets == 4) && (G & 7) == 0 && a.H % want_sets == 0 && n_items >= 4 * G && a.n_groups >= 8) b.head_sets = want_sets;
+  hipLaunchKernelGGL((mhsa16_kernel<NKB, CAUSAL, TRAIN>), dim3((unsigned)G), dim3(F_THREADS), G_SMEM * sizeof(float), s, b);
   return stlt_check_launch("mhsa16_kernel");
 }
 

@@ -17,6 +17,8 @@ namespace {
 inline int64_t up32(int64_t v) { return (v + 31) / 32 * 32; }
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+#define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
 struct LayerTape { float *x, *qkv, *ctx, *a, *x1, *u, *h, *f; };
 
 struct Tape {
@@ -58,9 +60,14 @@ static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, 
 
 // backward scratch: gradient buffers for the spatial phase (tok rows) and, separately, the temporal phase (BT
 // rows) so that each one's row padding stays zero; split-K slabs; reduction scratch.
+// The output gradients of a layer's four Linears (df, du, da, dqkv) are the operands of its weight-gradient products, which run on
+// a second stream beside the NEXT layer's dX chain: two sets per tower, used by alternate layers (GradBufs).
+struct GradBufs { float *B, *D, *E, *Q, *H; };
 struct Scratch {
   float *sA, *sB, *sC, *sD, *sE, *sQKV, *sH;  // spatial: (tokp,d) x5, (tokp,3d), (tokp,4d)
   float *tA, *tB, *tC, *tD, *tE, *tQKV, *tH;  // temporal
+  GradBufs s2, t2;                  // the second sets
+  float* sk2;                       // stream-K partial tiles of the second stream's launches
   float *hA, *hB;                   // head: (bp,d) x2
   float* slabs;
   float* red;
@@ -89,11 +96,70 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   if (eb > red) red = eb;
   s.red = take(red);
   s.sk = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
+  s.s2 = GradBufs{take(tokp * d), take(tokp * d), take(tokp * d), take(tokp * 3 * d), take(tokp * 4 * d)};
+  s.t2 = GradBufs{take(btp * d), take(btp * d), take(btp * d), take(btp * 3 * d), take(btp * 4 * d)};
+  s.sk2 = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
   s.bytes = off;
   return s;
 }
 
-#define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+// ---- second stream for the weight-gradient products --------------------------------------------------------------------------
+// A layer's four weight gradients are off the dX chain (nothing downstream reads them before the optimiser).  They are enqueued
+// on a per-device side stream (lower priority: the chain is the critical path) behind an event the chain records, with their own
+// stream-K scratch; the chain waits for them only when it is about to reuse their operand buffers (two layers later) and at the
+// end of the call.  The products fill the chip while the chain runs its row-wise kernels, fix-ups and under-filled launches.
+// STLT_TRAIN_DW_STREAM=0 keeps everything on the caller's stream (A/B runs); STLT_TRAIN_DW_WG / STLT_TRAIN_DX_WG cap the grids of
+// the side products / the chain's dX products (0 = uncapped) so that both persistent kernels can be resident at once.
+struct DwSide {
+  hipStream_t s = nullptr;
+  hipEvent_t chain[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+  bool pending[2] = {false, false};
+  bool on = false;
+  float* sk = nullptr;
+  int layer_no = 0;
+};
+struct DwSideDevice { hipStream_t s = nullptr; hipEvent_t ev[4] = {}; bool tried = false, ok = false; };
+static DwSideDevice g_dw_side[STLT_MAX_DEVICES];
+
+static bool dw_side_wanted() {
+  static const bool on = [] { const char* e = getenv("STLT_TRAIN_DW_STREAM"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
+static int dw_side_wg_cap() { static const int n = [] { const char* e = getenv("STLT_TRAIN_DW_WG"); return e ? atoi(e) : 0; }(); return n; }
+static int dx_chain_wg_cap() { static const int n = [] { const char* e = getenv("STLT_TRAIN_DX_WG"); return e ? atoi(e) : 0; }(); return n; }
+
+static DwSide dw_side_open(const Scratch& sc) {
+  DwSide sd;
+  if (!dw_side_wanted() || !sc.sk2) return sd;
+  DwSideDevice& dv = g_dw_side[stlt_current_device() & (STLT_MAX_DEVICES - 1)];
+  if (!dv.tried) {
+    dv.tried = true;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
+    bool ok = hipStreamCreateWithPriority(&dv.s, hipStreamNonBlocking, lo) == hipSuccess;
+    for (int i = 0; ok && i < 4; ++i) ok = hipEventCreateWithFlags(&dv.ev[i], hipEventDisableTiming) == hipSuccess;
+    dv.ok = ok;
+    (void)hipGetLastError();
+  }
+  if (!dv.ok) return sd;
+  sd.s = dv.s;
+  sd.chain[0] = dv.ev[0]; sd.chain[1] = dv.ev[1]; sd.done[0] = dv.ev[2]; sd.done[1] = dv.ev[3];
+  sd.sk = sc.sk2;
+  sd.on = true;
+  return sd;
+}
+// the chain is about to write the operand buffers of set `par`: the side products that still read them must have finished
+static int dw_side_wait(DwSide* sd, int par, hipStream_t s) {
+  if (sd && sd->on && sd->pending[par]) {
+    if (hipError_t e = hipStreamWaitEvent(s, sd->done[par], 0); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
+    sd->pending[par] = false;
+  }
+  return 0;
+}
+static int dw_side_join(DwSide* sd, hipStream_t s) {
+  TRY(dw_side_wait(sd, 0, s));
+  return dw_side_wait(sd, 1, s);
+}
 
 static int n_cu_cached() { return stlt_device_cus(); }
 
@@ -169,8 +235,17 @@ static int ffn_hidden_backward(const float* df, const float* lin2_w, const float
 static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
                           int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, float* bufA, float* bufB,
                           float* bufC, float* bufD, float* bufE, float* bufQ, float* bufH, const Scratch& sc, StltDrop dr, uint32_t site0,
-                          hipStream_t s, const AttnBwdRagged* rg = nullptr) {
+                          hipStream_t s, const AttnBwdRagged* rg = nullptr, DwSide* side = nullptr, const GradBufs* second = nullptr) {
   auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
+  // with the side stream on, alternate layers use the second set of operand buffers, and a set is only rewritten once the side
+  // products that read it (two layers ago) have finished
+  int par = 0;
+  if (side && side->on && second) {
+    par = side->layer_no++ & 1;
+    if (par) { bufB = second->B; bufD = second->D; bufE = second->E; bufQ = second->Q; bufH = second->H; }
+    TRY(dw_side_wait(side, par, s));
+  }
+  StltGemmWgCap chain_cap(side && side->on ? dx_chain_wg_cap() : 0);
   float* df = dr.thr ? bufD : bufB;   // gradient wrt f (after the dropout mask)
   float* ds1 = dr.thr ? bufB : bufE;  // residual-path gradient behind norm1 (bufB's ds2 is dead by then when dropout is on)
   float* da = bufE;                   // gradient wrt a
@@ -198,6 +273,18 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
                                        {bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w)},
                                        {da, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w)},
                                        {bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w)}};
+  if (side && side->on && second) {
+    if (hipError_t e = hipEventRecord(side->chain[par], s); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
+    if (hipError_t e = hipStreamWaitEvent(side->s, side->chain[par], 0); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
+    {
+      StltGemmScratch lend(side->sk, STLT_GEMM_SCRATCH_BYTES);
+      StltGemmWgCap cap(dw_side_wg_cap());
+      TRY(weight_grad_all(items, 4, sc, side->s));
+    }
+    if (hipError_t e = hipEventRecord(side->done[par], side->s); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
+    side->pending[par] = true;
+    return 0;
+  }
   return weight_grad_all(items, 4, sc, s);
 }
 
@@ -455,15 +542,16 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // Both schedules: the caller may hand in scratch that an earlier step with another (B,T,N) left dirty (two shapes
   // can round to the same byte count), so the rows the weight-gradient products read beyond the row count are
   // cleared every step: at most 31 rows per buffer.
+  DwSide side = dw_side_open(sc);
   if (do_lower) {
-    for (float* b : {sc.sB, sc.sD, sc.sE}) TRY(zero_rows(b, d, tok, tokp, s));
-    TRY(zero_rows(sc.sQKV, 3 * d, tok, tokp, s));
-    TRY(zero_rows(sc.sH, 4 * d, tok, tokp, s));
+    for (float* b : {sc.sB, sc.sD, sc.sE, sc.s2.B, sc.s2.D, sc.s2.E}) TRY(zero_rows(b, d, tok, tokp, s));
+    for (float* b : {sc.sQKV, sc.s2.Q}) TRY(zero_rows(b, 3 * d, tok, tokp, s));
+    for (float* b : {sc.sH, sc.s2.H}) TRY(zero_rows(b, 4 * d, tok, tokp, s));
   }
   if (do_upper) {
-    for (float* b : {sc.tB, sc.tD, sc.tE}) TRY(zero_rows(b, d, BT, btp, s));
-    TRY(zero_rows(sc.tQKV, 3 * d, BT, btp, s));
-    TRY(zero_rows(sc.tH, 4 * d, BT, btp, s));
+    for (float* b : {sc.tB, sc.tD, sc.tE, sc.t2.B, sc.t2.D, sc.t2.E}) TRY(zero_rows(b, d, BT, btp, s));
+    for (float* b : {sc.tQKV, sc.t2.Q}) TRY(zero_rows(b, 3 * d, BT, btp, s));
+    for (float* b : {sc.tH, sc.t2.H}) TRY(zero_rows(b, 4 * d, BT, btp, s));
   }
   const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = !backbone_only && p->n_temporal > 0 && 2 * B <= BT;  // as the forward decided
   if (do_upper && backbone_only) {
@@ -473,7 +561,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     TRY(zero_rows(sc.tA, d, BT, btp, s));
     for (int64_t l = p->n_temporal - 1; l >= 0; --l)
       TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
-                         sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s, nullptr));
+                         sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s, nullptr, &side, &sc.t2));
   } else if (do_upper) {
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
@@ -503,34 +591,36 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   for (int64_t l = l_tp; l >= 0; --l)
     TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
                        sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s,
-                       ragged ? &rg_tp : nullptr));
+                       ragged ? &rg_tp : nullptr, &side, &sc.t2));
   }  // upper half: sc.tA now holds the gradient wrt the temporal tower's input
-  if (!do_lower) return 0;
-  // ---- frames embeddings (models.py:98-111)
-  TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, sc.tB, d, W(g->frames_ln_w),
-                    W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));                // tB = gradient wrt the frames' CLS rows
+  if (!do_lower) return dw_side_join(&side, s);
+  // ---- frames embeddings (models.py:98-111).  The gradient wrt the frames' CLS rows goes to tC, a chain-only buffer: the temporal
+  // tower's last weight-gradient products may still be reading tB / tD / tE / tQKV / tH on the side stream.
+  float* d_cls = sc.tC;
+  TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, d_cls, d, W(g->frames_ln_w),
+                    W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));                // d_cls = gradient wrt the frames' CLS rows
   const bool dense_scatter = !ragged && !sp_tail;  // padded dense schedule: the CLS rows sit at stride N in the token buffer
-  TRY(launch_frames_bwd(sc.tB, in->frame_types, B, T, N, d, dense_scatter ? sc.sA : nullptr, W(g->pos_emb), W(g->type_emb), sc.red, s,
+  TRY(launch_frames_bwd(d_cls, in->frame_types, B, T, N, d, dense_scatter ? sc.sA : nullptr, W(g->pos_emb), W(g->type_emb), sc.red, s,
                         ragged ? ix.f_row_of : nullptr));
   // ---- spatial transformer
   int64_t l_sp = p->n_spatial - 1;
   if (sp_tail) {
     TRY(layer_backward_tail(p->spatial[l_sp], g->spatial ? &g->spatial[l_sp] : nullptr, t.sp[l_sp], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
-                            ix.f_cls_row, BT, sc.tB, sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l_sp + 1)), s,
+                            ix.f_cls_row, BT, d_cls, sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l_sp + 1)), s,
                             ragged ? &rg_sp : nullptr));
     --l_sp;
   } else if (ragged) {
-    TRY(launch_scatter_rows(sc.tB, ix.f_cls_row, BT, d, sc.sA, tokp, s));                            // sA = d(spatial out), CLS rows only
+    TRY(launch_scatter_rows(d_cls, ix.f_cls_row, BT, d, sc.sA, tokp, s));                            // sA = d(spatial out), CLS rows only
   }
   for (int64_t l = l_sp; l >= 0; --l)
     TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
-                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr));
-  // ---- category / box / score embeddings (models.py:29-39)
-  TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sB, d, W(g->emb_ln_w), W(g->emb_ln_b),
+                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr, &side, &sc.s2));
+  // ---- category / box / score embeddings (models.py:29-39); sC for the same reason as tC above
+  TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sC, d, W(g->emb_ln_w), W(g->emb_ln_b),
                     sc.red, s, dr, 0, nullptr, STLT_SITE_EMBED));
-  TRY(launch_embed_bwd(sc.sB, in->categories, in->boxes, in->scores, p->n_categories, tok, d, W(g->cat_emb), W(g->box_w),
+  TRY(launch_embed_bwd(sc.sC, in->categories, in->boxes, in->scores, p->n_categories, tok, d, W(g->cat_emb), W(g->box_w),
                        W(g->box_b), W(g->score_w), W(g->score_b), sc.red, s, ragged ? ix.t_orig : nullptr));
-  return 0;
+  return dw_side_join(&side, s);
 }
 
 }  // extern "C"

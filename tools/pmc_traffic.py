@@ -17,8 +17,9 @@ def family(name: str) -> str:
     m = re.search(r"attn16_kernel<(\d), (true|false), (true|false)", name)
     if m:  # <NB, FULL, CAUSAL, SPLIT>: 16-row tiles, the kernel of the L <= 64 passes (temporal = causal)
         return "attn16_kernel/" + ("temporal" if m.group(3) == "true" else "spatial")
-    if "mhsa_fused_kernel" in name:
-        return "mhsa_fused_kernel"
+    m = re.search(r"mhsa16_kernel<(\d), (true|false), (true|false)>", name)
+    if m:  # <NKB, CAUSAL, TRAIN>: the fused in-projection + attention kernel (temporal = causal)
+        return "mhsa16_kernel/" + ("temporal" if m.group(2) == "true" else "spatial")
     m = re.search(r"(gemm_nt_kernel<\d|gemm_fixup_kernel|[a-z_0-9]+_kernel)", name)
     return m.group(1) if m else name[:40]
 
@@ -65,7 +66,9 @@ def main():
            "gemm_avg_bytes_per_launch": avg("gemm_nt_kernel"),
            "attn_temporal_avg_bytes_per_launch": (avg("attn16_kernel/temporal") or avg("attn_core_kernel/temporal")), "attn_temporal_algorithmic_bytes_per_launch": 1024 * (16 * 32 * 768 + 32),
            "attn_spatial_avg_bytes_per_launch": (avg("attn16_kernel/spatial") or avg("attn_core_kernel/spatial")), "attn_spatial_algorithmic_bytes_per_launch": 1024 * (16 * 32 * 7 * 768 + 32 * 7),
-           "mhsa_fused_avg_bytes_per_launch": avg("mhsa_fused_kernel"), "mhsa_fused_algorithmic_bytes_per_launch": 1024 * 32 * 768 * 8 + 4 * (3 * 768 * 768 + 3 * 768) + 1024 * 32,
+           "mhsa_fused_avg_bytes_per_launch": avg("mhsa16_kernel/temporal"), "mhsa_fused_algorithmic_bytes_per_launch": 1024 * 32 * 768 * 8 + 4 * (3 * 768 * 768 + 3 * 768) + 1024 * 32,
+           "mhsa_fused_spatial_avg_bytes_per_launch": avg("mhsa16_kernel/spatial"),
+           "mhsa_fused_spatial_algorithmic_bytes_per_launch": 1024 * 32 * 7 * 768 * 8 + 4 * (3 * 768 * 768 + 3 * 768) + 1024 * 32 * 7,
            "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps({k: doc[k] for k in ("gemm_avg_bytes_per_launch", "attn_temporal_avg_bytes_per_launch", "attn_spatial_avg_bytes_per_launch")}))

@@ -34,6 +34,15 @@ for r in step:
     d = tot.setdefault(nm, [0, 0.0]); d[0] += 1; d[1] += (e - s) / 1e3
     prev_end = max(prev_end, e)
 span = (prev_end - t0) / 1e3
-print(f"--- step span {span:.1f} us, {len(step)} dispatches, sum of gaps {gaps / 1e3:.1f} us")
+# concurrency: time with at least two kernels in flight (two streams), by queue
+evts = sorted([(int(r["Start_Timestamp"]), 1) for r in step] + [(int(r["End_Timestamp"]), -1) for r in step])
+depth, last, overlap_ns = 0, evts[0][0], 0
+for t, dlt in evts:
+    if depth >= 2:
+        overlap_ns += t - last
+    depth += dlt
+    last = t
+queues = collections.Counter(r.get("Queue_Id", "?") for r in step)
+print(f"--- step span {span:.1f} us, {len(step)} dispatches, sum of gaps {gaps / 1e3:.1f} us; >= 2 kernels in flight for {overlap_ns / 1e3:.1f} us; dispatches by queue {dict(queues)}")
 for nm, (n, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"{nm:52s} n={n:4d} total {us:9.1f} us  avg {us / n:8.1f} us  {100 * us / span:5.1f} %")
