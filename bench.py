@@ -782,7 +782,7 @@ def main():
         if world == 1 and not args.no_split_bf16 and not args.split_bf16_main:
             try:
                 # Same workload with the forward products on the BF16 matrix cores as six bf16 piece products per f32 product
-                # (csrc/gemm_bf16x3.hip, opt-in, f32-equivalent: error vs fp64 at or below the f32 kernel's).  Reported beside
+                # (csrc/gemm_bf16x3.hip, opt-in, f32-equivalent: error vs fp64 within the eps*sqrt(K) bound of an f32 accumulation).  Reported beside
                 # `value`, never as `value`: `value` is the f32-MFMA schedule's.
                 pkg.ops.set_gemm_split_bf16(6)
                 n_x3 = min(args.steps, 20)

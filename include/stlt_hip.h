@@ -69,6 +69,21 @@ int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
 int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb,
               const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride,
               int64_t M, int64_t N, int64_t K, int n_split, stlt_stream_t stream);
+/* The same nn.Linear forward (plus an optional add-source r: y = act(x·Wᵀ + b) + r, r only with STLT_ACT_NONE) on the small-tile
+ * kernel (csrc/gemm16.hip): whole tiles of 128 rows x tile_cols columns (48, 64, 96, 128, 144 or 192), no stream-K, no fix-up
+ * launch.  stlt_linear_fwd and every whole-path / training / block entry point route a product here by themselves when its launch
+ * would be under-filled on the 256 x 128 tiles and the small tiles are estimated faster (few rows: the temporal tower at the
+ * reference's default batch of 64 clips, the fusion models' 2048 / 2112-row blocks); stlt_linear_small_choice returns the tile width
+ * that dispatch picks for (M, N, K) — 0: the product stays on the large tiles; STLT_GEMM16=0 in the environment disables the routing.
+ * This entry point runs the kernel on any shape it can take (K % 32 == 0, K >= 64, N % 4 == 0, pitches % 4 == 0) with the tile width
+ * given (tests, A/B measurements); other shapes return STLT_EINVAL.  Same result as stlt_linear_fwd to fp32 rounding. */
+int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y, int64_t ldy,
+                          int64_t M, int64_t N, int64_t K, int act, int tile_cols, stlt_stream_t stream);
+int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K);
+/* Process-wide routing switch: -1 = by the launch-time estimate (default; STLT_GEMM16 in the environment is the initial value),
+ * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements). */
+int stlt_set_gemm_small_tiles(int mode);
+
 /* Optional scratch for the calling thread's stlt_linear_fwd / stlt_gemm launches (torch's nn.Linear has no
  * counterpart: this is launch policy).  With scratch lent, a launch whose 256x128 output tiles would leave compute
  * units idle (fewer tiles than CUs, or a ragged last round) is cut into equal contiguous k-step ranges instead
@@ -465,8 +480,10 @@ size_t stlt_debug_buffer_bytes(void);  /* (54 * compute units of the current dev
  * backwards (through a transposed copy of W in their scratch), when the launch has whole tiles filling at least half of the
  * workgroups (STLT_X3_MIN_FILL, default 0.5), K % 32 == 0 and K >= 64; everything else — the weight-gradient products, small
  * launches — keeps the f32-MFMA kernel.  Not the default: results agree with the f32 kernel's to f32 rounding (error against an
- * fp64 product at or below the f32 kernel's) but are not bit-identical to it, non-finite inputs give NaN where the f32 kernel
- * may give an infinity, and bench.py never reports it as `value` (side objects of the JSON line).  Process-wide switch;
+ * fp64 product within eps_f32 * sqrt(K) of the largest output, the bound of one sequential f32 accumulation: equal to the f32
+ * kernel's within 15 % on whole-tile launches, up to ~9x it on small ones, whose stream-K form sums K in short ranges) but are not
+ * bit-identical to it; an output is finite exactly where the f32 kernel's is, but infinite operands give NaN where the f32 kernel
+ * gives +-inf; and bench.py never reports it as `value` (side objects of the JSON line).  Process-wide switch;
  * STLT_EINVAL for other values. */
 int stlt_set_gemm_split_bf16(int terms);
 

@@ -86,6 +86,9 @@ SIGNATURES = {
                                  C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_linear_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                   C.c_int, _vp]),
+    "stlt_linear_small_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp]),
+    "stlt_linear_small_choice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
+    "stlt_set_gemm_small_tiles": (C.c_int, [C.c_int]),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
     "stlt_weight_grad_group": (C.c_int, [_vp, C.c_int, _vp]),

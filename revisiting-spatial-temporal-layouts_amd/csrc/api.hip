@@ -152,6 +152,17 @@ int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
   return launch_linear(x, ldx, w, bias, y, ldy, M, N, K, act, (hipStream_t)stream);
 }
 
+int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y, int64_t ldy, int64_t M,
+                          int64_t N, int64_t K, int act, int tile_cols, stlt_stream_t stream) {
+  if (tile_cols % 16 != 0) return stlt_set_error(STLT_EINVAL, "stlt_linear_small_fwd: tile_cols must be 48, 64, 96, 128, 144 or 192");
+  bool taken = false;
+  if (int e = launch_linear_gemm16(x, ldx, w, K, bias, r, ldr, y, ldy, M, N, K, act, (hipStream_t)stream, &taken, tile_cols / 16)) return e;
+  return taken || M == 0 ? 0 : stlt_set_error(STLT_EINVAL, "stlt_linear_small_fwd: shape or activation not taken by the small-tile kernel");
+}
+
+int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K) { return 16 * stlt_gemm16_choice(M, N, K, K, K); }
+int stlt_set_gemm_small_tiles(int mode) { return stlt_gemm16_set_mode(mode); }
+
 int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* r, int64_t ldr,
               float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N, int64_t K, int n_split,
               stlt_stream_t stream) {

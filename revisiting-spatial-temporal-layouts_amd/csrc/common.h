@@ -52,6 +52,38 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+#ifndef STLT_GELU_BRANCH_FREE
+#define STLT_GELU_BRANCH_FREE 1
+#endif
+// GELU of the FFN1 epilogue.  The library erff takes one of two branches per lane (|z| < 1: 8 instructions; else a
+// degree-7 polynomial + exp, ~24), so its cost in a 64-lane wave depends on the data: cheap while every lane of a wave
+// is below 1, ~38 instructions once both branches are live.  STLT_GELU_BRANCH_FREE=1 selects a fixed-cost form instead:
+// erf(t) = 1 - 2^q(t) for t = min(|z|, 3.95) with q a degree-11 fit of log2(erfc) and one v_exp_f32; max abs error of
+// erf 1.1e-7 in fp32 (200k points), the order of erff's own rounding.
+__device__ __forceinline__ float gelu_epilogue(float x) {
+#if STLT_GELU_BRANCH_FREE
+  const float z = x * 0.70710678118654752440f;
+  const float t = fminf(fabsf(z), 3.95f);
+  float q = 1.1830035617776957e-07f;
+  q = fmaf(q, t, -3.0875787615514128e-06f);
+  q = fmaf(q, t, 3.5860794014297426e-05f);
+  q = fmaf(q, t, -0.00024206875241361558f);
+  q = fmaf(q, t, 0.0010191010078415275f);
+  q = fmaf(q, t, -0.002435620641335845f);
+  q = fmaf(q, t, 0.00011764218652388081f);
+  q = fmaf(q, t, 0.027792135253548622f);
+  q = fmaf(q, t, -0.14836618304252625f);
+  q = fmaf(q, t, -0.9184255599975586f);
+  q = fmaf(q, t, -1.6279090642929077f);
+  q = fmaf(q, t, 2.831300349726007e-08f);
+  const float e = copysignf(1.0f - __builtin_amdgcn_exp2f(q), z);
+  return 0.5f * x * (1.0f + e);
+#else
+  return gelu_erf(x);
+#endif
+}
+
+
 // Counter-based dropout: keep element `idx` of site `site` iff mix32(idx; key(seed, site)) >= thr (thr = p * 2^32).
 // No mask is stored: the backward recomputes it.  Sites per encoder layer g (0.. spatial, then temporal):
 // 8g+0 attention probabilities, 8g+1 after out-proj, 8g+2 FFN hidden, 8g+3 after linear2; 0xE0 / 0xE1 = embedding outputs.
@@ -114,6 +146,11 @@ int launch_input_grad_bf16x3(const float* dy, int64_t ld_dy, const float* w, int
                              int64_t ldc, int64_t rows, float* wt_scratch, hipStream_t s, bool* taken);  // dX = dY·W through a transposed copy of W
 int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
                          int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken);
+// gemm16.hip: the same product on 128 x (16 NT) whole tiles for under-filled launches (no stream-K, no fix-up); *taken = launched
+int stlt_gemm16_set_mode(int mode);  // -1 by estimate (default), 0 off, 1 always
+int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw);  // 0 = gemm.hip keeps the product, else the tile's NT
+int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
+                         int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken, int force_nt = 0);
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
                 int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi = nullptr);

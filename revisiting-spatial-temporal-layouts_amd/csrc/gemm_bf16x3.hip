@@ -7,7 +7,10 @@
 //     a0·b0 + a0·b1 + a1·b0 + a1·b1 + a0·b2 + a2·b0,
 // each a v_mfma_f32_16x16x32_bf16 accumulating in f32 (smallest terms first): products of bf16 pieces are exact in f32, the
 // dropped terms (a1·b2, a2·b1, a2·b2) are below 2^-24 |a·b| — the rounding an f32 multiply makes anyway.  Measured error
-// against an fp64 product: at or below the f32-MFMA kernel's on every forward shape (profiles/round3_gemm_bf16x3.txt).
+// against an fp64 product: within eps_f32·sqrt(K) of the largest output on every shape tried (the bound of one sequential f32
+// accumulation; 1 200 random shapes, profiles/round3_gemm_bf16x3_fuzz.txt); on the whole-tile forward shapes at bench sizes equal
+// to the f32-MFMA kernel's within 15 % (profiles/round3_gemm_bf16x3.txt), on small launches up to ~9x the f32 kernel's, whose
+// stream-K form sums K in short ranges.  Infinite operands give NaN where the f32 kernel gives +-inf (a - a0 of an infinity).
 // The bf16 MFMA issues 16x the FLOPs of the f32 one per cycle, six of them make one f32-equivalent product: 2.7x on paper
 // (419 TFLOP/s-equivalent).  Measured 215-235 = 1.62-1.79x the f32 kernel: the chip is power-bound under bf16 MFMAs (it runs
 // this kernel at ~1.5 GHz) and after that the producer waves set the k-step; DESIGN.md section 3 has the numbers.

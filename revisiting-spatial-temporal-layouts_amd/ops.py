@@ -79,6 +79,26 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: 
     return out
 
 
+def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], tile_cols: int, act: int = L.ACT_NONE,
+                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """The same product on the small-tile kernel (csrc/gemm16.hip; include/stlt_hip.h: stlt_linear_small_fwd): whole tiles of 128 rows x
+    tile_cols columns; `residual` (M, N) is added after the bias (act must then be ACT_NONE)."""
+    lib = L.load()
+    _chk(x, torch.float32, "x"); _chk(w, torch.float32, "w")
+    N, K = w.shape
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    L.check(lib.stlt_linear_small_fwd(_p(x), K, _p(w), _p(bias), _p(residual), N, _p(out), N, M, N, K, act, int(tile_cols), _stream()),
+            "stlt_linear_small_fwd")
+    return out
+
+
+def set_gemm_small_tiles(mode: int) -> None:
+    """Routing of under-filled products to the small-tile kernel: -1 by estimate (default), 0 off, 1 always (stlt_set_gemm_small_tiles)."""
+    L.check(L.load().stlt_set_gemm_small_tiles(int(mode)), "stlt_set_gemm_small_tiles")
+
+
 def set_gemm_split_bf16(terms: int) -> None:
     """Opt-in split-bf16 build of the `linear` forward (include/stlt_hip.h: stlt_set_gemm_split_bf16): 6 = six bf16 MFMA
     products per f32 product, f32-equivalent results; 0 = the f32-MFMA kernel (default).  Process-wide."""

@@ -72,6 +72,40 @@ def test_split_bf16_leaves_other_shapes_to_the_f32_kernel(pkg, split, M, N, K):
     assert torch.equal(y0, y6)
 
 
+def test_split_bf16_special_operands_fall_in_the_f32_kernels_result_class(pkg, split):
+    """inf / NaN / subnormal / +-FLT_MAX operands (round-3 review): wherever the f32 kernel's output is finite the split kernel's is
+    finite and within the eps * sqrt(K) bound of it; wherever the f32 kernel's is not (an infinite or NaN operand, an overflowing
+    sum) the split kernel's is not either — as NaN where the f32 kernel may say +-inf (a - a0 of an infinity is NaN), which is the
+    documented difference (include/stlt_hip.h).  Rows without special operands keep the ordinary error bound."""
+    M, N, K = 10240, 768, 768
+    x, w, b = _operands(M, N, K, seed=99)
+    FLT_MAX, tiny = 3.4028234663852886e38, 1e-41  # 1e-41: an f32 subnormal
+    x[5, 17] = float("inf")
+    x[6, 100] = float("-inf")
+    x[7, 3] = float("nan")
+    x[8, :] = tiny * torch.arange(1, K + 1, device=DEV)         # a whole row of subnormals
+    x[9, 40] = FLT_MAX                                            # one huge element: finite outputs of ~1e37
+    x[10, 41] = -FLT_MAX
+    x[11, 50] = FLT_MAX; x[11, 51] = FLT_MAX                      # two of them against weights of one sign: the sum overflows
+    w[3, :] = tiny                                                # a subnormal weight row
+    w[:, 50] = w[:, 50].abs() + 0.75; w[:, 51] = w[:, 51].abs() + 0.75
+    with pkg.ops.gemm_scratch(DEV):
+        split(0)
+        y0 = pkg.ops.linear(x, w, b)
+        split(6)
+        y6 = pkg.ops.linear(x, w, b)
+    assert not torch.equal(y0[100:], y6[100:]), "the split-bf16 kernel did not run"
+    fin0, fin6 = torch.isfinite(y0), torch.isfinite(y6)
+    assert torch.equal(fin0, fin6), f"finite / non-finite pattern differs in {int((fin0 != fin6).sum())} outputs"
+    assert not fin0[5].any() and not fin0[6].any() and not fin0[7].any() and not fin0[11].any()  # the special rows really are special
+    assert fin0[8].all() and fin0[9].all() and fin0[10].all() and fin0[:, 3][fin0[:, 3]].numel() > M - 10
+    assert torch.isnan(y6[7]).all() and torch.isnan(y0[7]).all()
+    # finite outputs: the bound of one sequential f32 accumulation, relative to the row's largest output
+    scale = y0.masked_fill(~fin0, 0).abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    rel = ((y6 - y0).masked_fill(~fin0, 0).abs() / scale).max().item()
+    assert rel <= 1.2e-7 * math.sqrt(K) * 4, rel
+
+
 def test_split_bf16_setter_rejects_other_term_counts(pkg):
     with pytest.raises(pkg.StltHipError):
         pkg.ops.set_gemm_split_bf16(3)

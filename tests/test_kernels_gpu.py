@@ -505,6 +505,52 @@ def test_attn_core_short_sequences_many_items_and_masked_rows(pkg, S, L, causal)
     assert (got.double() - ref).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("tile_cols", [48, 64, 96, 128, 144, 192])
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (2112, 2304, 768), (2048, 3072, 768), (2048, 768, 3072), (1000, 1536, 64), (77, 52, 96),
+                                   (1, 4, 64), (33000, 768, 128)])
+def test_linear_small_tiles_vs_fp64(pkg, M, N, K, tile_cols):
+    """csrc/gemm16.hip: the nn.Linear forward on whole 128 x tile_cols tiles (under-filled launches), every tile width on ragged
+    and exact shapes, with bias / GELU / ReLU / residual, against an fp64 product and against the large-tile kernel."""
+    x = _rand(M, K, seed=M + K, scale=1.5)
+    w = _rand(N, K, seed=N + 1, scale=2.0 / math.sqrt(K))
+    b = _rand(N, seed=N + 2, scale=0.5)
+    r = _rand(M, N, seed=7)
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    ref = x.double() @ w.double().t()
+    tol = 3e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item())
+    for act, bias, res in ((0, bd, None), (1, bd, None), (2, bd, None), (0, None, None), (0, bd, rd)):
+        got = pkg.ops.linear_small(xd, wd, bias, tile_cols, act=act, residual=res)
+        again = pkg.ops.linear_small(xd, wd, bias, tile_cols, act=act, residual=res)
+        want = ref + (b.double() if bias is not None else 0.0)
+        if act == 1:
+            want = torch.nn.functional.gelu(want)
+        elif act == 2:
+            want = torch.relu(want)
+        if res is not None:
+            want = want + r.double()
+        assert torch.isfinite(got).all() and torch.equal(got, again)
+        assert (got.cpu().double() - want).abs().max().item() <= tol, (act, bias is not None, res is not None)
+        if res is None:
+            big = pkg.ops.linear(xd, wd, bias, act=act)
+            assert (got - big).abs().max().item() <= tol
+    with pytest.raises(pkg._lib.StltHipError):
+        pkg.ops.linear_small(xd[:, :K - 8].contiguous(), wd[:, :K - 8].contiguous(), bd, tile_cols)  # K % 32 != 0
+
+
+def test_linear_dispatch_picks_small_tiles_for_the_under_filled_products(pkg):
+    """The launch-time choice (stlt_linear_small_choice): the 2048-row products of the temporal tower at the reference's default batch
+    go to whole small tiles, the bench-sized ones stay on the 256 x 128 tiles; and ops.linear gives the small-tile kernel's bits where
+    the choice says so."""
+    lib = pkg._lib.load()
+    assert lib.stlt_linear_small_choice(2048, 768, 768) > 0 and lib.stlt_linear_small_choice(2048, 3072, 768) > 0
+    assert lib.stlt_linear_small_choice(229376, 2304, 768) == 0 and lib.stlt_linear_small_choice(32768, 3072, 768) == 0
+    M, N, K = 2048, 768, 768
+    tc = lib.stlt_linear_small_choice(M, N, K)
+    x, w, b = _rand(M, K, seed=1).to(DEV), _rand(N, K, seed=2, scale=0.05).to(DEV), _rand(N, seed=3).to(DEV)
+    with pkg.ops.gemm_scratch(DEV):
+        assert torch.equal(pkg.ops.linear(x, w, b, act=1), pkg.ops.linear_small(x, w, b, tc, act=1))
+
+
 def _mhsa_case(S, L, H, seed):
     d = 64 * H
     x = _rand(S, L, d, seed=seed, scale=1.5)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Small-tile product kernel (csrc/gemm16.hip) against the large-tile kernel (stream-K + fix-up where under-filled), per shape and
+tile width (GPU box only).  Prints one row per shape: us per launch of stlt_linear_fwd's large-tile path (routing switched off) and
+of every tile width, and the tile width the dispatch's launch-time estimate picks (0 = large tiles).
+
+    python tools/bench_gemm16.py [--rows 2048 2112 4096] [--iters 50]
+"""
+import argparse, importlib, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("revisiting-spatial-temporal-layouts_amd")
+
+
+def timed(fn, iters):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, nargs="+", default=[2048, 2112, 1088, 4096, 14336])
+    ap.add_argument("--iters", type=int, default=50)
+    a = ap.parse_args()
+    lib = pkg._lib.load()
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    d = 768
+    for M in a.rows:
+        for name, N, K, act in (("qkv", 3 * d, d, 0), ("out", d, d, 0), ("ffn1", 4 * d, d, 1), ("ffn2", d, 4 * d, 0), ("kv", 2 * d, d, 0), ("in_dx", d, 3 * d, 0)):
+            x = torch.rand(M, K, device=dev, generator=g) * 2 - 1
+            w = (torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5
+            b = torch.rand(N, device=dev, generator=g) - 0.5
+            y = torch.empty(M, N, device=dev)
+            row = {"M": M, "shape": name, "N": N, "K": K}
+            pkg.ops.set_gemm_small_tiles(0)
+            with pkg.ops.gemm_scratch(dev):
+                row["large_us"] = round(timed(lambda: pkg.ops.linear(x, w, b, act=act, out=y), a.iters), 1)
+            pkg.ops.set_gemm_small_tiles(-1)
+            best = None
+            for tc in (48, 64, 96, 128, 144, 192):
+                us = round(timed(lambda: pkg.ops.linear_small(x, w, b, tc, act=act, out=y), a.iters), 1)
+                row[f"t{tc}_us"] = us
+                if best is None or us < best[1]:
+                    best = (tc, us)
+            row["best"] = best[0]
+            row["choice"] = int(lib.stlt_linear_small_choice(M, N, K))
+            row["tflops_large"] = round(2.0 * M * N * K / row["large_us"] / 1e6, 1)
+            row["tflops_best"] = round(2.0 * M * N * K / best[1] / 1e6, 1)
+            print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -7,14 +7,24 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("revisiting-spatial-temporal-layouts_amd")
 lib = pkg._lib.load()
 M, N, K = 229376, 768, 3072
-if len(sys.argv) > 3: M, N, K = map(int, sys.argv[1:4])
+RES = "--residual" in sys.argv  # the residual-add instantiation (out-proj / FFN2 of a post-norm layer): y = x·Wᵀ + r through stlt_gemm's add-source
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+if len(args) >= 3: M, N, K = map(int, args[:3])
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
 y = torch.empty(M, N, device="cuda")
-for _ in range(2): pkg.ops.linear(x, w, b, out=y)
+r = torch.randn(M, N, device="cuda") if RES else None
+stream = torch.cuda.current_stream().cuda_stream
+def product():
+    if RES:
+        pkg._lib.check(lib.stlt_gemm(0, 0, x.data_ptr(), K, w.data_ptr(), K, r.data_ptr(), N, y.data_ptr(), N, 0, M, N, K, 1, stream), "stlt_gemm")
+    else:
+        pkg.ops.linear(x, w, b, out=y)
+for _ in range(2): product()
 buf = torch.zeros(4 * 4096 + 8192, dtype=torch.int64, device="cuda")
 lib.stlt_debug_set_buffer(buf.data_ptr())
-pkg.ops.linear(x, w, b, out=y); torch.cuda.synchronize()
+product(); torch.cuda.synchronize()
 lib.stlt_debug_set_buffer(None)
+print(f"shape M={M} N={N} K={K}  epilogue: {'+ residual (add-source)' if RES else '+ bias'}")
 G = min(((M + 255) // 256) * ((N + 127) // 128), 256)
 WAVES = 8
 t = buf[: 4 * G].view(G, 4).cpu()
