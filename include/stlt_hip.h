@@ -80,6 +80,12 @@ int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* 
 int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y, int64_t ldy,
                           int64_t M, int64_t N, int64_t K, int act, int tile_cols, stlt_stream_t stream);
 int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K);
+/* The input gradient of that Linear on the same kernel: dx (M, k_in; ld_dx) = dy (M, n_out; ld_dy) · w (n_out, k_in) (+ r), the weight
+ * read as it lies (no transposed copy: the [k][n] image is gathered inside the kernel).  The training sweeps (stlt_train_backward,
+ * the block backwards, stlt_linear_bwd) route their under-filled dX products here by the same launch-time estimate; this entry point
+ * runs it with the tile width given (n_out % 32 == 0, n_out >= 64, k_in % 4 == 0).  Same result as stlt_gemm(0, 1, ...) to rounding. */
+int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* dx,
+                          int64_t ld_dx, int64_t M, int tile_cols, stlt_stream_t stream);
 /* Process-wide routing switch: -1 = by the launch-time estimate (default; STLT_GEMM16 in the environment is the initial value),
  * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements). */
 int stlt_set_gemm_small_tiles(int mode);
@@ -129,10 +135,11 @@ int stlt_mhsa_fused_fwd_ex(const float* x, const float* in_proj_w, const float* 
                            int64_t L, int64_t H, int64_t d, float dropout_p, uint64_t seed, uint32_t site, float* ctx, float* qkv_out,
                            stlt_stream_t stream);
 /* 1 when stlt_forward / stlt_backbone_forward / stlt_train_forward run their temporal layers through the fused kernel for this
- * shape at batches that fill the device (64-channel heads, T <= 64 frames whose whole clips fill at least 112 of a work item's
- * 128 rows: T = 17, 32, 64 do, T = 33 does not and keeps the two launches; STLT_FUSED_MHSA=0 in the environment switches the
- * fused kernel off).  stlt_fused_mhsa_used answers for one launch of S sequences of L tokens (causal: temporal tower, else the
- * spatial tower): it also weighs how well S fills the last round of workgroups. */
+ * shape at 1024 clips per launch (64-channel heads, T <= 64 frames; the launch-time estimate of csrc/mhsa.hip compares the fused
+ * launch with the in-projection + attention-core pair: T = 17, 32, 64 take the fused kernel, T = 33 — 99 of a work item's 128 rows —
+ * keeps the pair; STLT_FUSED_MHSA=0 in the environment switches the fused kernel off).  stlt_fused_mhsa_used answers for one
+ * launch of S sequences of L tokens (causal: temporal tower, else the spatial tower): small launches (64 clips) go to the pair,
+ * whose in-projection then runs on the small-tile kernel. */
 int stlt_fused_mhsa_active(int64_t T, int64_t d, int64_t H);
 int stlt_fused_mhsa_used(int64_t S, int64_t L, int64_t d, int64_t H, int causal);
 /* Cross-attention core (CrossAttentionLayer of CAF/CACNF, models.py:362-382; also self-attention on unpacked buffers):

@@ -88,6 +88,7 @@ SIGNATURES = {
                                   C.c_int, _vp]),
     "stlt_linear_small_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp]),
     "stlt_linear_small_choice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
+    "stlt_input_grad_small": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int, _vp]),
     "stlt_set_gemm_small_tiles": (C.c_int, [C.c_int]),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),

@@ -160,6 +160,14 @@ int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const flo
   return taken || M == 0 ? 0 : stlt_set_error(STLT_EINVAL, "stlt_linear_small_fwd: shape or activation not taken by the small-tile kernel");
 }
 
+int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* dx, int64_t ld_dx,
+                          int64_t M, int tile_cols, stlt_stream_t stream) {
+  if (tile_cols % 16 != 0) return stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: tile_cols must be 48, 64, 96, 128, 144 or 192");
+  bool taken = false;
+  if (int e = launch_input_grad_gemm16(dy, ld_dy, w, n_out, k_in, r, ldr, dx, ld_dx, M, (hipStream_t)stream, &taken, tile_cols / 16)) return e;
+  return taken || M == 0 ? 0 : stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: shape not taken by the small-tile kernel");
+}
+
 int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K) { return 16 * stlt_gemm16_choice(M, N, K, K, K); }
 int stlt_set_gemm_small_tiles(int mode) { return stlt_gemm16_set_mode(mode); }
 
@@ -195,7 +203,7 @@ int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal, int64_t
                      (hipStream_t)stream);
 }
 
-int stlt_fused_mhsa_active(int64_t T, int64_t d, int64_t H) { return (stlt_fused_mhsa_on(1) && stlt_mhsa_fused_pays(1 << 20, T, H, d, 1)) ? 1 : 0; }
+int stlt_fused_mhsa_active(int64_t T, int64_t d, int64_t H) { return (stlt_fused_mhsa_on(1) && stlt_mhsa_fused_pays(1024, T, H, d, 1)) ? 1 : 0; }
 int stlt_fused_mhsa_used(int64_t S, int64_t L, int64_t d, int64_t H, int causal) { return (stlt_fused_mhsa_on(causal) && stlt_mhsa_fused_pays(S, L, H, d, causal)) ? 1 : 0; }
 
 int stlt_mhsa_fused_fwd(const float* x, const float* in_proj_w, const float* in_proj_b, const uint8_t* kpm, int64_t S, int64_t L, int64_t H,

@@ -74,6 +74,7 @@ int linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64
     StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
     bool taken = false;
     if ((size_t)(N * K) <= sc.wt_floats) TRY(launch_input_grad_bf16x3(dy, N, w, N, K, add, K, dx, K, M, sc.wt, s, &taken));
+    if (!taken) TRY(launch_input_grad_gemm16(dy, N, w, N, K, add, K, dx, K, M, s, &taken));  // few rows: whole small tiles
     if (!taken) TRY(launch_gemm(0, 1, dy, N, w, K, nullptr, add, K, dx, K, 0, M, K, N, 1, STLT_ACT_NONE, s));
   }
   dws.add(dy, N, x, K, M, dw);

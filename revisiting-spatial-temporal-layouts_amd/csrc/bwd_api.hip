@@ -295,7 +295,10 @@ int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, 
   float* red = (float*)((char*)scratch + STLT_GEMM_SCRATCH_BYTES);
   const bool mfma_ok = N % 32 == 0 && K % 4 == 0;  // contraction lengths / leading dimensions the MFMA kernel takes
   if (dx) {  // dx (M,K) = dy (M,N) · W (N,K)
-    if (mfma_ok) { if (int e = launch_gemm(0, 1, dy, N, w, K, nullptr, nullptr, 0, dx, K, 0, M, K, N, 1, STLT_ACT_NONE, s)) return e; }
+    bool small = false;
+    if (mfma_ok) { if (int e = launch_input_grad_gemm16(dy, N, w, N, K, nullptr, 0, dx, K, M, s, &small)) return e; }
+    if (small) {}
+    else if (mfma_ok) { if (int e = launch_gemm(0, 1, dy, N, w, K, nullptr, nullptr, 0, dx, K, 0, M, K, N, 1, STLT_ACT_NONE, s)) return e; }
     else if (int e = launch_small_gemm(dy, N, 1, w, K, 1, dx, K, M, K, N, 0, s)) return e;
   }
   if (dw) {  // dw (N,K) += dyᵀ (N,M) · x (M,K): the MFMA kernel contracts over multiples of 32 rows, the rest goes to the strided kernel

@@ -147,10 +147,13 @@ int launch_input_grad_bf16x3(const float* dy, int64_t ld_dy, const float* w, int
 int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
                          int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken);
 // gemm16.hip: the same product on 128 x (16 NT) whole tiles for under-filled launches (no stream-K, no fix-up); *taken = launched
+double stlt_linear_est_us(int64_t M, int64_t N, int64_t K);  // launch-time estimate of launch_linear's duration (us)
 int stlt_gemm16_set_mode(int mode);  // -1 by estimate (default), 0 off, 1 always
-int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw);  // 0 = gemm.hip keeps the product, else the tile's NT
+int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, bool wkn = false);  // 0 = gemm.hip keeps the product, else the tile's NT (wkn: the input-gradient build)
 int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
                          int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken, int force_nt = 0);
+int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
+                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_nt = 0);  // dX = dY·W on the small tiles, W as it lies
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
                 int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi = nullptr);

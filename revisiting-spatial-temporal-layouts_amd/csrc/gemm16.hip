@@ -39,7 +39,11 @@ struct Gemm16Args {
 template <int NT> constexpr int q_stage_floats() { return (QM + 16 * NT) * QK; }
 template <int NT> constexpr int q_smem_floats() { return q_nstage<NT>() * q_stage_floats<NT>() + 2 * 16 * NT; }
 
-template <int NT, int ACT, bool ADD>
+// WKN = false: W is (N, K) row-major (nn.Linear's weight; forward products).  WKN = true: W is (K, N) row-major — the input-gradient
+// product dX = dY·W of a Linear whose weight (n_out, k_in) is read as it lies, contraction over its rows: the W image in LDS is then
+// [32 k][BN n], both operands' fragments are gathered with the k order (16 c + lg + 4 e) so that a lane's four values of a column tile
+// are four rows of that image (ds_read_b32; bank-conflict-free for 48 / 144 columns, 2-way otherwise) — no transposed weight copy.
+template <int NT, int ACT, bool ADD, bool WKN>
 __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a) {
   constexpr int BN = 16 * NT;
   constexpr int STAGE = q_stage_floats<NT>();
@@ -89,10 +93,18 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
       }
 #pragma unroll
       for (int i = 0; i < NBL_MAX; ++i) {
-        const int r = (Ld + 4 * i) * 8 + drow;
-        int gn = tn * BN + r;
-        gn = gn < a.N ? gn : a.N - 1;
-        pb[i] = a.W + (int64_t)gn * a.ldw + (dslot ^ ((r >> 1) & 7)) * 4;
+        if (WKN) {  // instruction j = Ld + 4 i fills floats [256 j, 256 j + 256) of the [32 k][BN n] image: lane -> (k, n .. n + 3)
+          const int f = ((Ld + 4 * i) * 64 + lane) * 4;
+          const int k = f / BN, n = f - k * BN;
+          int gn = tn * BN + n;
+          gn = gn + 4 <= a.N ? gn : a.N - 4;  // columns past the matrix re-read its last four; their outputs are never stored
+          pb[i] = a.W + (int64_t)k * a.ldw + gn;
+        } else {
+          const int r = (Ld + 4 * i) * 8 + drow;
+          int gn = tn * BN + r;
+          gn = gn < a.N ? gn : a.N - 1;
+          pb[i] = a.W + (int64_t)gn * a.ldw + (dslot ^ ((r >> 1) & 7)) * 4;
+        }
       }
     };
     auto dma_bias = [&](int it) {  // loader 0 (and 1, 2 for wide tiles): BN bias values, 64 per instruction
@@ -114,7 +126,8 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
       for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_void_ptr)(pa[i] + l_kt * QK), (lds_void_ptr)(sa + i * 8 * QK), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < NBL_MAX; ++i)
-        if (i < nbl) __builtin_amdgcn_global_load_lds((glb_void_ptr)(pb[i] + l_kt * QK), (lds_void_ptr)(sb + (Ld + 4 * i) * 8 * QK), 16, 0, 0);
+        if (i < nbl) __builtin_amdgcn_global_load_lds((glb_void_ptr)(pb[i] + (WKN ? (int64_t)l_kt * QK * a.ldw : (int64_t)l_kt * QK)),
+                                                      (lds_void_ptr)(sb + (Ld + 4 * i) * 8 * QK), 16, 0, 0);
       if (++l_kt == nk) { ++l_it; l_kt = 0; }
       if (++l_stage == Q_NSTAGE) l_stage = 0;
     };
@@ -164,6 +177,19 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
     const float* s = smem + stage * STAGE;
     const int off = ((4 * (hc >> 1) + lg) ^ sw) * 4;
     Frags f;
+    if (WKN) {  // k order 16 c + lg + 4 e for MFMA e: element lg of X chunk 4 c + e; row 16 c + lg + 4 e of the [k][n] W image
+      const int c = hc >> 1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f.x[e] = s[x_row + (((4 * c + e) ^ sw) * 4) + lg];
+      const float* wk = s + QM * QK + (16 * c + lg) * BN + li;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+        if (HT * (hc & 1) + t < NT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f.w[t][e] = wk[4 * e * BN + (HT * (hc & 1) + t) * 16];
+        }
+      return f;
+    }
     f.x = *reinterpret_cast<const f32x4*>(s + x_row + off);
 #pragma unroll
     for (int t = 0; t < HT; ++t)
@@ -246,28 +272,40 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
   }
 }
 
-template <int NT, int ACT, bool ADD>
+template <int NT, int ACT, bool ADD, bool WKN>
 int launch16_as(const Gemm16Args& a, hipStream_t s) {
   static StltPerDeviceOnce attr_done;
   constexpr int SMEM = q_smem_floats<NT>() * (int)sizeof(float);
   if (!attr_done.flag()) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)gemm16_kernel<NT, ACT, ADD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); e != hipSuccess)
+    if (hipError_t e = hipFuncSetAttribute((const void*)gemm16_kernel<NT, ACT, ADD, WKN>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); e != hipSuccess)
       return stlt_set_error((int)e, "gemm16: %s", hipGetErrorString(e));
     attr_done.flag() = true;
   }
   const int64_t n_tiles = (int64_t)a.tiles_m * a.tiles_n;
   int64_t G = stlt_device_cus();
   if (G > n_tiles) G = n_tiles;
-  hipLaunchKernelGGL((gemm16_kernel<NT, ACT, ADD>), dim3((unsigned)G), dim3(Q_THREADS), SMEM, s, a);
+  hipLaunchKernelGGL((gemm16_kernel<NT, ACT, ADD, WKN>), dim3((unsigned)G), dim3(Q_THREADS), SMEM, s, a);
   return stlt_check_launch("gemm16_kernel");
 }
 
 template <int NT>
-int launch16_nt(const Gemm16Args& a, int act, bool add, hipStream_t s) {
-  if (add) return launch16_as<NT, STLT_ACT_NONE, true>(a, s);
-  if (act == STLT_ACT_GELU) return launch16_as<NT, STLT_ACT_GELU, false>(a, s);
-  if (act == STLT_ACT_RELU) return launch16_as<NT, STLT_ACT_RELU, false>(a, s);
-  return launch16_as<NT, STLT_ACT_NONE, false>(a, s);
+int launch16_nt(const Gemm16Args& a, int act, bool add, bool wkn, hipStream_t s) {
+  if (wkn) return add ? launch16_as<NT, STLT_ACT_NONE, true, true>(a, s) : launch16_as<NT, STLT_ACT_NONE, false, true>(a, s);
+  if (add) return launch16_as<NT, STLT_ACT_NONE, true, false>(a, s);
+  if (act == STLT_ACT_GELU) return launch16_as<NT, STLT_ACT_GELU, false, false>(a, s);
+  if (act == STLT_ACT_RELU) return launch16_as<NT, STLT_ACT_RELU, false, false>(a, s);
+  return launch16_as<NT, STLT_ACT_NONE, false, false>(a, s);
+}
+
+int launch16_any(int nt, const Gemm16Args& a, int act, bool add, bool wkn, hipStream_t s) {
+  switch (nt) {
+    case 3: return launch16_nt<3>(a, act, add, wkn, s);
+    case 4: return launch16_nt<4>(a, act, add, wkn, s);
+    case 6: return launch16_nt<6>(a, act, add, wkn, s);
+    case 8: return launch16_nt<8>(a, act, add, wkn, s);
+    case 9: return launch16_nt<9>(a, act, add, wkn, s);
+    default: return launch16_nt<12>(a, act, add, wkn, s);
+  }
 }
 
 constexpr int NT_CHOICES[] = {3, 4, 6, 8, 9, 12};
@@ -275,10 +313,11 @@ constexpr int NT_CHOICES[] = {3, 4, 6, 8, 9, 12};
 // Launch-time estimates (us), fitted to stand-alone measurements on MI355X (profiles/round4_gemm16_shapes.txt).
 // Small tiles: rounds x (k-steps x the tile's MFMA time at 0.54 TFLOP/s per CU + ~7 us per tile for prologue, epilogue and the
 // launch boundary) — the operand fetch is not the limit even at 48 columns.
-double est16_us(int64_t M, int64_t N, int64_t K, int nt, int64_t cus) {
+// The WKN build (input gradients: W read as [k][n]) gathers its fragments with ds_read_b32 and measures 1.25 - 1.4x the k-step time.
+double est16_us(int64_t M, int64_t N, int64_t K, int nt, int64_t cus, bool wkn = false) {
   const int64_t tiles = ((M + QM - 1) / QM) * ((N + 16 * nt - 1) / (16 * nt));
   const int64_t rounds = (tiles + cus - 1) / cus;
-  const double step = 2.0 * QM * 16.0 * nt * QK / 0.54e6;
+  const double step = 2.0 * QM * 16.0 * nt * QK / 0.54e6 * (wkn ? 1.38 : 1.0);
   return (double)rounds * ((double)(K / QK) * step + 7.0) + 1.0;
 }
 // gemm.hip's launch: 256 x 128 tiles at 3.62 us per k-step; whole-tile rounds when they fill >= 0.9 of the last round, else equal
@@ -304,7 +343,7 @@ int stlt_gemm16_set_mode(int mode) {
   g_gemm16_mode = mode;
   return 0;
 }
-int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
+int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, bool wkn) {
   if (g_gemm16_mode == -2) { const char* e = getenv("STLT_GEMM16"); g_gemm16_mode = e ? (atoi(e) == 0 ? 0 : (atoi(e) == 1 ? 1 : -1)) : -1; }
   const int mode = g_gemm16_mode;
   static const int force_nt = [] { const char* e = getenv("STLT_GEMM16_NT"); return e ? atoi(e) : 0; }();
@@ -317,12 +356,22 @@ int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw
     if (force_nt && nt != force_nt) continue;
     const int64_t tiles = ((M + QM - 1) / QM) * ((N + 16 * nt - 1) / (16 * nt));
     if (tiles > 0x3fffffffLL) continue;
-    const double us = est16_us(M, N, K, nt, cus);
+    const double us = est16_us(M, N, K, nt, cus, wkn);
     if (us < best_us) { best_us = us; best = nt; }
   }
   if (best == 0) return 0;
   if (mode == 1) return best;
   return best_us < 0.97 * est_big_us(M, N, K, cus) ? best : 0;
+}
+
+// Estimated duration (us) of the nn.Linear forward launch_linear would make for this shape: the faster of the two kernels' estimates
+// (what the routing picks).  Used by the fused MHSA dispatch to price the product + attention-core pair it competes with.
+double stlt_linear_est_us(int64_t M, int64_t N, int64_t K) {
+  const int64_t cus = stlt_device_cus();
+  double us = est_big_us(M, N, K, cus);
+  const int nt = stlt_gemm16_choice(M, N, K, K, K, false);
+  if (nt > 0) { const double small = est16_us(M, N, K, nt, cus); if (small < us) us = small; }
+  return us;
 }
 
 // Y (M, N; ldy) = act(X (M, K; ldx) · W (N, K; ldw)ᵀ + bias) (+ R (ldr)) on the small-tile kernel; *taken = false when the shape is not its.
@@ -332,7 +381,7 @@ int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ld
   if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU) return 0;
   if (r && act != STLT_ACT_NONE) return 0;
   int nt = force_nt;
-  if (nt == 0) nt = stlt_gemm16_choice(M, N, K, ldx, ldw);
+  if (nt == 0) nt = stlt_gemm16_choice(M, N, K, ldx, ldw, false);
   else if (M <= 0 || N <= 0 || K < 2 * QK || K % QK != 0 || N % 4 != 0 || ldx % 4 != 0 || ldw % 4 != 0 || M > 0x3fffff00LL || N > 0x3fffff00LL ||
            (nt != 3 && nt != 4 && nt != 6 && nt != 8 && nt != 9 && nt != 12))
     return stlt_set_error(STLT_EINVAL, "gemm16: K must be a multiple of 32 (>= 64), N and the row pitches multiples of 4, tile width 16 x {3,4,6,8,9,12}");
@@ -349,12 +398,30 @@ int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ld
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
   *taken = true;
-  switch (nt) {
-    case 3: return launch16_nt<3>(a, act, r != nullptr, s);
-    case 4: return launch16_nt<4>(a, act, r != nullptr, s);
-    case 6: return launch16_nt<6>(a, act, r != nullptr, s);
-    case 8: return launch16_nt<8>(a, act, r != nullptr, s);
-    case 9: return launch16_nt<9>(a, act, r != nullptr, s);
-    default: return launch16_nt<12>(a, act, r != nullptr, s);
-  }
+  return launch16_any(nt, a, act, r != nullptr, false, s);
+}
+
+// C (rows, k_in; ldc) = dY (rows, n_out; ld_dy) · W (n_out, k_in) (+ R): the input gradient of a Linear on the small-tile kernel, W read
+// as it lies (WKN build).  *taken = false: the product stays on gemm.hip's NN kernel (shape not taken, or estimated slower).
+int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
+                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_nt) {
+  *taken = false;
+  int nt = force_nt;
+  if (nt == 0) nt = stlt_gemm16_choice(rows, k_in, n_out, ld_dy, k_in, true);
+  else if (rows <= 0 || k_in <= 0 || n_out < 2 * QK || n_out % QK != 0 || k_in % 4 != 0 || ld_dy % 4 != 0 || rows > 0x3fffff00LL || k_in > 0x3fffff00LL ||
+           (nt != 3 && nt != 4 && nt != 6 && nt != 8 && nt != 9 && nt != 12))
+    return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): n_out must be a multiple of 32 (>= 64), k_in and the row pitches multiples of 4");
+  if (nt == 0) return 0;
+  if (!dy || !w || !c) return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): null pointer");
+  if (ld_dy < n_out || ldc < k_in || (r && ldr < k_in) || ldc % 4 != 0 || (r && ldr % 4 != 0)) return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): bad leading dimension");
+  Gemm16Args a;
+  a.X = dy; a.W = w; a.bias = nullptr; a.R = r; a.Y = c;
+  a.ldx = ld_dy; a.ldw = k_in; a.ldr = ldr; a.ldy = ldc;
+  a.M = (int)rows; a.N = (int)k_in; a.K = (int)n_out;
+  a.tiles_m = (int)((rows + QM - 1) / QM);
+  a.tiles_n = (int)((k_in + 16 * nt - 1) / (16 * nt));
+  StltProfScope ps(STLT_K_GEMM, s);
+  stlt_prof_add_flops(2.0 * (double)rows * (double)k_in * (double)n_out);
+  *taken = true;
+  return launch16_any(nt, a, STLT_ACT_NONE, r != nullptr, true, s);
 }

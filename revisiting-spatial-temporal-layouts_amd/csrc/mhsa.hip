@@ -426,21 +426,27 @@ bool stlt_mhsa_fused_takes(int64_t L, int64_t H, int64_t d, int causal) {
   return mhsa16_key_blocks((int)L, rows, causal != 0) <= 5;
 }
 
-// Is the fused launch the faster form for S sequences?  The tile holds whole sequences, so a shape whose sequences fill less than
-// 7/8 of the 128 rows loses to the product + attention-core pair (33 tokens: 99 rows -> 1227 against 1031 us at 1024 clips), and so
-// does a launch whose items leave much of the last round of workgroups idle (17 frames x 64 clips: 120 items for 256 CUs, 74.7
-// against 65.8 us; 64 frames x 64 clips: 1.5 rounds, 158.7 against 149.9) — profiles/round4_mhsa_fused_ab.txt.
+// Is the fused launch the faster form for S sequences?  Launch-time estimates fitted to stand-alone measurements on MI355X
+// (profiles/round4_mhsa_fused_ab.txt, round4_gemm16_shapes.txt):
+//   fused  = rounds of items x (k-steps x 2.91 us + 2.2 us per key block - 0.9) + 6 us — whole sequences per 128-row item, so
+//            33 tokens fill 99 rows and pay for 128 (1227 us against the pair's 1031 at 1024 clips), and a launch pays for whole
+//            rounds of workgroups (64 frames x 64 clips: 1.5 rounds = 2);
+//   pair   = the in-projection as launch_linear would run it (large tiles, stream-K, or gemm16's small tiles) + the attention core
+//            at ~5.2 TB/s of its 16 bytes per token and channel + 6 us.
+// Fused wins from ~256 clips on for 17 / 32 / 64 frames and for 5 - 8 object slots at bench sizes; the pair wins at 64 clips (small
+// tiles: 63 + 10 us against 79), for 33 frames and for 36 objects.  STLT_FUSED_MHSA_FORCE=1: whenever the shape is taken (A/B runs).
 bool stlt_mhsa_fused_pays(int64_t S, int64_t L, int64_t H, int64_t d, int causal) {
   if (!stlt_mhsa_fused_takes(L, H, d, causal)) return false;
-  static const int force = [] { const char* e = getenv("STLT_FUSED_MHSA_FORCE"); return e ? atoi(e) : 0; }();  // A/B runs: 1 = whenever the shape is taken
+  static const int force = [] { const char* e = getenv("STLT_FUSED_MHSA_FORCE"); return e ? atoi(e) : 0; }();
   if (force) return true;
   const int64_t seq_per_item = FM / L;
-  if (seq_per_item * L < 112) return false;
   const int64_t n_items = (S + seq_per_item - 1) / seq_per_item * H;
   const int64_t cus = stlt_device_cus();
   const int64_t rounds = (n_items + cus - 1) / cus;
-  const double fill = (double)n_items / (double)(rounds * cus);
-  return rounds == 1 ? fill >= 0.6 : fill >= 0.8;
+  const int nkb = mhsa16_key_blocks((int)L, (int)(seq_per_item * L), causal != 0);
+  const double fused = (double)rounds * ((double)(d / FK) * 2.91 + 2.2 * nkb - 0.9) + 6.0;
+  const double pair = stlt_linear_est_us(S * L, 3 * d, d) + 6.0 + 16.0 * (double)(S * L) * (double)d / 5.2e6;
+  return fused < pair;
 }
 
 // ctx (S*L, d) = multi-head self-attention of S sequences of L tokens with the in-projection fused in.

@@ -63,10 +63,14 @@ static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, 
 // The output gradients of a layer's four Linears (df, du, da, dqkv) are the operands of its weight-gradient products, which run on
 // a second stream beside the NEXT layer's dX chain: two sets per tower, used by alternate layers (GradBufs).
 struct GradBufs { float *B, *D, *E, *Q, *H; };
+constexpr int DW_EXTRA_SETS = 6;            // + the tower's own set + the second set = 8 layers per grouped launch
+constexpr int64_t DW_DEFER_MAX_ROWS = 4096;  // beyond this the products are long enough by themselves (weight_grad_all) and the sets large
 struct Scratch {
   float *sA, *sB, *sC, *sD, *sE, *sQKV, *sH;  // spatial: (tokp,d) x5, (tokp,3d), (tokp,4d)
   float *tA, *tB, *tC, *tD, *tE, *tQKV, *tH;  // temporal
   GradBufs s2, t2;                  // the second sets
+  GradBufs tx[DW_EXTRA_SETS];       // temporal tower, few rows (<= DW_DEFER_MAX_ROWS): more sets, so that the weight gradients of up to
+  int n_tx;                         //   eight layers run as ONE grouped launch (32 products) instead of one launch per layer
   float* sk2;                       // stream-K partial tiles of the second stream's launches
   float *hA, *hB;                   // head: (bp,d) x2
   float* slabs;
@@ -98,6 +102,8 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   s.sk = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
   s.s2 = GradBufs{take(tokp * d), take(tokp * d), take(tokp * d), take(tokp * 3 * d), take(tokp * 4 * d)};
   s.t2 = GradBufs{take(btp * d), take(btp * d), take(btp * d), take(btp * 3 * d), take(btp * 4 * d)};
+  s.n_tx = btp <= DW_DEFER_MAX_ROWS ? DW_EXTRA_SETS : 0;
+  for (int i = 0; i < s.n_tx; ++i) s.tx[i] = GradBufs{take(btp * d), take(btp * d), take(btp * d), take(btp * 3 * d), take(btp * 4 * d)};
   s.sk2 = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
   s.bytes = off;
   return s;
@@ -116,7 +122,7 @@ struct DwSide {
   bool pending[2] = {false, false};
   bool on = false;
   float* sk = nullptr;
-  int layer_no = 0;
+  int flush_no = 0;
 };
 struct DwSideDevice { hipStream_t s = nullptr; hipEvent_t ev[4] = {}; bool tried = false, ok = false; };
 static DwSideDevice g_dw_side[STLT_MAX_DEVICES];
@@ -161,6 +167,32 @@ static int dw_side_join(DwSide* sd, hipStream_t s) {
   return dw_side_wait(sd, 1, s);
 }
 
+// The weight-gradient launches of one tower.  Layers take the operand-buffer sets in turn; the products of `group_layers` consecutive
+// layers are collected and flushed as one grouped launch — on the side stream when it is on (behind an event of the chain), else on the
+// caller's stream.  A set is rewritten only after the flush that read it has finished.
+struct DwQueue {
+  DwSide* side = nullptr;
+  GradBufs sets[2 + DW_EXTRA_SETS];
+  int n_sets = 1, group_layers = 1;
+  StltWeightGradItem items[STLT_GEMM_GROUP_MAX];
+  int n_items = 0, layers_in_chunk = 0, layer_no = 0;
+  int set_flush[2 + DW_EXTRA_SETS];  // parity of the side-stream flush still reading the set, -1 = none
+  int chunk_sets[2 + DW_EXTRA_SETS];  // sets of the layers collected since the last flush
+  DwQueue() { for (int& f : set_flush) f = -1; }
+};
+static int dwq_wait_parity(DwQueue& q, int par, hipStream_t s) {
+  TRY(dw_side_wait(q.side, par, s));
+  for (int k = 0; k < q.n_sets; ++k) if (q.set_flush[k] == par) q.set_flush[k] = -1;
+  return 0;
+}
+static int dwq_begin_layer(DwQueue& q, hipStream_t s, GradBufs& out, int& set_idx) {
+  set_idx = q.layer_no++ % q.n_sets;
+  if (q.set_flush[set_idx] >= 0) TRY(dwq_wait_parity(q, q.set_flush[set_idx], s));
+  out = q.sets[set_idx];
+  return 0;
+}
+static int dwq_flush(DwQueue& q, const Scratch& sc, hipStream_t s);
+
 static int n_cu_cached() { return stlt_device_cus(); }
 
 // g_w (n_out, k_in) += dYᵀ·X with dY (Mp, n_out), X (Mp, k_in).  A weight matrix is only 18-72 output tiles, so the
@@ -191,6 +223,9 @@ static int dx_product(const float* dy, int64_t ld_dy, const float* w, int64_t n_
     TRY(launch_input_grad_bf16x3(dy, ld_dy, w, n_out, k_in, r, ldr, c, ldc, rows, sc.slabs, s, &taken));
     if (taken) return 0;
   }
+  bool small = false;  // under-filled launches (few rows): whole small tiles, W read as it lies (gemm16.hip)
+  TRY(launch_input_grad_gemm16(dy, ld_dy, w, n_out, k_in, r, ldr, c, ldc, rows, s, &small));
+  if (small) return 0;
   return launch_gemm(0, 1, dy, ld_dy, w, k_in, nullptr, r, ldr, c, ldc, 0, rows, k_in, n_out, 1, STLT_ACT_NONE, s);
 }
 
@@ -235,17 +270,17 @@ static int ffn_hidden_backward(const float* df, const float* lin2_w, const float
 static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* g, const LayerTape& t, int64_t d, int64_t H,
                           int64_t M, int64_t Mp, int64_t S, int64_t L, const uint8_t* kpm, int causal, float* bufA, float* bufB,
                           float* bufC, float* bufD, float* bufE, float* bufQ, float* bufH, const Scratch& sc, StltDrop dr, uint32_t site0,
-                          hipStream_t s, const AttnBwdRagged* rg = nullptr, DwSide* side = nullptr, const GradBufs* second = nullptr) {
+                          hipStream_t s, const AttnBwdRagged* rg = nullptr, DwQueue* q = nullptr) {
   auto G = [&](const float* stlt_layer_params::*m) -> float* { return g ? const_cast<float*>(g->*m) : nullptr; };
-  // with the side stream on, alternate layers use the second set of operand buffers, and a set is only rewritten once the side
-  // products that read it (two layers ago) have finished
-  int par = 0;
-  if (side && side->on && second) {
-    par = side->layer_no++ & 1;
-    if (par) { bufB = second->B; bufD = second->D; bufE = second->E; bufQ = second->Q; bufH = second->H; }
-    TRY(dw_side_wait(side, par, s));
+  // with a queue, the layer takes the next set of operand buffers (waiting for the flush that still reads it, if any) and leaves its
+  // four weight-gradient products with the queue
+  int set_idx = 0;
+  if (q) {
+    GradBufs gb;
+    TRY(dwq_begin_layer(*q, s, gb, set_idx));
+    bufB = gb.B; bufD = gb.D; bufE = gb.E; bufQ = gb.Q; bufH = gb.H;
   }
-  StltGemmWgCap chain_cap(side && side->on ? dx_chain_wg_cap() : 0);
+  StltGemmWgCap chain_cap(q && q->side && q->side->on ? dx_chain_wg_cap() : 0);
   float* df = dr.thr ? bufD : bufB;   // gradient wrt f (after the dropout mask)
   float* ds1 = dr.thr ? bufB : bufE;  // residual-path gradient behind norm1 (bufB's ds2 is dead by then when dropout is on)
   float* da = bufE;                   // gradient wrt a
@@ -273,19 +308,39 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
                                        {bufH, 4 * d, t.x1, d, Mp, G(&stlt_layer_params::lin1_w)},
                                        {da, d, t.ctx, d, Mp, G(&stlt_layer_params::out_proj_w)},
                                        {bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w)}};
-  if (side && side->on && second) {
+  if (q) {
+    for (int i = 0; i < 4; ++i) q->items[q->n_items++] = items[i];
+    q->chunk_sets[q->layers_in_chunk++] = set_idx;
+    if (q->layers_in_chunk >= q->group_layers || q->n_items + 4 > STLT_GEMM_GROUP_MAX) return dwq_flush(*q, sc, s);
+    return 0;
+  }
+  return weight_grad_all(items, 4, sc, s);
+}
+
+// launch what the queue has collected: one grouped launch (weight_grad_all groups products of <= 4096 rows) on the side stream behind
+// the chain's event, or on the caller's stream
+static int dwq_flush(DwQueue& q, const Scratch& sc, hipStream_t s) {
+  if (q.n_items == 0) return 0;
+  DwSide* side = q.side;
+  if (side && side->on) {
+    const int par = side->flush_no++ & 1;
+    TRY(dwq_wait_parity(q, par, s));  // the events of this parity are re-recorded below: nothing may still be waiting on them
     if (hipError_t e = hipEventRecord(side->chain[par], s); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
     if (hipError_t e = hipStreamWaitEvent(side->s, side->chain[par], 0); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
     {
       StltGemmScratch lend(side->sk, STLT_GEMM_SCRATCH_BYTES);
       StltGemmWgCap cap(dw_side_wg_cap());
-      TRY(weight_grad_all(items, 4, sc, side->s));
+      TRY(weight_grad_all(q.items, q.n_items, sc, side->s));
     }
     if (hipError_t e = hipEventRecord(side->done[par], side->s); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
     side->pending[par] = true;
-    return 0;
+    for (int i = 0; i < q.layers_in_chunk; ++i) q.set_flush[q.chunk_sets[i]] = par;
+  } else {
+    TRY(weight_grad_all(q.items, q.n_items, sc, s));
   }
-  return weight_grad_all(items, 4, sc, s);
+  q.n_items = 0;
+  q.layers_in_chunk = 0;
+  return 0;
 }
 
 // in-projection + attention core of a training forward: the packed projections stay in the tape (t.qkv) for the reverse sweep.
@@ -543,15 +598,29 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // can round to the same byte count), so the rows the weight-gradient products read beyond the row count are
   // cleared every step: at most 31 rows per buffer.
   DwSide side = dw_side_open(sc);
+  // weight-gradient queues: the spatial tower flushes per layer over two sets; the temporal tower, when it has few rows, collects up to
+  // eight layers (32 products) per grouped launch over eight sets (STLT_TRAIN_DW_GROUP_LAYERS=1: per layer, A/B runs)
+  static const int group_env = [] { const char* e = getenv("STLT_TRAIN_DW_GROUP_LAYERS"); return e ? atoi(e) : 8; }();
+  DwQueue q_sp, q_tp;
+  q_sp.side = q_tp.side = &side;
+  q_sp.sets[0] = GradBufs{sc.sB, sc.sD, sc.sE, sc.sQKV, sc.sH}; q_sp.sets[1] = sc.s2; q_sp.n_sets = 2;
+  q_tp.sets[0] = GradBufs{sc.tB, sc.tD, sc.tE, sc.tQKV, sc.tH}; q_tp.sets[1] = sc.t2; q_tp.n_sets = 2;
+  if (sc.n_tx > 0 && group_env > 1 && sc.sk) {
+    for (int i = 0; i < sc.n_tx; ++i) q_tp.sets[2 + i] = sc.tx[i];
+    q_tp.n_sets = 2 + sc.n_tx;
+    q_tp.group_layers = group_env < q_tp.n_sets ? group_env : q_tp.n_sets;
+  }
   if (do_lower) {
     for (float* b : {sc.sB, sc.sD, sc.sE, sc.s2.B, sc.s2.D, sc.s2.E}) TRY(zero_rows(b, d, tok, tokp, s));
     for (float* b : {sc.sQKV, sc.s2.Q}) TRY(zero_rows(b, 3 * d, tok, tokp, s));
     for (float* b : {sc.sH, sc.s2.H}) TRY(zero_rows(b, 4 * d, tok, tokp, s));
   }
   if (do_upper) {
-    for (float* b : {sc.tB, sc.tD, sc.tE, sc.t2.B, sc.t2.D, sc.t2.E}) TRY(zero_rows(b, d, BT, btp, s));
-    for (float* b : {sc.tQKV, sc.t2.Q}) TRY(zero_rows(b, 3 * d, BT, btp, s));
-    for (float* b : {sc.tH, sc.t2.H}) TRY(zero_rows(b, 4 * d, BT, btp, s));
+    for (int k = 0; k < q_tp.n_sets; ++k) {
+      for (float* b : {q_tp.sets[k].B, q_tp.sets[k].D, q_tp.sets[k].E}) TRY(zero_rows(b, d, BT, btp, s));
+      TRY(zero_rows(q_tp.sets[k].Q, 3 * d, BT, btp, s));
+      TRY(zero_rows(q_tp.sets[k].H, 4 * d, BT, btp, s));
+    }
   }
   const bool sp_tail = p->n_spatial > 0 && 2 * BT <= tok, tp_tail = !backbone_only && p->n_temporal > 0 && 2 * B <= BT;  // as the forward decided
   if (do_upper && backbone_only) {
@@ -561,7 +630,8 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     TRY(zero_rows(sc.tA, d, BT, btp, s));
     for (int64_t l = p->n_temporal - 1; l >= 0; --l)
       TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
-                         sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s, nullptr, &side, &sc.t2));
+                         sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s, nullptr, &q_tp));
+    TRY(dwq_flush(q_tp, sc, s));
   } else if (do_upper) {
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
@@ -591,7 +661,8 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   for (int64_t l = l_tp; l >= 0; --l)
     TRY(layer_backward(p->temporal[l], g->temporal ? &g->temporal[l] : nullptr, t.tp[l], d, H, BT, btp, B, T, in->kpm_frames, 1,
                        sc.tA, sc.tB, sc.tC, sc.tD, sc.tE, sc.tQKV, sc.tH, sc, dr, (uint32_t)(8 * (p->n_spatial + l + 1)), s,
-                       ragged ? &rg_tp : nullptr, &side, &sc.t2));
+                       ragged ? &rg_tp : nullptr, &q_tp));
+    TRY(dwq_flush(q_tp, sc, s));
   }  // upper half: sc.tA now holds the gradient wrt the temporal tower's input
   if (!do_lower) return dw_side_join(&side, s);
   // ---- frames embeddings (models.py:98-111).  The gradient wrt the frames' CLS rows goes to tC, a chain-only buffer: the temporal
@@ -614,7 +685,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   }
   for (int64_t l = l_sp; l >= 0; --l)
     TRY(layer_backward(p->spatial[l], g->spatial ? &g->spatial[l] : nullptr, t.sp[l], d, H, tok, tokp, B * T, N, in->kpm_boxes, 0,
-                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr, &side, &sc.s2));
+                       sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr, &q_sp));
   // ---- category / box / score embeddings (models.py:29-39); sC for the same reason as tC above
   TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sC, d, W(g->emb_ln_w), W(g->emb_ln_b),
                     sc.red, s, dr, 0, nullptr, STLT_SITE_EMBED));

@@ -94,6 +94,19 @@ def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual: Optional[torch.Tensor] = None):
+    """dx (M, k_in) = dy (M, n_out) · w (n_out, k_in) (+ residual) on the small-tile kernel, the weight read as it lies
+    (include/stlt_hip.h: stlt_input_grad_small)."""
+    lib = L.load()
+    _chk(dy, torch.float32, "dy"); _chk(w, torch.float32, "w")
+    n_out, k_in = w.shape
+    M = dy.numel() // n_out
+    dx = torch.empty(*dy.shape[:-1], k_in, device=dy.device, dtype=torch.float32)
+    L.check(lib.stlt_input_grad_small(_p(dy), n_out, _p(w), n_out, k_in, _p(residual), k_in, _p(dx), k_in, M, int(tile_cols), _stream()),
+            "stlt_input_grad_small")
+    return dx
+
+
 def set_gemm_small_tiles(mode: int) -> None:
     """Routing of under-filled products to the small-tile kernel: -1 by estimate (default), 0 off, 1 always (stlt_set_gemm_small_tiles)."""
     L.check(L.load().stlt_set_gemm_small_tiles(int(mode)), "stlt_set_gemm_small_tiles")

@@ -537,6 +537,33 @@ def test_linear_small_tiles_vs_fp64(pkg, M, N, K, tile_cols):
         pkg.ops.linear_small(xd[:, :K - 8].contiguous(), wd[:, :K - 8].contiguous(), bd, tile_cols)  # K % 32 != 0
 
 
+@pytest.mark.parametrize("tile_cols", [48, 64, 96, 128, 144, 192])
+@pytest.mark.parametrize("M,n_out,k_in", [(2048, 768, 768), (2112, 2304, 768), (2048, 3072, 768), (2048, 768, 3072), (1000, 64, 1536), (77, 96, 52),
+                                          (1, 64, 4), (20000, 128, 768)])
+def test_input_grad_small_tiles_vs_fp64(pkg, M, n_out, k_in, tile_cols):
+    """csrc/gemm16.hip, WKN build: dx = dy·W (+ residual) with the weight read as it lies ([k][n] image gathered in the kernel), every tile
+    width, ragged and exact shapes, against an fp64 product and against the large-tile NN kernel."""
+    dy = _rand(M, n_out, seed=M + n_out, scale=1.5)
+    w = _rand(n_out, k_in, seed=k_in + 1, scale=2.0 / math.sqrt(n_out))
+    r = _rand(M, k_in, seed=9)
+    dyd, wd, rd = dy.to(DEV), w.to(DEV), r.to(DEV)
+    ref = dy.double() @ w.double()
+    tol = 3e-6 * math.sqrt(n_out) * max(1.0, ref.abs().max().item())
+    got = pkg.ops.input_grad_small(dyd, wd, tile_cols)
+    again = pkg.ops.input_grad_small(dyd, wd, tile_cols)
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    assert (got.cpu().double() - ref).abs().max().item() <= tol
+    got_r = pkg.ops.input_grad_small(dyd, wd, tile_cols, residual=rd)
+    assert (got_r.cpu().double() - (ref + r.double())).abs().max().item() <= tol
+    if k_in % 4 == 0 and n_out % 32 == 0 and M > 1:
+        lib = pkg._lib.load()
+        big = torch.empty(M, k_in, device=DEV)
+        with pkg.ops.gemm_scratch(DEV):
+            pkg._lib.check(lib.stlt_gemm(0, 1, dyd.data_ptr(), n_out, wd.data_ptr(), k_in, None, 0, big.data_ptr(), k_in, 0, M, k_in, n_out, 1,
+                                         torch.cuda.current_stream().cuda_stream), "stlt_gemm")
+        assert (got - big).abs().max().item() <= tol
+
+
 def test_linear_dispatch_picks_small_tiles_for_the_under_filled_products(pkg):
     """The launch-time choice (stlt_linear_small_choice): the 2048-row products of the temporal tower at the reference's default batch
     go to whole small tiles, the bench-sized ones stay on the 256 x 128 tiles; and ops.linear gives the small-tile kernel's bits where

@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, nargs="+", default=[2048, 2112, 1088, 4096, 14336])
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--dx", action="store_true", help="also the input-gradient products (W read as it lies)")
     a = ap.parse_args()
     lib = pkg._lib.load()
     dev = "cuda"
@@ -54,6 +55,30 @@ def main():
             row["choice"] = int(lib.stlt_linear_small_choice(M, N, K))
             row["tflops_large"] = round(2.0 * M * N * K / row["large_us"] / 1e6, 1)
             row["tflops_best"] = round(2.0 * M * N * K / best[1] / 1e6, 1)
+            print(json.dumps(row), flush=True)
+        if not a.dx:
+            continue
+        # the input-gradient products dX = dY·W of the same Linears (W (n_out, k_in) read as it lies): large NN kernel vs the WKN build
+        for name, n_out, k_in in (("qkv_dx", 3 * d, d), ("out_dx", d, d), ("ffn1_dx", 4 * d, d), ("ffn2_dx", d, 4 * d), ("kv_dx", 2 * d, d)):
+            dy = torch.rand(M, n_out, device=dev, generator=g) * 2 - 1
+            w = (torch.rand(n_out, k_in, device=dev, generator=g) * 2 - 1) / n_out ** 0.5
+            dx = torch.empty(M, k_in, device=dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            row = {"M": M, "shape": name, "N": k_in, "K": n_out}
+            def large():
+                pkg._lib.check(lib.stlt_gemm(0, 1, dy.data_ptr(), n_out, w.data_ptr(), k_in, None, 0, dx.data_ptr(), k_in, 0, M, k_in, n_out, 1, stream), "stlt_gemm")
+            with pkg.ops.gemm_scratch(dev):
+                row["large_us"] = round(timed(large, a.iters), 1)
+            best = None
+            for tc in (48, 64, 96, 128, 144, 192):
+                us = round(timed(lambda: pkg.ops.input_grad_small(dy, w, tc), a.iters), 1)
+                row[f"t{tc}_us"] = us
+                if best is None or us < best[1]:
+                    best = (tc, us)
+            row["best"] = best[0]
+            row["choice"] = int(lib.stlt_linear_small_choice(M, k_in, n_out))
+            row["tflops_large"] = round(2.0 * M * n_out * k_in / row["large_us"] / 1e6, 1)
+            row["tflops_best"] = round(2.0 * M * n_out * k_in / best[1] / 1e6, 1)
             print(json.dumps(row), flush=True)
 
 
