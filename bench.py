@@ -312,6 +312,52 @@ def side_fusion_leg(pkg, torch, dev, B, steps, warmup):
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items() if v[1] > 0}}
 
 
+def side_fusion_train_leg(pkg, torch, dev, B, steps, warmup):
+    """BASELINE config 5's training counterpart for the default line's `cfg5_train` sub-object: one CACNF optimisation step (layout branch
+    trainable, precomputed appearance features; forward, cross entropy over the four logit heads, reverse sweep through the block-level
+    native calls, clip 5.0, AdamW) per step, dropout 0.1 as the reference trains."""
+    c = pkg.synth.CONFIGS["cfg2"]
+    kw = dict(pkg.synth.model_kwargs("cfg2"), appearance_num_frames=32, hidden_dropout_prob=0.1)
+    m = pkg.models_factory["cacnf"](pkg.MultimodalModelConfig(**kw))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234))
+    m.train(True).to(dev)
+    batch = pkg.synth.make_batch(B, c["T"], c["N"], seed=3000)
+    batch["appearance_features"] = pkg.synth.make_appearance_features(B, seed=1)
+    batch["labels"] = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(0))
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    tr = pkg.train.Trainer(m, "something", learning_rate=5e-5, weight_decay=1e-3, clip_val=5.0, warmup_steps=0, total_steps=100000)
+    for _ in range(warmup):
+        tr.step(batch)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = tr.step(batch)
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    pkg.ops.prof_take_gemm_flops()
+    pkg.ops.set_train_side_stream(False)  # per-kernel events: with the weight gradients on the side stream the kernels' spans overlap and their sum is not the step
+    pkg.ops.prof_enable(True)
+    try:
+        for _ in range(steps):
+            tr.step(batch)
+        torch.cuda.synchronize(dev)
+        prof = pkg.ops.prof_collect()
+        gflops = pkg.ops.prof_take_gemm_flops() / steps
+    finally:
+        pkg.ops.prof_enable(False)
+        pkg.ops.set_train_side_stream(True)
+    k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
+    gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
+    tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return {"workload": "cfg5 training: CACNF optimisation step (layout branch T=32, N=7, d=768 trainable + appearance features (B,2048,2,4,4), 4 appearance + "
+                        "4 fusion layers, 4 logit heads; forward, cross entropy, reverse sweep, clip 5.0, AdamW), dropout 0.1", "per_gpu_batch": B,
+            "steps": steps, "warmup": warmup, "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4),
+            "roofline": {"kernel": "every matrix-core product of the step (gemm_nt_kernel + gemm16_kernel: forward, dX, dW)", "bound": "mfma",
+                         "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                         "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4), "flops_per_step": gflops},
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items() if v[1] > 0}, "loss": float(res["loss"]), "grad_norm": float(res["grad_norm"])}
+
+
 def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
     """BASELINE config 3 on one GPU for the default line's `train_step` sub-object: the same step `--mode train` times."""
     c = pkg.synth.CONFIGS[config]
@@ -330,6 +376,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
     torch.cuda.synchronize(dev)
     sec = (time.perf_counter() - t0) / steps
     pkg.ops.prof_take_gemm_flops()
+    pkg.ops.set_train_side_stream(False)  # per-kernel events: with the weight gradients on the side stream the kernels' spans overlap and their sum is not the step
     pkg.ops.prof_enable(True)
     try:
         for _ in range(steps):
@@ -339,6 +386,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
         gflops = pkg.ops.prof_take_gemm_flops() / steps
     finally:
         pkg.ops.prof_enable(False)
+        pkg.ops.set_train_side_stream(True)
     k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -361,7 +409,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
         pkg.ops.set_gemm_split_bf16(0)
     return {**x3, "workload": f"{config}: STLT optimisation step (forward with tape, loss, reverse sweep, clip 5.0, AdamW), dropout 0.1", "per_gpu_batch": B,
             "steps": steps, "warmup": warmup, "value": round(B / sec, 2), "unit": "clips/s", "ms_per_step": round(sec * 1e3, 4),
-            "roofline": {"kernel": "gemm_nt_kernel, forward + dX + dW products", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+            "roofline": {"kernel": "gemm_nt_kernel + gemm16_kernel, forward + dX + dW products (event-timed on one stream: the timed steps run the dW products on the side stream)", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4),
                          "flops_per_step": gflops},
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()}, "loss": float(res["loss"]), "grad_norm": float(res["grad_norm"])}
@@ -423,6 +471,7 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin=None):
     k_ms, gflops = {}, 0.0
     try:
         pkg.ops.prof_take_gemm_flops()
+        pkg.ops.set_train_side_stream(False)  # per-kernel events: on the side stream the kernels' spans overlap and their sum is not the step
         pkg.ops.prof_enable(rank == 0)
         try:
             for _ in range(args.steps):
@@ -434,6 +483,7 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin=None):
                 k_ms = {k: (ms / args.steps, int(n / args.steps)) for k, (ms, n) in prof.items()}
         finally:
             pkg.ops.prof_enable(False)
+            pkg.ops.set_train_side_stream(True)
     except Exception as exc:  # the roofline leg must never cost the main line
         if world > 1:
             raise  # a rank that stops stepping would leave the others waiting in the all-reduce
@@ -452,7 +502,7 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin=None):
                                f"{c['num_spatial_layers']}+{c['num_temporal_layers']} layers, {c['num_classes']} classes, dropout 0.1",
                    "per_gpu_batch": B, "global_batch": B * world,
                    "parallelism": f"batch-shard x{world}" + (", flat-gradient all-reduce (RCCL) in two slices overlapped with the reverse sweep" if world > 1 else ", no collective")},
-        "roofline": {"kernel": "gemm_nt_kernel, forward + backward (dX, dW) products of the step", "bound": "mfma", "achieved": round(gemm_tflops, 2),
+        "roofline": {"kernel": "gemm_nt_kernel + gemm16_kernel, forward + backward (dX, dW) products of the step (event-timed on one stream: the timed steps run the dW products on the side stream)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                      "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4), "flops_per_step": gflops},
         "kernel_ms_per_step": {k: round(v[0], 4) for k, v in k_ms.items()},
@@ -670,7 +720,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collective",
                        "cls_only_last_spatial": not args.no_cls_only,
                        "flops_per_clip_dense": pkg.synth.flops_per_clip(T, N, d, c["num_spatial_layers"], c["num_temporal_layers"], c["num_classes"])},
-            "roofline": {"kernel": "gemm_nt_kernel (f32 MFMA nn.Linear)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
+            "roofline": {"kernel": "gemm_nt_kernel (f32 MFMA nn.Linear; under-filled launches on gemm16_kernel's small tiles)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                          "note": "the out-proj / FFN2 products carry the layers' residual adds in their epilogues (STLT_FUSE_RESIDUAL, default on: LayerNorm passes read one tensor); with the adds in the LayerNorm pass the products alone measure about 0.006 higher",
                          "traffic": traffic_gemm, "traffic_note": "QUOTED, not measured in this run: avg bytes/launch over the step's GEMM launches, L2 memory-side (FETCH_SIZE x2 + WRITE_SIZE), from the committed rocprofv3 --pmc passes of this command (counters cannot be read from inside the process): " + os.path.basename(tpath), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 4),
@@ -830,7 +880,8 @@ def main():
                             # utils/parser.py:62-66): the released checkpoints' 32 + 1 frames x 8 slots, and the parser's default 16 + 1 x 5
                             ("cfg2p", lambda: side_forward_leg(pkg, torch, dev, "cfg2p", B, 8, 2, split_bf16=False)),
                             ("ref_default", lambda: side_forward_leg(pkg, torch, dev, "refdef", B, 8, 2, split_bf16=False)),
-                            ("cfg5", lambda: side_fusion_leg(pkg, torch, dev, 256, 5, 2))):
+                            ("cfg5", lambda: side_fusion_leg(pkg, torch, dev, 256, 5, 2)),
+                            ("cfg5_train", lambda: side_fusion_train_leg(pkg, torch, dev, 64, 5, 2))):
                 try:
                     out[key] = fn()
                 except Exception as exc:  # the secondary legs must never cost the main line

@@ -302,6 +302,10 @@ int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, cons
  * categories (the embedding-gradient kernel keeps per-category sums in LDS; the reference's vocabularies have 4 and 38):
  * stlt_train_scratch_bytes returns 0 and stlt_train_forward / _backward return STLT_EINVAL above it, before anything runs. */
 #define STLT_TRAIN_MAX_CATEGORIES 128
+/* stlt_train_backward runs the weight-gradient products (off the dX chain) on a second, library-owned stream per device, forked
+ * from and joined to the caller's stream with events inside the call; 0 keeps every launch on the caller's stream (A/B runs, per-kernel
+ * event timing without overlap).  Process-wide; STLT_TRAIN_DW_STREAM in the environment is the initial value (default on). */
+int stlt_set_train_side_stream(int on);
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);
 size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories);
 /* flags: 0, or STLT_FLAG_SKIP_PADDING (the same value in both calls of a step): forward and reverse sweep run over the

@@ -395,10 +395,10 @@ static int launch_mhsa16_as(const Mhsa16Args& a, hipStream_t s) {
   Mhsa16Args b = a;
   // head sets per XCD group (see the kernel): only for launches of several rounds on a full grid of 8 x n workgroups.  Measured at
   // 1024 clips of 32 frames (profiles/round4_mhsa_head_sets.txt): memory-side traffic per launch 907 MB (1 set) -> 668 MB (2 sets) ->
-  // 699 MB (4 sets) at equal speed (930 / 926 / 930 us); the spatial launches (7 objects) are 0.3 % / 5.7 % slower with 2 / 4 sets
-  // and keep one.  STLT_MHSA_HEAD_SETS=1|2|4 forces a value for both towers (A/B runs).
+  // 699 MB (4 sets) at equal speed (930 / 926 / 930 us); the spatial launches (7 objects: 9.4 GB per launch with one set against
+  // 1.4 GB algorithmic) measure 6353 / 6373 / 6715 us with 1 / 2 / 4 sets.  Both towers use 2.  STLT_MHSA_HEAD_SETS=1|2|4 forces a value.
   static const int env_sets = [] { const char* e = getenv("STLT_MHSA_HEAD_SETS"); return e ? atoi(e) : 0; }();
-  const int want_sets = env_sets ? env_sets : (CAUSAL ? 2 : 1);
+  const int want_sets = env_sets ? env_sets : 2;
   b.head_sets = 1;
   if ((want_sets == 2 || want_sets == 4) && (G & 7) == 0 && a.H % want_sets == 0 && n_items >= 4 * G && a.n_groups >= 8) b.head_sets = want_sets;
   hipLaunchKernelGGL((mhsa16_kernel<NKB, CAUSAL, TRAIN>), dim3((unsigned)G), dim3(F_THREADS), G_SMEM * sizeof(float), s, b);

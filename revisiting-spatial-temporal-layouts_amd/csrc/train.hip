@@ -127,9 +127,10 @@ struct DwSide {
 struct DwSideDevice { hipStream_t s = nullptr; hipEvent_t ev[4] = {}; bool tried = false, ok = false; };
 static DwSideDevice g_dw_side[STLT_MAX_DEVICES];
 
+static int g_dw_side_wanted = -1;  // -1: not read yet (STLT_TRAIN_DW_STREAM, default on); stlt_set_train_side_stream overrides
 static bool dw_side_wanted() {
-  static const bool on = [] { const char* e = getenv("STLT_TRAIN_DW_STREAM"); return e ? atoi(e) != 0 : true; }();
-  return on;
+  if (g_dw_side_wanted < 0) { const char* e = getenv("STLT_TRAIN_DW_STREAM"); g_dw_side_wanted = e ? (atoi(e) != 0) : 1; }
+  return g_dw_side_wanted != 0;
 }
 static int dw_side_wg_cap() { static const int n = [] { const char* e = getenv("STLT_TRAIN_DW_WG"); return e ? atoi(e) : 0; }(); return n; }
 static int dx_chain_wg_cap() { static const int n = [] { const char* e = getenv("STLT_TRAIN_DX_WG"); return e ? atoi(e) : 0; }(); return n; }
@@ -459,6 +460,8 @@ static int check_train(const stlt_params* p, const stlt_inputs* in, bool need_he
 }  // namespace
 
 extern "C" {
+
+int stlt_set_train_side_stream(int on) { g_dw_side_wanted = on != 0; return 0; }
 
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal) {
   if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || n_spatial < 0 || n_spatial > 64 || n_temporal < 0 || n_temporal > 64) return 0;

@@ -107,6 +107,11 @@ def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual
     return dx
 
 
+def set_train_side_stream(on: bool) -> None:
+    """stlt_train_backward's weight-gradient products on the library's side stream (default) or on the caller's stream."""
+    L.check(L.load().stlt_set_train_side_stream(int(bool(on))), "stlt_set_train_side_stream")
+
+
 def set_gemm_small_tiles(mode: int) -> None:
     """Routing of under-filled products to the small-tile kernel: -1 by estimate (default), 0 off, 1 always (stlt_set_gemm_small_tiles)."""
     L.check(L.load().stlt_set_gemm_small_tiles(int(mode)), "stlt_set_gemm_small_tiles")

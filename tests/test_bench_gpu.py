@@ -39,6 +39,7 @@ def test_side_legs_ride_on_the_default_line():
                         "--no-skip-padding"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
+    assert "error" not in j["cfg5_train"] and j["cfg5_train"]["value"] > 0 and j["cfg5_train"]["grad_norm"] > 0 and 0 < j["cfg5_train"]["roofline"]["frac"] < 1, j["cfg5_train"]
     assert "error" not in j["cfg5"] and j["cfg5"]["value"] > 0 and j["cfg5"]["finite"] and 0 < j["cfg5"]["roofline"]["frac"] < 1, j["cfg5"]
     for key in ("train_step", "cfg4", "small_batch"):
         assert "error" not in j[key], j[key]

@@ -81,6 +81,36 @@ def test_config_surface(pkg):
     assert pkg.models_factory["stlt"] is pkg.Stlt and pkg.model_configs_factory["stlt"] is pkg.StltModelConfig
 
 
+def test_launch_time_dispatch_is_host_arithmetic(pkg):
+    """The two launch-time choices of round 4 are pure host arithmetic over (shape, CU count) and can be pinned without a GPU (256 CUs
+    are assumed when no device answers): which products go to the small-tile kernel (csrc/gemm16.hip) and which layers run the fused
+    in-projection + attention kernel (csrc/mhsa.hip) instead of the two launches."""
+    lib = pkg._lib.load()
+    # 64-clip batches of cfg2 (M = 2048): whole small tiles of 48 / 144 / 192 columns = 256 tiles; bench-sized launches stay on 256 x 128
+    assert lib.stlt_linear_small_choice(2048, 768, 768) == 48
+    assert lib.stlt_linear_small_choice(2048, 2304, 768) == 144
+    assert lib.stlt_linear_small_choice(2048, 3072, 768) == 192
+    assert lib.stlt_linear_small_choice(229376, 2304, 768) == 0 and lib.stlt_linear_small_choice(32768, 768, 3072) == 0
+    assert lib.stlt_linear_small_choice(2048, 174, 768) == 0          # N % 4 != 0: not the kernel's shape
+    # fused MHSA: from ~256 clips on for 17 / 32 / 64 frames, never for 33 frames (99 of an item's 128 rows) or 36 objects; 64-clip
+    # launches go to the pair (small-tile in-projection + attention core)
+    used = lambda S, L, causal: int(lib.stlt_fused_mhsa_used(S, L, 768, 12, causal))
+    assert [used(S, 32, 1) for S in (64, 256, 1024)] == [0, 1, 1]
+    assert [used(S, 64, 1) for S in (64, 256, 1024)] == [0, 1, 1]
+    assert used(1024, 17, 1) == 1 and used(64, 17, 1) == 0
+    assert [used(S, 33, 1) for S in (64, 256, 1024)] == [0, 0, 0]
+    assert used(32768, 7, 0) == 1 and used(32768, 8, 0) == 1 and used(32768, 36, 0) == 0
+    assert lib.stlt_fused_mhsa_active(32, 768, 12) == 1 and lib.stlt_fused_mhsa_active(17, 768, 12) == 1 and lib.stlt_fused_mhsa_active(64, 768, 12) == 1
+    assert lib.stlt_fused_mhsa_active(33, 768, 12) == 0
+    assert lib.stlt_fused_mhsa_active(65, 768, 12) == 0 and lib.stlt_fused_mhsa_active(32, 768, 8) == 0   # > 64 tokens / head dim != 64: not taken
+    # the routing switch
+    assert lib.stlt_set_gemm_small_tiles(0) == 0 and lib.stlt_linear_small_choice(2048, 768, 768) == 0
+    assert lib.stlt_set_gemm_small_tiles(-1) == 0 and lib.stlt_linear_small_choice(2048, 768, 768) == 48
+    assert lib.stlt_set_gemm_small_tiles(7) != 0
+    # training scratch: sized for the second operand sets, refused above the category limit
+    assert lib.stlt_train_scratch_bytes(64, 32, 7, 768, 4) > 0 and lib.stlt_train_scratch_bytes(64, 32, 7, 768, 129) == 0
+
+
 def test_no_cpu_fallback(pkg):
     m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs("cfg1")))
     m.train(False)
