@@ -86,6 +86,7 @@ int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K);
  * runs it with the tile width given (n_out % 32 == 0, n_out >= 64, k_in % 4 == 0).  Same result as stlt_gemm(0, 1, ...) to rounding. */
 int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* dx,
                           int64_t ld_dx, int64_t M, int tile_cols, stlt_stream_t stream);
+int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in);  /* the tile width the routing picks for that input gradient (0: large tiles) */
 /* Process-wide routing switch: -1 = by the launch-time estimate (default; STLT_GEMM16 in the environment is the initial value),
  * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements). */
 int stlt_set_gemm_small_tiles(int mode);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "stlt_linear_small_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp]),
     "stlt_linear_small_choice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "stlt_input_grad_small": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int, _vp]),
+    "stlt_input_grad_small_choice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "stlt_set_gemm_small_tiles": (C.c_int, [C.c_int]),
     "stlt_set_train_side_stream": (C.c_int, [C.c_int]),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,

@@ -169,6 +169,7 @@ int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_
 }
 
 int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K) { return 16 * stlt_gemm16_choice(M, N, K, K, K); }
+int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in) { return 16 * stlt_gemm16_choice(M, k_in, n_out, n_out, k_in, true); }
 int stlt_set_gemm_small_tiles(int mode) { return stlt_gemm16_set_mode(mode); }
 
 int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* r, int64_t ldr,

@@ -92,6 +92,8 @@ def test_launch_time_dispatch_is_host_arithmetic(pkg):
     assert lib.stlt_linear_small_choice(2048, 3072, 768) == 192
     assert lib.stlt_linear_small_choice(229376, 2304, 768) == 0 and lib.stlt_linear_small_choice(32768, 768, 3072) == 0
     assert lib.stlt_linear_small_choice(2048, 174, 768) == 0          # N % 4 != 0: not the kernel's shape
+    # input gradients (weight read as it lies: 1.38x the k-step time): the out-projection's goes to the small tiles, FFN1's (K = 3072) stays
+    assert lib.stlt_input_grad_small_choice(2048, 768, 768) == 48 and lib.stlt_input_grad_small_choice(2048, 3072, 768) == 0
     # fused MHSA: from ~256 clips on for 17 / 32 / 64 frames, never for 33 frames (99 of an item's 128 rows) or 36 objects; 64-clip
     # launches go to the pair (small-tile in-projection + attention core)
     used = lambda S, L, causal: int(lib.stlt_fused_mhsa_used(S, L, 768, 12, causal))

@@ -76,7 +76,7 @@ def main():
                 if best is None or us < best[1]:
                     best = (tc, us)
             row["best"] = best[0]
-            row["choice"] = int(lib.stlt_linear_small_choice(M, k_in, n_out))
+            row["choice"] = int(lib.stlt_input_grad_small_choice(M, n_out, k_in))
             row["tflops_large"] = round(2.0 * M * n_out * k_in / row["large_us"] / 1e6, 1)
             row["tflops_best"] = round(2.0 * M * n_out * k_in / best[1] / 1e6, 1)
             print(json.dumps(row), flush=True)
