@@ -17,6 +17,8 @@ struct BlockScratch {
   char* lin;        // stlt_linear_bwd's scratch (stream-K partial tiles + column-sum partials)
   size_t lin_bytes;
   float *ds, *da, *dctx, *dq, *dkv, *dh, *red;
+  float* red_pool;  // 4 x red: the call's partial-row reductions are deferred into one batched launch (StltReduceDefer)
+  size_t red_floats;
   float* wt;        // 4 d^2 floats: a transposed weight for the opt-in split-bf16 input-gradient products
   size_t wt_floats, total;
 };
@@ -38,11 +40,25 @@ BlockScratch block_scratch(char* base, int64_t rows, int64_t d) {
   int64_t red = ln_bwd_scratch_floats(d);
   if (512 * 4 * d > red) red = 512 * 4 * d;
   b.red = (float*)take((size_t)red * f);
+  b.red_floats = (size_t)red;
+  b.red_pool = (float*)take((size_t)red * 4 * f);
   b.wt_floats = (size_t)4 * d * d;
   b.wt = (float*)take(b.wt_floats * f);
   b.total = off;
   return b;
 }
+
+// The partial-row reductions of one backward call (LayerNorm parameters, bias column sums) run as one batched launch at its end.
+struct BlockDefer {
+  StltReduceDefer d;
+  BlockDefer(const BlockScratch& sc, hipStream_t s) {
+    d.s = s; d.pool = sc.red_pool; d.pool_floats = sc.red_floats * 4;
+    stlt_reduce_defer_set(sc.red_pool ? &d : nullptr);
+  }
+  ~BlockDefer() { stlt_reduce_defer_set(nullptr); }
+  float* chunk(const BlockScratch& sc) { int err = 0; return stlt_reduce_defer_chunk(sc.red_pool ? &d : nullptr, sc.red_floats, sc.red, &err); }
+  int flush() { return stlt_reduce_defer_flush(&d); }
+};
 
 // The weight-gradient products of a block are collected and run as ONE grouped stream-K launch at the end of the block's
 // backward (gemm.hip: launch_weight_grad_group) when every product contracts over a multiple of 32 rows; otherwise product
@@ -69,7 +85,7 @@ int flush_dw(const DwList& l, const BlockScratch& sc, hipStream_t s) {
 // dx (M,K) = dy·W (+ add); the weight gradient dw (N,K) += dyᵀ·x is queued on `dws`; db (N) += column sums of dy.
 // N (the contraction length of dx) is a multiple of 32 for every Linear of these blocks (d, 2d, 3d, 4d with d = 64 H).
 int linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, const float* add, float* dw,
-               float* db, DwList& dws, const BlockScratch& sc, hipStream_t s) {
+               float* db, DwList& dws, const BlockScratch& sc, hipStream_t s, BlockDefer* defer = nullptr) {
   if (dx && M > 0) {
     StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
     bool taken = false;
@@ -130,22 +146,25 @@ int stlt_attn_block_bwd_train(const stlt_attn_block_params* p, const stlt_attn_b
   if (scratch_bytes < sc.total) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_block_bwd_train: scratch %zu B < required %zu B", scratch_bytes, sc.total);
   const StltDrop dr = stlt_drop_make(drop_p, seed);
   auto G = [&](const float* q_) { return const_cast<float*>(q_); };
+  BlockDefer defer(sc, s);
   // out = LN(x + drop(a)): ds = residual-path gradient, da = gradient wrt a (= ds without dropout); out_proj_b += colsum(da)
   float* da = dr.thr ? sc.da : sc.ds;
-  TRY(launch_ln_bwd(dy, d, x, d, a, d, p->ln_w, eps, Mq, d, sc.ds, d, G(g->ln_w), G(g->ln_b), sc.red, s, dr, site0 + 1, sc.da, 0, G(g->out_proj_b)));
+  TRY(launch_ln_bwd(dy, d, x, d, a, d, p->ln_w, eps, Mq, d, sc.ds, d, G(g->ln_w), G(g->ln_b), defer.chunk(sc), s, dr, site0 + 1, sc.da, 0, G(g->out_proj_b)));
   // a = ctx·Woᵀ + bo
   DwList dws;
   TRY(linear_bwd(ctx, p->out_proj_w, da, Mq, d, d, sc.dctx, nullptr, G(g->out_proj_w), nullptr, dws, sc, s));
   if (!c) {
     // packed self-attention: dqkv (Mq, 3d); in_proj_b += its column sums (accumulated by the attention backward)
-    TRY(launch_attn_bwd(q, sc.dctx, kpm, causal, S, Lq, H, 64, sc.dq, s, dr, site0, G(g->in_proj_b), sc.red));
+    TRY(launch_attn_bwd(q, sc.dctx, kpm, causal, S, Lq, H, 64, sc.dq, s, dr, site0, G(g->in_proj_b), defer.chunk(sc)));
     TRY(linear_bwd(x, p->in_proj_w, sc.dq, Mq, 3 * d, d, dx, sc.ds, G(g->in_proj_w), nullptr, dws, sc, s));  // dx = dqkv·Win + ds
+    TRY(defer.flush());
     return flush_dw(dws, sc, s);
   }
   TRY(stlt_attn_bwd(q, d, kv, kv + d, 2 * d, sc.dctx, kpm, causal, S, Lq, Lk, H, 64, drop_p, seed, site0, sc.dq, d, sc.dkv, sc.dkv + d, 2 * d, stream));
-  TRY(linear_bwd(x, p->in_proj_w, sc.dq, Mq, d, d, dx, sc.ds, G(g->in_proj_w), G(g->in_proj_b), dws, sc, s));  // dx = dq·Wq + ds
+  TRY(linear_bwd(x, p->in_proj_w, sc.dq, Mq, d, d, dx, sc.ds, G(g->in_proj_w), G(g->in_proj_b), dws, sc, s, &defer));  // dx = dq·Wq + ds
   TRY(linear_bwd(c, p->in_proj_w + d * d, sc.dkv, Mk, 2 * d, d, dc, nullptr, g->in_proj_w ? G(g->in_proj_w) + d * d : nullptr,
-                 g->in_proj_b ? G(g->in_proj_b) + d : nullptr, dws, sc, s));
+                 g->in_proj_b ? G(g->in_proj_b) + d : nullptr, dws, sc, s, &defer));
+  TRY(defer.flush());
   return flush_dw(dws, sc, s);
 }
 
@@ -181,19 +200,21 @@ int stlt_ffn_block_bwd_train(const stlt_ffn_block_params* p, const stlt_ffn_bloc
   const StltDrop dr = stlt_drop_make(drop_p, seed);
   const StltDrop inner = inner_dropout ? dr : StltDrop{0u, 1.0f, 0ull};
   auto G = [&](const float* q_) { return const_cast<float*>(q_); };
+  BlockDefer defer(sc, s);
   float* df = dr.thr ? sc.da : sc.ds;
-  TRY(launch_ln_bwd(dy, d, x, d, f, d, p->ln_w, eps, M, d, sc.ds, d, G(g->ln_w), G(g->ln_b), sc.red, s, dr, site0 + 1, sc.da, 0, G(g->lin2_b)));
+  TRY(launch_ln_bwd(dy, d, x, d, f, d, p->ln_w, eps, M, d, sc.ds, d, G(g->ln_w), G(g->ln_b), defer.chunk(sc), s, dr, site0 + 1, sc.da, 0, G(g->lin2_b)));
   DwList dws;
   TRY(linear_bwd(h, p->lin2_w, df, M, d, 4 * d, sc.dh, nullptr, G(g->lin2_w), nullptr, dws, sc, s));  // dh = df·W2 ; lin2_w += dfᵀ·h
   if (act == STLT_ACT_GELU) {
-    if (g->lin1_b) TRY(launch_gelu_bwd_colsum(sc.dh, u, sc.dh, M, 4 * d, G(g->lin1_b), sc.red, s, inner, site0));
+    if (g->lin1_b) TRY(launch_gelu_bwd_colsum(sc.dh, u, sc.dh, M, 4 * d, G(g->lin1_b), defer.chunk(sc), s, inner, site0));
     else TRY(launch_gelu_bwd(sc.dh, u, sc.dh, M * 4 * d, s, inner, site0));
   } else {
     if (inner.thr) TRY(stlt_dropout(sc.dh, sc.dh, M * 4 * d, drop_p, seed, site0, stream));
     TRY(stlt_relu_bwd(sc.dh, h, sc.dh, M * 4 * d, stream));  // h > 0 <=> pre-activation > 0 and kept
-    if (g->lin1_b) TRY(launch_colsum_acc(sc.dh, 4 * d, M, 4 * d, G(g->lin1_b), sc.red, s));
+    if (g->lin1_b) TRY(launch_colsum_acc(sc.dh, 4 * d, M, 4 * d, G(g->lin1_b), defer.chunk(sc), s));
   }
   TRY(linear_bwd(x, p->lin1_w, sc.dh, M, 4 * d, d, dx, sc.ds, G(g->lin1_w), nullptr, dws, sc, s));  // dx = du·W1 + ds ; lin1_w += duᵀ·x
+  TRY(defer.flush());
   return flush_dw(dws, sc, s);
 }
 

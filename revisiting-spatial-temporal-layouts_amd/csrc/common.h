@@ -197,6 +197,23 @@ struct StltWeightGradItem { const float* dy; int64_t n_out; const float* x; int6
 int launch_weight_grad_group(const StltWeightGradItem* items, int n_items, hipStream_t s);  // needs lent stream-K scratch (StltGemmScratch); rows % 32 == 0
 bool stlt_gemm_has_scratch();
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s);
+// Deferred partial-row reductions: while a StltReduceDefer is set on the calling thread, the accumulating (+=) launch_reduce_slabs /
+// launch_reduce_slabs3 calls on its stream are collected and run as ONE batched launch per flush, each destination summed in the same
+// fixed order.  The producers' partial rows must then outlive the call that wrote them: stlt_reduce_defer_chunk hands out chunks of a
+// pool instead of one shared scratch (a full pool flushes what is pending and rewinds).  Used by stlt_train_backward: ~55 small
+// reduction launches per step become 2 - 3.
+struct StltReduceEntry { const float* slabs; float* dst[3]; int64_t stride, n; int n_slabs, n_dst; };
+constexpr int STLT_REDUCE_DEFER_MAX = 48;
+struct StltReduceDefer {
+  StltReduceEntry e[STLT_REDUCE_DEFER_MAX];
+  int n = 0;
+  hipStream_t s = nullptr;
+  float* pool = nullptr;
+  size_t pool_floats = 0, used = 0;
+};
+void stlt_reduce_defer_set(StltReduceDefer* d);  // nullptr: off
+int stlt_reduce_defer_flush(StltReduceDefer* d);
+float* stlt_reduce_defer_chunk(StltReduceDefer* d, size_t floats, float* fallback, int* err);
 int launch_reduce_slabs3(const float* slabs, int64_t stride, int n_slabs, float* dst0, float* dst1, float* dst2, int64_t n, int accumulate,
                          hipStream_t s);  // three destinations of n columns each, side by side in the slabs
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,

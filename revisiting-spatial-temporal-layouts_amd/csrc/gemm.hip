@@ -975,7 +975,86 @@ __global__ __launch_bounds__(256) void reduce_tall3_kernel(const float* __restri
   }
 }
 
+// Batched form of the two kernels above: block b belongs to entry e with blk_base[e] <= b < blk_base[e + 1]; per destination column the
+// same summation order (16 interleaved partial sums over the slabs, then the 16 parts in order, then += dst).
+struct ReduceBatch { StltReduceEntry e[STLT_REDUCE_DEFER_MAX]; int blk_base[STLT_REDUCE_DEFER_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceBatch b) {
+  __shared__ float part[16][17];
+  int ei = 0;
+  while (ei + 1 < b.n && (int)blockIdx.x >= b.blk_base[ei + 1]) ++ei;
+  const StltReduceEntry& en = b.e[ei];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t j = (int64_t)((int)blockIdx.x - b.blk_base[ei]) * 16 + col;
+  const int which = en.n_dst == 1 ? 0 : (int)(j / en.n);  // n % 16 == 0 for multi-destination entries: a block never straddles destinations
+  float* dst = which < en.n_dst ? (which == 0 ? en.dst[0] : which == 1 ? en.dst[1] : en.dst[2]) : nullptr;
+  const bool live = j < (int64_t)en.n_dst * en.n && dst != nullptr;
+  float acc = 0.f;
+  if (live)
+    for (int s = sl; s < en.n_slabs; s += 16) acc += en.slabs[s * en.stride + j];
+  part[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && live) {
+    const int64_t c = j - (int64_t)which * en.n;
+    float t = dst[c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][col];
+    dst[c] = t;
+  }
+}
+
+thread_local StltReduceDefer* t_reduce_defer = nullptr;
+
 }  // namespace
+
+void stlt_reduce_defer_set(StltReduceDefer* d) { t_reduce_defer = d; }
+
+int stlt_reduce_defer_flush(StltReduceDefer* d) {
+  if (!d || d->n == 0) return 0;
+  ReduceBatch b;
+  int blocks = 0;
+  for (int i = 0; i < d->n; ++i) {
+    b.e[i] = d->e[i];
+    b.blk_base[i] = blocks;
+    blocks += (int)(((int64_t)d->e[i].n_dst * d->e[i].n + 15) / 16);
+  }
+  for (int i = d->n; i <= STLT_REDUCE_DEFER_MAX; ++i) b.blk_base[i] = blocks;
+  b.n = d->n;
+  d->n = 0;
+  StltProfScope ps(STLT_K_MISC, d->s);
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, d->s, b);
+  return stlt_check_launch("reduce_batch_kernel");
+}
+
+// next chunk of the pool for a producer's partial rows; a full pool first flushes the entries that still read it
+float* stlt_reduce_defer_chunk(StltReduceDefer* d, size_t floats, float* fallback, int* err) {
+  *err = 0;
+  if (!d || !d->pool || floats > d->pool_floats) return fallback;
+  floats = (floats + 63) / 64 * 64;
+  if (d->used + floats > d->pool_floats) {
+    *err = stlt_reduce_defer_flush(d);
+    d->used = 0;
+  }
+  float* p = d->pool + d->used;
+  d->used += floats;
+  return p;
+}
+
+static bool reduce_defer_take(const float* slabs, int64_t stride, int n_slabs, float* d0, float* d1, float* d2, int n_dst, int64_t n, hipStream_t s, int* err) {
+  StltReduceDefer* d = t_reduce_defer;
+  *err = 0;
+  if (!d || s != d->s || !d->pool || slabs < d->pool || slabs >= d->pool + d->pool_floats) return false;  // only partial rows that live in the pool
+  if (((int64_t)n_dst * n + 15) / 16 > 0x3fffffLL) return false;
+  bool clash = d->n == STLT_REDUCE_DEFER_MAX;  // a destination may appear once per batch (its blocks read-modify-write it)
+  for (int i = 0; i < d->n && !clash; ++i)
+    for (int a = 0; a < d->e[i].n_dst; ++a) {
+      float* q = d->e[i].dst[a];
+      if (q && (q == d0 || (n_dst > 1 && (q == d1 || q == d2)))) clash = true;
+    }
+  if (clash) { *err = stlt_reduce_defer_flush(d); if (*err) return true; }
+  StltReduceEntry& e = d->e[d->n++];
+  e.slabs = slabs; e.dst[0] = d0; e.dst[1] = d1; e.dst[2] = d2; e.stride = stride; e.n = n; e.n_slabs = n_slabs; e.n_dst = n_dst;
+  return true;
+}
 
 // workgroups a launch may use: the device's CUs, or fewer while a StltGemmWgCap is alive on the calling thread (two persistent
 // launches on two streams can only share the chip if their grids add up to the CU count: one 144-KB workgroup fits a CU)
@@ -1226,6 +1305,7 @@ void stlt_gemm_set_scratch_impl(void* p, size_t bytes) {
 int launch_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* dst, int64_t n, int accumulate, hipStream_t s) {
   if (!slabs || !dst || n_slabs < 1) return stlt_set_error(STLT_EINVAL, "reduce_slabs: bad arguments");
   if (n == 0) return 0;
+  if (accumulate) { int err = 0; if (reduce_defer_take(slabs, stride, n_slabs, dst, nullptr, nullptr, 1, n, s, &err)) return err; }
   if (n_slabs > 32 && n <= 16384) {
     hipLaunchKernelGGL(reduce_tall_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, slabs, stride, n_slabs, dst, n, accumulate);
     return stlt_check_launch("reduce_tall_kernel");
@@ -1241,6 +1321,7 @@ int launch_reduce_slabs3(const float* slabs, int64_t stride, int n_slabs, float*
                          hipStream_t s) {
   if (!slabs || n_slabs < 1) return stlt_set_error(STLT_EINVAL, "reduce_slabs: bad arguments");
   if (n == 0 || (!dst0 && !dst1 && !dst2)) return 0;
+  if (accumulate && n % 16 == 0) { int err = 0; if (reduce_defer_take(slabs, stride, n_slabs, dst0, dst1, dst2, 3, n, s, &err)) return err; }
   if (n % 16 != 0 || n > 16384) {  // shapes the fused kernel does not take: one launch per destination
     float* dsts[3] = {dst0, dst1, dst2};
     for (int k = 0; k < 3; ++k)

@@ -77,7 +77,15 @@ struct Scratch {
   float* red;
   float* sk;
   size_t slab_floats, bytes;
+  float* red_pool;                  // chunks of `red_floats` for the sweep's partial rows while their reductions are deferred (StltReduceDefer)
+  size_t red_floats, red_pool_floats;
+  StltReduceDefer* defer = nullptr;
 };
+// the partial-row scratch of the next producer: a fresh chunk of the pool while reductions are deferred, else the one shared buffer
+static float* RED(const Scratch& sc) {
+  int err = 0;
+  return stlt_reduce_defer_chunk(sc.defer, sc.red_floats, sc.red, &err);
+}
 
 constexpr int MAX_SPLIT = 32;
 constexpr int AB_MAX_ROWS = 256;  // attention backward: longest sequence (backward.hip: 64 in LDS, up to 256 streamed)
@@ -99,6 +107,10 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   const int64_t eb = embed_bwd_scratch_floats(B * T * N, C, d);
   if (eb > red) red = eb;
   s.red = take(red);
+  s.red_floats = (size_t)red;
+  s.red_pool_floats = (size_t)red * 24 < ((size_t)64 << 20) ? (size_t)red * 24 : ((size_t)64 << 20);  // <= 256 MB
+  if (s.red_pool_floats < (size_t)red) s.red_pool_floats = 0;  // a chunk would not fit: no deferral
+  s.red_pool = s.red_pool_floats ? take((int64_t)s.red_pool_floats) : nullptr;
   s.sk = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
   s.s2 = GradBufs{take(tokp * d), take(tokp * d), take(tokp * d), take(tokp * 3 * d), take(tokp * 4 * d)};
   s.t2 = GradBufs{take(btp * d), take(btp * d), take(btp * d), take(btp * 3 * d), take(btp * 4 * d)};
@@ -253,12 +265,13 @@ static int ffn_hidden_backward(const float* df, const float* lin2_w, const float
                                const Scratch& sc, StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s) {
   static const bool fused = [] { const char* e = getenv("STLT_FUSE_GELU_BWD"); return e ? atoi(e) != 0 : true; }();
   if (fused && g_lin1_b && !(sc.sk && stlt_split_bf16_takes(rows, 4 * d, d, d, d))) {  // (the split-bf16 product has no GELU-backward epilogue)
-    const StltGemmEpi epi{dr, site, drop_rows, sc.red};
+    float* cs = RED(sc);
+    const StltGemmEpi epi{dr, site, drop_rows, cs};
     TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi));
-    return launch_reduce_slabs(sc.red, 4 * d, (int)((rows + 255) / 256 * 16), g_lin1_b, 4 * d, 1, s);
+    return launch_reduce_slabs(cs, 4 * d, (int)((rows + 255) / 256 * 16), g_lin1_b, 4 * d, 1, s);
   }
   TRY(dx_product(df, d, lin2_w, d, 4 * d, nullptr, 0, du, 4 * d, rows, sc, s));  // dh
-  if (g_lin1_b) return launch_gelu_bwd_colsum(du, u, du, rows, 4 * d, g_lin1_b, sc.red, s, dr, site, drop_rows);  // du; lin1_b += colsum(du)
+  if (g_lin1_b) return launch_gelu_bwd_colsum(du, u, du, rows, 4 * d, g_lin1_b, RED(sc), s, dr, site, drop_rows);  // du; lin1_b += colsum(du)
   return launch_gelu_bwd(du, u, du, rows * 4 * d, s, dr, site, drop_rows, 4 * d);
 }
 
@@ -287,7 +300,7 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
   float* da = bufE;                   // gradient wrt a
   // y = LN2(x1 + drop(f))
   TRY(launch_ln_bwd(bufA, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, M, d, bufB, d, G(&stlt_layer_params::norm2_w),
-                    G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0,
+                    G(&stlt_layer_params::norm2_b), RED(sc), s, dr, site0 + 3, bufD, 0,
                     G(&stlt_layer_params::lin2_b)));                                               // bufB = ds2, df; lin2_b += colsum(df)
   // f = h·W2ᵀ + b2
   // h = drop(gelu(u)): bufH = du = drop(df·W2) ∘ gelu'(u); lin1_b += colsum(du)
@@ -296,12 +309,12 @@ static int layer_backward(const stlt_layer_params& lp, const stlt_layer_params* 
   TRY(dx_product(bufH, 4 * d, lp.lin1_w, 4 * d, d, bufB, d, bufC, d, M, sc, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x + drop(a))
   TRY(launch_ln_bwd(bufC, d, t.x, d, t.a, d, lp.norm1_w, 1e-5f, M, d, ds1, d, G(&stlt_layer_params::norm1_w),
-                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufE, 0,
+                    G(&stlt_layer_params::norm1_b), RED(sc), s, dr, site0 + 1, bufE, 0,
                     G(&stlt_layer_params::out_proj_b)));                                           // ds1, da; out_proj_b += colsum(da)
   // a = ctx·Woᵀ + bo
   TRY(dx_product(da, d, lp.out_proj_w, d, d, nullptr, 0, bufC, d, M, sc, s));  // bufC = dctx
   // ctx = attention(qkv) with dropout on the probabilities
-  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv; in_proj_b += colsum(dqkv)
+  TRY(launch_attn_bwd(t.qkv, bufC, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), RED(sc), rg));  // bufQ = dqkv; in_proj_b += colsum(dqkv)
   // qkv = x·Winᵀ + bin
   TRY(dx_product(bufQ, 3 * d, lp.in_proj_w, 3 * d, d, ds1, d, bufA, d, M, sc, s));  // bufA = dx = dqkv·Win + ds1
   // the four weight gradients (off the dX chain): one grouped launch
@@ -418,7 +431,7 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   TRY(zero_rows(bufH, 4 * d, n, np, s));
   // y = LN2(x1 + drop(f))
   TRY(launch_ln_bwd(dy, d, t.x1, d, t.f, d, lp.norm2_w, 1e-5f, n, d, bufB, d, G(&stlt_layer_params::norm2_w),
-                    G(&stlt_layer_params::norm2_b), sc.red, s, dr, site0 + 3, bufD, 0, G(&stlt_layer_params::lin2_b), rows));
+                    G(&stlt_layer_params::norm2_b), RED(sc), s, dr, site0 + 3, bufD, 0, G(&stlt_layer_params::lin2_b), rows));
   TRY(ffn_hidden_backward(df, lp.lin2_w, t.u, bufH, n, d, G(&stlt_layer_params::lin1_b), sc, dr, site0 + 2, rows, s));  // bufH = du
   TRY(dx_product(bufH, 4 * d, lp.lin1_w, 4 * d, d, bufB, d, bufC, d, n, sc, s));  // bufC = dx1 = du·W1 + ds2
   // x1 = LN1(x[rows] + drop(a)), a = ctx[rows]·Woᵀ + bo: gather the two inputs again (bufQ is free until the attention backward)
@@ -427,7 +440,7 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   TRY(launch_gather_rows(t.x, d, rows, n, d, g_x, s));
   TRY(launch_gather_rows(t.ctx, d, rows, n, d, g_ctx, s));
   TRY(launch_ln_bwd(bufC, d, g_x, d, t.a, d, lp.norm1_w, 1e-5f, n, d, ds1, d, G(&stlt_layer_params::norm1_w),
-                    G(&stlt_layer_params::norm1_b), sc.red, s, dr, site0 + 1, bufE, 0, G(&stlt_layer_params::out_proj_b), rows));  // ds1, da
+                    G(&stlt_layer_params::norm1_b), RED(sc), s, dr, site0 + 1, bufE, 0, G(&stlt_layer_params::out_proj_b), rows));  // ds1, da
   TRY(dx_product(da, d, lp.out_proj_w, d, d, nullptr, 0, bufC, d, n, sc, s));  // bufC = dctx of the picked rows
   // the weight gradients of the three Linears that ran on the picked rows: one grouped launch, before bufH / bufQ are reused
   const StltWeightGradItem items[3] = {{df, d, t.h, 4 * d, np, G(&stlt_layer_params::lin2_w)},
@@ -436,7 +449,7 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
   TRY(weight_grad_all(items, 3, sc, s));
   // the other rows' attention outputs were never read: their dctx is zero
   TRY(launch_scatter_rows(bufC, rows, n, d, bufH, M, s));                                           // bufH (as M x d) = dctx
-  TRY(launch_attn_bwd(t.qkv, bufH, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), sc.red, rg));  // bufQ = dqkv
+  TRY(launch_attn_bwd(t.qkv, bufH, kpm, causal, S, L, H, d / H, bufQ, s, dr, site0, G(&stlt_layer_params::in_proj_b), RED(sc), rg));  // bufQ = dqkv
   TRY(weight_grad(bufQ, 3 * d, t.x, d, Mp, G(&stlt_layer_params::in_proj_w), sc, s));
   TRY(launch_scatter_rows(ds1, rows, n, d, bufC, M, s));                                            // residual path: ds1 on the picked rows only
   TRY(dx_product(bufQ, 3 * d, lp.in_proj_w, 3 * d, d, bufC, d, bufA, d, M, sc, s));  // bufA = dx = dqkv·Win + ds1
@@ -572,8 +585,21 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H, K = p->n_classes;
   const Tape t = tape_layout((char*)const_cast<void*>(tape_mem), B, T, N, d, p->n_spatial, p->n_temporal);
   if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
-  const Scratch sc = scratch_layout((char*)scratch_mem, B, T, N, d, p->n_categories);
+  Scratch sc = scratch_layout((char*)scratch_mem, B, T, N, d, p->n_categories);
   if (scratch_bytes < sc.bytes) return stlt_set_error(STLT_EWORKSPACE, "scratch %zu B < required %zu B", scratch_bytes, sc.bytes);
+  // the sweep's ~55 partial-row reductions (LayerNorm / bias gradients) are collected and run as a few batched launches
+  // (STLT_TRAIN_DEFER_REDUCE=0: one launch each, A/B runs)
+  static const bool defer_on = [] { const char* e = getenv("STLT_TRAIN_DEFER_REDUCE"); return e ? atoi(e) != 0 : true; }();
+  StltReduceDefer defer;
+  defer.s = (hipStream_t)stream;
+  defer.pool = sc.red_pool;
+  defer.pool_floats = sc.red_pool_floats;
+  struct DeferGuard {
+    StltReduceDefer* d;
+    explicit DeferGuard(StltReduceDefer* x) : d(x) { stlt_reduce_defer_set(d); }
+    ~DeferGuard() { stlt_reduce_defer_set(nullptr); }
+  } defer_guard(defer_on && sc.red_pool ? &defer : nullptr);
+  if (defer_on && sc.red_pool) sc.defer = &defer;
   int64_t tok = B * T * N, BT = B * T;
   int64_t tokp = t.tokp, btp = t.btp;
   StltGemmScratch gemm_scratch(sc.sk, STLT_GEMM_SCRATCH_BYTES);
@@ -600,7 +626,9 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // Both schedules: the caller may hand in scratch that an earlier step with another (B,T,N) left dirty (two shapes
   // can round to the same byte count), so the rows the weight-gradient products read beyond the row count are
   // cleared every step: at most 31 rows per buffer.
-  DwSide side = dw_side_open(sc);
+  // (the fusion models' layout branch — STLT_FLAG_TRAIN_BACKBONE — keeps one stream: measured 43.75 against 44.1 ms per CACNF step at 64
+  // clips; the block-level calls around the sweep are single-stream and the side launches only delay their small kernels)
+  DwSide side = backbone_only ? DwSide{} : dw_side_open(sc);
   // weight-gradient queues: the spatial tower flushes per layer over two sets; the temporal tower, when it has few rows, collects up to
   // eight layers (32 products) per grouped launch over eight sets (STLT_TRAIN_DW_GROUP_LAYERS=1: per layer, A/B runs)
   static const int group_env = [] { const char* e = getenv("STLT_TRAIN_DW_GROUP_LAYERS"); return e ? atoi(e) : 8; }();
@@ -638,10 +666,10 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   } else if (do_upper) {
   // ---- prediction head (models.py:162-163): logits = z2·W2ᵀ+b2, z2 = LN(z1), z1 = gelu(u0), u0 = h0·W1ᵀ+b1
   if (g->fc2_w) TRY(launch_small_gemm(dlogits, 1, K, t.z2, d, 1, W(g->fc2_w), d, K, d, B, 1, s));   // (K,d) += dlogitsᵀ·z2
-  if (g->fc2_b) TRY(launch_colsum_acc(dlogits, K, B, K, W(g->fc2_b), sc.red, s));
+  if (g->fc2_b) TRY(launch_colsum_acc(dlogits, K, B, K, W(g->fc2_b), RED(sc), s));
   TRY(launch_small_gemm(dlogits, K, 1, p->fc2_w, d, 1, sc.hA, d, B, d, K, 0, s));                   // hA = dz2
   TRY(launch_ln_bwd(sc.hA, d, t.z1, d, nullptr, 0, p->head_ln_w, p->ln_eps, B, d, sc.hB, d, W(g->head_ln_w), W(g->head_ln_b),
-                    sc.red, s));                                                                    // hB = dz1
+                    RED(sc), s));                                                                    // hB = dz1
   TRY(launch_gelu_bwd(sc.hB, t.u0, sc.hB, B * d, s));                                               // hB = du0
   // the two d x d products of fc1 go to the MFMA kernel (it contracts over multiples of 32 clips; the strided kernel takes the rest)
   if (g->fc1_w) {                                                                                   // (d,d) += du0ᵀ·h0
@@ -649,7 +677,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     if (Bf > 0) TRY(launch_gemm(1, 1, sc.hB, d, t.h0, d, nullptr, W(g->fc1_w), d, W(g->fc1_w), d, 0, d, d, Bf, 1, STLT_ACT_NONE, s));
     if (B > Bf) TRY(launch_small_gemm(sc.hB + Bf * d, 1, d, t.h0 + Bf * d, d, 1, W(g->fc1_w), d, d, d, B - Bf, 1, s));
   }
-  if (g->fc1_b) TRY(launch_colsum_acc(sc.hB, d, B, d, W(g->fc1_b), sc.red, s));
+  if (g->fc1_b) TRY(launch_colsum_acc(sc.hB, d, B, d, W(g->fc1_b), RED(sc), s));
   TRY(launch_gemm(0, 1, sc.hB, d, p->fc1_w, d, nullptr, nullptr, 0, sc.hA, d, 0, B, d, d, 1, STLT_ACT_NONE, s));  // hA = dh0
   // ---- temporal transformer
   int64_t l_tp = p->n_temporal - 1;
@@ -667,14 +695,14 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
                        ragged ? &rg_tp : nullptr, &q_tp));
     TRY(dwq_flush(q_tp, sc, s));
   }  // upper half: sc.tA now holds the gradient wrt the temporal tower's input
-  if (!do_lower) return dw_side_join(&side, s);
+  if (!do_lower) { TRY(stlt_reduce_defer_flush(sc.defer)); return dw_side_join(&side, s); }
   // ---- frames embeddings (models.py:98-111).  The gradient wrt the frames' CLS rows goes to tC, a chain-only buffer: the temporal
   // tower's last weight-gradient products may still be reading tB / tD / tE / tQKV / tH on the side stream.
   float* d_cls = sc.tC;
   TRY(launch_ln_bwd(sc.tA, d, t.s_frames, d, nullptr, 0, p->frames_ln_w, p->ln_eps, BT, d, d_cls, d, W(g->frames_ln_w),
-                    W(g->frames_ln_b), sc.red, s, dr, 0, nullptr, STLT_SITE_FRAMES));                // d_cls = gradient wrt the frames' CLS rows
+                    W(g->frames_ln_b), RED(sc), s, dr, 0, nullptr, STLT_SITE_FRAMES));                // d_cls = gradient wrt the frames' CLS rows
   const bool dense_scatter = !ragged && !sp_tail;  // padded dense schedule: the CLS rows sit at stride N in the token buffer
-  TRY(launch_frames_bwd(d_cls, in->frame_types, B, T, N, d, dense_scatter ? sc.sA : nullptr, W(g->pos_emb), W(g->type_emb), sc.red, s,
+  TRY(launch_frames_bwd(d_cls, in->frame_types, B, T, N, d, dense_scatter ? sc.sA : nullptr, W(g->pos_emb), W(g->type_emb), RED(sc), s,
                         ragged ? ix.f_row_of : nullptr));
   // ---- spatial transformer
   int64_t l_sp = p->n_spatial - 1;
@@ -691,9 +719,10 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
                        sc.sA, sc.sB, sc.sC, sc.sD, sc.sE, sc.sQKV, sc.sH, sc, dr, (uint32_t)(8 * (l + 1)), s, ragged ? &rg_sp : nullptr, &q_sp));
   // ---- category / box / score embeddings (models.py:29-39); sC for the same reason as tC above
   TRY(launch_ln_bwd(sc.sA, d, t.s_embed, d, nullptr, 0, p->emb_ln_w, p->ln_eps, tok, d, sc.sC, d, W(g->emb_ln_w), W(g->emb_ln_b),
-                    sc.red, s, dr, 0, nullptr, STLT_SITE_EMBED));
+                    RED(sc), s, dr, 0, nullptr, STLT_SITE_EMBED));
   TRY(launch_embed_bwd(sc.sC, in->categories, in->boxes, in->scores, p->n_categories, tok, d, W(g->cat_emb), W(g->box_w),
-                       W(g->box_b), W(g->score_w), W(g->score_b), sc.red, s, ragged ? ix.t_orig : nullptr));
+                       W(g->box_b), W(g->score_w), W(g->score_b), RED(sc), s, ragged ? ix.t_orig : nullptr));
+  TRY(stlt_reduce_defer_flush(sc.defer));
   return dw_side_join(&side, s);
 }
 

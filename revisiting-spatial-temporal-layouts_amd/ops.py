@@ -552,6 +552,21 @@ def grad_targets(ws, needs):
     return targets, returned
 
 
+_NO_MASK = {}
+
+
+def _no_mask(S: int, Lk: int, device) -> torch.Tensor:
+    """The all-zeros key-padding mask of a block call without a mask: one cached tensor per (device, shape) instead of a fill kernel per
+    call (16 per CACNF step).  Read-only: the kernels never write a mask."""
+    key = (device, S, Lk)
+    t = _NO_MASK.get(key)
+    if t is None:
+        if len(_NO_MASK) > 64:
+            _NO_MASK.clear()
+        _NO_MASK[key] = t = torch.zeros(S, Lk, dtype=torch.uint8, device=device)
+    return t
+
+
 class AttnBlockFn(torch.autograd.Function):
     """One residual attention block as ONE native call each way (include/stlt_hip.h: stlt_attn_block_fwd_train / _bwd_train):
     LN_eps(x + drop(MHA(x, c, c) Woᵀ + bo)) — SelfAttentionLayer / CrossAttentionLayer of the fusion models (models.py:345-382)
@@ -565,7 +580,7 @@ class AttnBlockFn(torch.autograd.Function):
         if c is not None:
             c = _chk(c.contiguous(), torch.float32, "c")
         Lk = Lq if c is None else c.shape[1]
-        kpm8 = torch.zeros(S, Lk, dtype=torch.uint8, device=x.device) if kpm is None else _mask_u8(kpm.contiguous(), "kpm")
+        kpm8 = _no_mask(S, Lk, x.device) if kpm is None else _mask_u8(kpm.contiguous(), "kpm")
         q = torch.empty(S * Lq, (3 if c is None else 1) * d, device=x.device, dtype=torch.float32)
         kv = None if c is None else torch.empty(S * Lk, 2 * d, device=x.device, dtype=torch.float32)
         att, a, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
