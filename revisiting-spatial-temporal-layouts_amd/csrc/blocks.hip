@@ -204,8 +204,16 @@ int stlt_ffn_block_bwd_train(const stlt_ffn_block_params* p, const stlt_ffn_bloc
   float* df = dr.thr ? sc.da : sc.ds;
   TRY(launch_ln_bwd(dy, d, x, d, f, d, p->ln_w, eps, M, d, sc.ds, d, G(g->ln_w), G(g->ln_b), defer.chunk(sc), s, dr, site0 + 1, sc.da, 0, G(g->lin2_b)));
   DwList dws;
-  TRY(linear_bwd(h, p->lin2_w, df, M, d, 4 * d, sc.dh, nullptr, G(g->lin2_w), nullptr, dws, sc, s));  // dh = df·W2 ; lin2_w += dfᵀ·h
-  if (act == STLT_ACT_GELU) {
+  bool gelu_fused = false;
+  if (act == STLT_ACT_GELU && g->lin1_b && (size_t)((M + 255) / 256 * 16 * 4 * d) <= sc.red_floats) {
+    // du = drop(df·W2) ∘ gelu'(u) in the dX product's epilogue + the bias column sums (train.hip's fused form); lin2_w += dfᵀ·h queued
+    StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
+    TRY(stlt_ffn_hidden_backward_fused(df, p->lin2_w, u, sc.dh, M, d, G(g->lin1_b), defer.chunk(sc), inner, site0, s, &gelu_fused));
+    if (gelu_fused) dws.add(df, d, h, 4 * d, M, G(g->lin2_w));
+  }
+  if (!gelu_fused) TRY(linear_bwd(h, p->lin2_w, df, M, d, 4 * d, sc.dh, nullptr, G(g->lin2_w), nullptr, dws, sc, s));  // dh = df·W2 ; lin2_w += dfᵀ·h
+  if (gelu_fused) {
+  } else if (act == STLT_ACT_GELU) {
     if (g->lin1_b) TRY(launch_gelu_bwd_colsum(sc.dh, u, sc.dh, M, 4 * d, G(g->lin1_b), defer.chunk(sc), s, inner, site0));
     else TRY(launch_gelu_bwd(sc.dh, u, sc.dh, M * 4 * d, s, inner, site0));
   } else {

@@ -282,6 +282,8 @@ int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop
                     const int* drop_rows = nullptr, int64_t ncols = 0);
 int launch_gelu_bwd(const float* dh, const float* u, float* du, int64_t n, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull},
                     uint32_t site = 0, const int* drop_rows = nullptr, int64_t ncols = 0);
+int stlt_ffn_hidden_backward_fused(const float* df, const float* lin2_w, const float* u, float* du, int64_t rows, int64_t d, float* g_lin1_b,
+                                   float* cs_part, StltDrop dr, uint32_t site, hipStream_t s, bool* taken);  // train.hip
 int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
                            hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0, const int* drop_rows = nullptr);  // scratch >= 512*N floats
 // ragged attention backward: groups of whole segments (rows [grp_ptr[g], grp_ptr[g+1]), at most max_rows <= 64 each)

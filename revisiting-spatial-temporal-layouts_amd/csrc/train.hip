@@ -262,6 +262,23 @@ static int weight_grad_all(const StltWeightGradItem* items, int n, const Scratch
 // derivative, the dropout mask and the column sums ride in the product's epilogue / fix-up (gemm.hip: STLT_ACT_GELU_BWD) and
 // one reduction finishes the bias gradient; STLT_FUSE_GELU_BWD=0 keeps the stand-alone pass behind the product (A/B runs).
 static int ffn_hidden_backward(const float* df, const float* lin2_w, const float* u, float* du, int64_t rows, int64_t d, float* g_lin1_b,
+                               const Scratch& sc, StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s);
+}  // namespace
+// The same for the block-level training calls (blocks.hip): du = drop(df·W2) ∘ gelu'(u) in the dX product's epilogue, lin1_b += colsum(du)
+// through `cs_part` (>= ceil(rows / 256) * 16 * 4d floats; with deferred reductions a chunk of the caller's pool).  Needs lent stream-K
+// scratch on the calling thread like every under-filled product; *taken = false when the fused form does not apply.
+int stlt_ffn_hidden_backward_fused(const float* df, const float* lin2_w, const float* u, float* du, int64_t rows, int64_t d, float* g_lin1_b,
+                                   float* cs_part, StltDrop dr, uint32_t site, hipStream_t s, bool* taken) {
+  static const bool fused = [] { const char* e = getenv("STLT_FUSE_GELU_BWD"); return e ? atoi(e) != 0 : true; }();
+  *taken = false;
+  if (!fused || !g_lin1_b || !cs_part || stlt_split_bf16_takes(rows, 4 * d, d, d, d)) return 0;
+  *taken = true;
+  const StltGemmEpi epi{dr, site, nullptr, cs_part};
+  if (int e = launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi)) return e;
+  return launch_reduce_slabs(cs_part, 4 * d, (int)((rows + 255) / 256 * 16), g_lin1_b, 4 * d, 1, s);
+}
+namespace {
+static int ffn_hidden_backward(const float* df, const float* lin2_w, const float* u, float* du, int64_t rows, int64_t d, float* g_lin1_b,
                                const Scratch& sc, StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s) {
   static const bool fused = [] { const char* e = getenv("STLT_FUSE_GELU_BWD"); return e ? atoi(e) != 0 : true; }();
   if (fused && g_lin1_b && !(sc.sk && stlt_split_bf16_takes(rows, 4 * d, d, d, d))) {  // (the split-bf16 product has no GELU-backward epilogue)
