@@ -10,6 +10,7 @@
 //   layer math:  qkv = x·Winᵀ+b ; ctx = attn(qkv) ; a = ctx·Woᵀ+bo ; x1 = LN1(x+a) ; u = x1·W1ᵀ+b1 ; h = gelu(u) ;
 //                f = h·W2ᵀ+b2 ; y = LN2(x1+f)   (y is the next layer's x)
 #include <cstdlib>
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -151,6 +152,8 @@ static DwSide dw_side_open(const Scratch& sc) {
   DwSide sd;
   if (!dw_side_wanted() || !sc.sk2) return sd;
   DwSideDevice& dv = g_dw_side[stlt_current_device() & (STLT_MAX_DEVICES - 1)];
+  static std::mutex mu;  // one creation per device, whichever thread's sweep comes first
+  std::lock_guard<std::mutex> lk(mu);
   if (!dv.tried) {
     dv.tried = true;
     int lo = 0, hi = 0;
