@@ -52,7 +52,9 @@ def test_side_legs_ride_on_the_default_line():
     sb_t = j["small_batch"]["roofline_attn_temporal"]
     assert sb_t["launches_per_step"] > 0 and sb_t["frac"] > 0, sb_t
     # 256 clips (this run's main line): the fused kernel, with the core alone still reported against HBM
-    assert j["roofline_mhsa_fused"]["frac"] > 0 and j["roofline_attn_temporal"]["frac"] > 0
+    assert j["roofline_attn_temporal"]["frac"] > 0
+    if os.environ.get("STLT_FUSED_MHSA") != "0":  # (a suite run with the fused kernel switched off keeps the two launches)
+        assert j["roofline_mhsa_fused"]["frac"] > 0
     # the dense schedule beside `value` (how much of the headline is the exact elision of unread rows)
     ds = j["dense_schedule"]
     assert "error" not in ds and 0 < ds["value"] < j["value"] * 1.02 and ds["logit_max_abs_diff_vs_value_schedule"] <= 1e-5 and 0 < ds["roofline"]["frac"] < 1, ds

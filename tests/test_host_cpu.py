@@ -85,6 +85,8 @@ def test_launch_time_dispatch_is_host_arithmetic(pkg):
     """The two launch-time choices of round 4 are pure host arithmetic over (shape, CU count) and can be pinned without a GPU (256 CUs
     are assumed when no device answers): which products go to the small-tile kernel (csrc/gemm16.hip) and which layers run the fused
     in-projection + attention kernel (csrc/mhsa.hip) instead of the two launches."""
+    if os.environ.get("STLT_GEMM16") == "0" or os.environ.get("STLT_FUSED_MHSA") == "0":
+        pytest.skip("dispatch switched off in the environment")
     lib = pkg._lib.load()
     # 64-clip batches of cfg2 (M = 2048): whole small tiles of 48 / 144 / 192 columns = 256 tiles; bench-sized launches stay on 256 x 128
     assert lib.stlt_linear_small_choice(2048, 768, 768) == 48

@@ -66,6 +66,11 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o o -- python3 $R/tools/bench_caf.py --train --batch 64 --steps 4 --warmup 2 > /dev/null 2>&1
 python3 $R/tools/step_trace.py $(find /tmp/pc -name '*kernel_trace.csv' | head -1) --marker sumsq_kernel --summary > $O/round4_caf_train_step_timeline_b64.txt
 cd $R
+# 10. the GPU suite on this box: default, with the opt-in split-bf16 products exported, and with the round-4 dispatches off
+python -m pytest tests -q -m gpu > $O/round4_pytest_gpu.log 2>&1
+STLT_GEMM_SPLIT_BF16=6 python -m pytest tests -q -m gpu > $O/round4_pytest_gpu_split_bf16_on.log 2>&1
+STLT_FUSED_MHSA=0 STLT_GEMM16=0 STLT_TRAIN_DW_STREAM=0 STLT_TRAIN_DEFER_REDUCE=0 python -m pytest tests -q -m gpu > $O/round4_pytest_gpu_fused_off.log 2>&1
+tail -2 $O/round4_pytest_gpu.log $O/round4_pytest_gpu_split_bf16_on.log $O/round4_pytest_gpu_fused_off.log
 tail -1 $O/round4_bench_b1024.json | cut -c1-300
 tail -1 $O/round4_bench_train_b64.json | cut -c1-300
 head -8 $O/round4_kernel_stats_b1024.csv | cut -c1-200
