@@ -210,6 +210,7 @@ struct StltReduceDefer {
   hipStream_t s = nullptr;
   float* pool = nullptr;
   size_t pool_floats = 0, used = 0;
+  int err = 0;  // first error of a flush made on the way (pool wrap): returned by the next explicit flush
 };
 void stlt_reduce_defer_set(StltReduceDefer* d);  // nullptr: off
 int stlt_reduce_defer_flush(StltReduceDefer* d);

@@ -1009,7 +1009,8 @@ thread_local StltReduceDefer* t_reduce_defer = nullptr;
 void stlt_reduce_defer_set(StltReduceDefer* d) { t_reduce_defer = d; }
 
 int stlt_reduce_defer_flush(StltReduceDefer* d) {
-  if (!d || d->n == 0) return 0;
+  if (!d) return 0;
+  if (d->n == 0) { const int e = d->err; d->err = 0; return e; }
   ReduceBatch b;
   int blocks = 0;
   for (int i = 0; i < d->n; ++i) {
@@ -1022,7 +1023,9 @@ int stlt_reduce_defer_flush(StltReduceDefer* d) {
   d->n = 0;
   StltProfScope ps(STLT_K_MISC, d->s);
   hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, d->s, b);
-  return stlt_check_launch("reduce_batch_kernel");
+  int e = stlt_check_launch("reduce_batch_kernel");
+  if (!e) { e = d->err; d->err = 0; }
+  return e;
 }
 
 // next chunk of the pool for a producer's partial rows; a full pool first flushes the entries that still read it
@@ -1032,6 +1035,7 @@ float* stlt_reduce_defer_chunk(StltReduceDefer* d, size_t floats, float* fallbac
   floats = (floats + 63) / 64 * 64;
   if (d->used + floats > d->pool_floats) {
     *err = stlt_reduce_defer_flush(d);
+    if (*err && !d->err) d->err = *err;  // callers that cannot return it (pointer-valued helpers) see it at their final flush
     d->used = 0;
   }
   float* p = d->pool + d->used;

@@ -395,10 +395,13 @@ static int launch_mhsa16_as(const Mhsa16Args& a, hipStream_t s) {
   Mhsa16Args b = a;
   // head sets per XCD group (see the kernel): only for launches of several rounds on a full grid of 8 x n workgroups.  Measured at
   // 1024 clips of 32 frames (profiles/round4_mhsa_head_sets.txt): memory-side traffic per launch 907 MB (1 set) -> 668 MB (2 sets) ->
-  // 699 MB (4 sets) at equal speed (930 / 926 / 930 us); the spatial launches (7 objects: 9.4 GB per launch with one set against
-  // 1.4 GB algorithmic) measure 6353 / 6373 / 6715 us with 1 / 2 / 4 sets.  Both towers use 2.  STLT_MHSA_HEAD_SETS=1|2|4 forces a value.
+  // 699 MB (4 sets) at equal speed (930 / 926 / 930 us) -> 2 sets.  The spatial launches (7 objects, 85 rounds of items) keep 1 set: with
+  // 2 sets their traffic went UP, 9.4 -> 11.5 GB per launch (1.4 GB algorithmic: six heads' weight slices still do not fit the L2 beside
+  // the X stream, and X is then fetched twice), and the launch from 6276 to 6376 us; 4 sets: 6715 us.  The re-fetched bytes are the 7 MB
+  // of weights, served by the Infinity Cache (9.4 GB in 6.3 ms = 1.5 TB/s); the kernel stays MFMA-bound at 0.83.
+  // STLT_MHSA_HEAD_SETS=1|2|4 forces a value for both towers (A/B runs).
   static const int env_sets = [] { const char* e = getenv("STLT_MHSA_HEAD_SETS"); return e ? atoi(e) : 0; }();
-  const int want_sets = env_sets ? env_sets : 2;
+  const int want_sets = env_sets ? env_sets : (CAUSAL ? 2 : 1);
   b.head_sets = 1;
   if ((want_sets == 2 || want_sets == 4) && (G & 7) == 0 && a.H % want_sets == 0 && n_items >= 4 * G && a.n_groups >= 8) b.head_sets = want_sets;
   hipLaunchKernelGGL((mhsa16_kernel<NKB, CAUSAL, TRAIN>), dim3((unsigned)G), dim3(F_THREADS), G_SMEM * sizeof(float), s, b);
