@@ -395,6 +395,7 @@ int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ld
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)((M + QM - 1) / QM);
   a.tiles_n = (int)((N + 16 * nt - 1) / (16 * nt));
+  if ((int64_t)a.tiles_m * a.tiles_n > 0x3fffffffLL) return stlt_set_error(STLT_EINVAL, "gemm16: too many tiles");
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
   *taken = true;
@@ -420,6 +421,7 @@ int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int
   a.M = (int)rows; a.N = (int)k_in; a.K = (int)n_out;
   a.tiles_m = (int)((rows + QM - 1) / QM);
   a.tiles_n = (int)((k_in + 16 * nt - 1) / (16 * nt));
+  if ((int64_t)a.tiles_m * a.tiles_n > 0x3fffffffLL) return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): too many tiles");
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)rows * (double)k_in * (double)n_out);
   *taken = true;

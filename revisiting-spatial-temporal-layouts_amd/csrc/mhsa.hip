@@ -462,7 +462,8 @@ int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, cons
     return stlt_set_error(STLT_EINVAL, "mhsa_fused: sequences of 1..64 tokens and 64-channel heads (L=%lld, d=%lld, H=%lld, causal=%d)", (long long)L,
                           (long long)d, (long long)H, causal);
   if (S <= 0) return 0;
-  if (S * L * 3 * d > 0x7fffffffLL * 4 || S * L > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "mhsa_fused: batch too large");
+  if (S * L * 3 * d > 0x7fffffffLL * 4 || S * L > 0x7fffff00LL || (S / (FM / L) + 1) * H > 0x3fffffffLL)
+    return stlt_set_error(STLT_EINVAL, "mhsa_fused: batch too large");
   StltProfScope ps(causal ? STLT_K_MHSA_FUSED : STLT_K_MHSA_FUSED_SPATIAL, s);
   Mhsa16Args a;
   a.X = x; a.Win = w_in; a.bin = b_in; a.kpm = kpm; a.ctx = ctx; a.qkv = qkv_out;
