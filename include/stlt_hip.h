@@ -55,12 +55,15 @@ int stlt_embed_fwd(const int64_t* categories, const float* boxes, const float* s
 /* K2/K4/K5/K6/K8 — nn.Linear (F.linear inside F.multi_head_attention_forward, linear1/linear2 of
  * nn.TransformerEncoderLayer as configured at models.py:46-52,118-124; fc1/fc2 models.py:158-163).
  * y[m, n] = act( sum_k x[m*ldx + k] * w[n*K + k] + bias[n] ),  w is (N,K) row-major (torch (out,in)).
- * K % 32 == 0; M, N arbitrary.  f32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate. */
+ * M, N arbitrary.  K % 32 == 0 (every hidden size the released checkpoints use): f32-input MFMA (v_mfma_f32_32x32x2_f32), fp32
+ * accumulate.  Any other K (hidden sizes like 100 or 200, which configs.py:92-111 allows): the same product and epilogues on the
+ * vector ALU (csrc/gemm_any.hip) — a compatibility path with the same tolerances, not a tuned one. */
 int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias,
                     float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, stlt_stream_t stream);
 
 /* General product on the same kernel, used by the backward pass of nn.Linear (autograd of F.linear in the reference):
- *   c (M,N) = opA(a)·opB(b) [+ r]   with contraction length K (multiple of 32)
+ *   c (M,N) = opA(a)·opB(b) [+ r]   with contraction length K (a multiple of 32 for the MFMA kernel; any other K runs on the vector
+ *                                   ALU, n_split = 1 only)
  *   transA=0: a is (M,K) row-major, lda;  transA=1: a is (K,M) row-major, lda   (dW = dY^T·X)
  *   transB=0: b is (N,K) row-major, ldb;  transB=1: b is (K,N) row-major, ldb   (dX = dY·W)
  * r (nullable, ldr) is added in the epilogue (residual gradient).  n_split > 1 splits the contraction: split s writes
@@ -115,7 +118,9 @@ int stlt_reduce_slabs(const float* slabs, int64_t stride, int n_slabs, float* ds
  * key-padding mask) and models.py:146-150 (temporal, causal mask of utils/model_utils.py:4-7 + key padding).
  * qkv: (S*L, 3*H*dh) packed rows [q;k;v]; ctx: (S*L, H*dh).  kpm: (S*L) bytes, 1 = key masked.
  * ctx[s,i,h,:] = softmax_j( q_i·k_j/sqrt(dh) + M_ij ) v_j with M_ij = -inf if kpm[s,j] or (causal and j>i).
- * Rows whose keys are all masked produce zeros.  dh == 64. */
+ * Rows whose keys are all masked produce zeros.  1 <= dh <= 256: dh == 64 (every released checkpoint) runs on the MFMA kernels; any
+ * other head dim the reference's configs.py:92-111 allows runs on the vector-ALU kernels of csrc/attn_any.hip (at most 1024 keys per
+ * sequence in the forward, 256 tokens a side in the backward) — the same arithmetic, masks, dropout indices and tolerances. */
 int stlt_attn_core_fwd(const float* qkv, const uint8_t* kpm, int causal,
                        int64_t S, int64_t L, int64_t H, int64_t dh, float* ctx, stlt_stream_t stream);
 

@@ -328,8 +328,8 @@ static int encoder_layer(const stlt_layer_params& lp, int64_t d, int64_t H, cons
 
 static int check_params(const stlt_params* p, const stlt_inputs* in, bool need_head) {
   if (!p || !in) return stlt_set_error(STLT_EINVAL, "null params/inputs");
-  if (p->d <= 0 || p->H <= 0 || p->d % p->H != 0 || p->d / p->H != 64)
-    return stlt_set_error(STLT_EINVAL, "hidden_size %lld / heads %lld: head dim must be 64", (long long)p->d, (long long)p->H);
+  if (!stlt_heads_ok(p->d, p->H))
+    return stlt_set_error(STLT_EINVAL, "hidden_size %lld / heads %lld: need hidden_size %% heads == 0, a head dim of at most 256 and hidden_size %% 4 == 0", (long long)p->d, (long long)p->H);
   if (in->B <= 0 || in->T <= 0 || in->N <= 0) return stlt_set_error(STLT_EINVAL, "empty batch (B=%lld,T=%lld,N=%lld)", (long long)in->B, (long long)in->T, (long long)in->N);
   if (in->T > p->n_positions) return stlt_set_error(STLT_EINVAL, "T=%lld exceeds the position table (%lld rows)", (long long)in->T, (long long)p->n_positions);
   if (!in->categories || !in->boxes || !in->kpm_boxes || !in->frame_types || !in->kpm_frames)

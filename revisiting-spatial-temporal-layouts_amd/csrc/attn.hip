@@ -344,7 +344,11 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
                         int causal, int64_t S, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx, int kid,
                         hipStream_t s, StltDrop dr, uint32_t site) {
   if (!q || !k || !v || !kpm || !ctx) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: null pointer");
-  if (dh != DH) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: head dim %lld unsupported (kernel is built for dh=64)", (long long)dh);
+  if (dh != DH) {  // any other head dim: the vector-ALU kernels of attn_any.hip
+    if (causal && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: causal masking needs Lq == Lk");
+    StltProfScope ps(kid, s);
+    return launch_attn_any_fwd(q, ldq, k, v, ldkv, kpm, nullptr, nullptr, causal, S * Lq, Lq, Lk, H, dh, ctx, s, dr, site);
+  }
   if (dr.thr && Lk > 256) return stlt_set_error(STLT_EINVAL, "attention dropout supports sequences of at most 256 tokens");
   if (Lq <= 0 || Lk <= 0 || Lq > 32768 || Lk > 32768 || H <= 0 || H > 65535) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: bad L/H");
   if (causal && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: causal masking needs Lq == Lk");
@@ -409,7 +413,11 @@ int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int
 int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_end, int causal, int64_t M, int64_t H, int64_t dh,
                        float* ctx, int kid, hipStream_t s, StltDrop dr, uint32_t site) {
   if (!qkv || !seg_start || !seg_end || !ctx) return stlt_set_error(STLT_EINVAL, "attn_ragged: null pointer");
-  if (dh != DH) return stlt_set_error(STLT_EINVAL, "attn_ragged: head dim %lld unsupported (kernel is built for dh=64)", (long long)dh);
+  if (dh != DH) {
+    StltProfScope ps(kid, s);
+    const int64_t d = H * dh;
+    return launch_attn_any_fwd(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, nullptr, seg_start, seg_end, causal, M, 256, 256, H, dh, ctx, s, dr, site);  // segments: frames / clips, at most the position table's 256 rows
+  }
   if (H <= 0 || H > 65535 || M < 0 || M > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "attn_ragged: bad M/H");
   if (M == 0) return 0;
   const int64_t d = H * dh;

@@ -797,10 +797,20 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
                     const AttnBwdRagged* rg) {
   StltProfScope ps(STLT_K_ATTN_BWD, s);
   if (!qkv || !dctx || (!kpm && !rg) || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
-  if (dh != AB_DH) return stlt_set_error(STLT_EINVAL, "attn_bwd: head dim must be 64");
   if (L <= 0 || L > AB_LONG_MAXL)
     return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld)", AB_LONG_MAXL, (long long)L);
   if (S == 0) return 0;
+  if (dh != AB_DH) {  // any other head dim: attn_any.hip, then the in-projection bias gradient as column sums of dqkv
+    const int64_t d = H * dh;
+    if (rg && rg->n_groups == 0) return 0;
+    if (int e = launch_attn_any_bwd(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, dctx, kpm, rg ? rg->grp_ptr : nullptr, rg ? rg->seg_start : nullptr,
+                                    rg ? rg->seg_end : nullptr, rg ? rg->max_rows : 0, causal, rg ? rg->n_groups : S, L, L, H, dh, dqkv, 3 * d,
+                                    dqkv + d, dqkv + 2 * d, 3 * d, s, dr, site))
+      return e;
+    if (!g_colsum) return 0;
+    if (!scratch) return stlt_set_error(STLT_EINVAL, "attn_bwd: column sums need scratch");
+    return launch_colsum_acc(dqkv, 3 * d, rg ? rg->n_rows : S * L, 3 * d, g_colsum, scratch, s);
+  }
   if (L > AB_MAXL) {  // long sequences: one block per (sequence, head), keys streamed in tiles
     const int64_t n_seq = rg ? rg->n_groups : S;
     if (rg && rg->max_rows > AB_LONG_MAXL) return stlt_set_error(STLT_EINVAL, "attn_bwd: group of %d rows unsupported", rg->max_rows);

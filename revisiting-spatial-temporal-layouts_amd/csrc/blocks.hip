@@ -113,7 +113,7 @@ int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_
   if (!p || !x || !kpm || !q || !ctx || !a || !out || (c && !kv)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_fwd_train: null argument");
   if (gemm_scratch && gemm_scratch_bytes < STLT_GEMM_SCRATCH_BYTES) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_block_fwd_train: gemm scratch too small");
   StltGemmScratch lend(gemm_scratch, STLT_GEMM_SCRATCH_BYTES);  // under-filled products run as stream-K when scratch is lent
-  if (d <= 0 || H <= 0 || d != H * 64) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_fwd_train: head dim must be 64");
+  if (!stlt_heads_ok(d, H)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_fwd_train: need d %% H == 0, a head dim of at most 256 and d %% 4 == 0");
   if (!(drop_p >= 0.f && drop_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
   if (!c && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_fwd_train: self-attention needs Lq == Lk");
   hipStream_t s = (hipStream_t)stream;
@@ -122,11 +122,11 @@ int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_
   const int kid = causal ? STLT_K_ATTN_TEMPORAL : STLT_K_ATTN_SPATIAL;
   if (!c) {  // packed q | k | v
     TRY(launch_linear(x, d, p->in_proj_w, p->in_proj_b, q, 3 * d, Mq, 3 * d, d, STLT_ACT_NONE, s));
-    TRY(launch_attn(q, kpm, causal, S, Lq, H, 64, ctx, kid, s, dr, site0));
+    TRY(launch_attn(q, kpm, causal, S, Lq, H, d / H, ctx, kid, s, dr, site0));
   } else {   // q from x, k | v from the other modality's tokens (models.py:362-382)
     TRY(launch_linear(x, d, p->in_proj_w, p->in_proj_b, q, d, Mq, d, d, STLT_ACT_NONE, s));
     TRY(launch_linear(c, d, p->in_proj_w + d * d, p->in_proj_b + d, kv, 2 * d, Mk, 2 * d, d, STLT_ACT_NONE, s));
-    TRY(launch_attn_general(q, d, kv, kv + d, 2 * d, kpm, causal, S, Lq, Lk, H, 64, ctx, kid, s, dr, site0));
+    TRY(launch_attn_general(q, d, kv, kv + d, 2 * d, kpm, causal, S, Lq, Lk, H, d / H, ctx, kid, s, dr, site0));
   }
   TRY(launch_linear(ctx, d, p->out_proj_w, p->out_proj_b, a, d, Mq, d, d, STLT_ACT_NONE, s));
   return launch_add_layernorm(a, d, x, d, p->ln_w, p->ln_b, eps, Mq, d, out, d, s, dr, site0 + 1);
@@ -139,7 +139,7 @@ int stlt_attn_block_bwd_train(const stlt_attn_block_params* p, const stlt_attn_b
                               uint32_t site0, const float* q, const float* kv, const float* ctx, const float* a, const float* dy, float* dx,
                               float* dc, void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
   if (!p || !g || !x || !kpm || !q || !ctx || !a || !dy || !dx || !scratch || (c && !kv)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: null argument");
-  if (d <= 0 || H <= 0 || d != H * 64) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: head dim must be 64");
+  if (!stlt_heads_ok(d, H)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: need d %% H == 0, a head dim of at most 256 and d %% 4 == 0");
   hipStream_t s = (hipStream_t)stream;
   const int64_t Mq = S * Lq, Mk = S * Lk;
   const BlockScratch sc = block_scratch((char*)scratch, Mq > Mk ? Mq : Mk, d);
@@ -155,12 +155,12 @@ int stlt_attn_block_bwd_train(const stlt_attn_block_params* p, const stlt_attn_b
   TRY(linear_bwd(ctx, p->out_proj_w, da, Mq, d, d, sc.dctx, nullptr, G(g->out_proj_w), nullptr, dws, sc, s));
   if (!c) {
     // packed self-attention: dqkv (Mq, 3d); in_proj_b += its column sums (accumulated by the attention backward)
-    TRY(launch_attn_bwd(q, sc.dctx, kpm, causal, S, Lq, H, 64, sc.dq, s, dr, site0, G(g->in_proj_b), defer.chunk(sc)));
+    TRY(launch_attn_bwd(q, sc.dctx, kpm, causal, S, Lq, H, d / H, sc.dq, s, dr, site0, G(g->in_proj_b), defer.chunk(sc)));
     TRY(linear_bwd(x, p->in_proj_w, sc.dq, Mq, 3 * d, d, dx, sc.ds, G(g->in_proj_w), nullptr, dws, sc, s));  // dx = dqkv·Win + ds
     TRY(defer.flush());
     return flush_dw(dws, sc, s);
   }
-  TRY(stlt_attn_bwd(q, d, kv, kv + d, 2 * d, sc.dctx, kpm, causal, S, Lq, Lk, H, 64, drop_p, seed, site0, sc.dq, d, sc.dkv, sc.dkv + d, 2 * d, stream));
+  TRY(stlt_attn_bwd(q, d, kv, kv + d, 2 * d, sc.dctx, kpm, causal, S, Lq, Lk, H, d / H, drop_p, seed, site0, sc.dq, d, sc.dkv, sc.dkv + d, 2 * d, stream));
   TRY(linear_bwd(x, p->in_proj_w, sc.dq, Mq, d, d, dx, sc.ds, G(g->in_proj_w), G(g->in_proj_b), dws, sc, s, &defer));  // dx = dq·Wq + ds
   TRY(linear_bwd(c, p->in_proj_w + d * d, sc.dkv, Mk, 2 * d, d, dc, nullptr, g->in_proj_w ? G(g->in_proj_w) + d * d : nullptr,
                  g->in_proj_b ? G(g->in_proj_b) + d : nullptr, dws, sc, s, &defer));

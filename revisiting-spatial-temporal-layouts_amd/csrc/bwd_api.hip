@@ -323,7 +323,11 @@ int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, i
                   float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv, stlt_stream_t stream) {
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
   if (!q || !k || !v || !dctx || !dq || !dk || !dv) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: null pointer");
-  if (dh != XB_DH) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: head dim must be 64");
+  if (dh != XB_DH) {  // any other head dim: attn_any.hip
+    StltProfScope ps(STLT_K_ATTN_BWD, (hipStream_t)stream);
+    return launch_attn_any_bwd(q, ldq, k, v, ldkv, dctx, kpm, nullptr, nullptr, nullptr, 0, causal, S, Lq, Lk, H, dh, dq, lddq, dk, dv, lddkv,
+                               (hipStream_t)stream, stlt_drop_make(dropout_p, seed), site);
+  }
   if (Lq <= 0 || Lk <= 0 || Lq > XB_LONG_MAXL || Lk > XB_LONG_MAXL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: sequences of at most %d tokens (got %lld / %lld)", XB_LONG_MAXL, (long long)Lq, (long long)Lk);
   if (causal && Lq != Lk) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: causal masking needs Lq == Lk");
   if (Lq > XB_MAXL || Lk > XB_MAXL) {  // streamed variant: query tiles of 32, keys in tiles through LDS
@@ -363,7 +367,7 @@ int stlt_attn_core_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, 
                        float dropout_p, uint64_t seed, uint32_t site, float* dqkv, float* in_proj_b_grad, void* scratch, size_t scratch_bytes,
                        stlt_stream_t stream) {
   if (!qkv || !dctx || !kpm || !dqkv) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_bwd: null pointer");
-  if (dh != 64 || H <= 0 || S < 0 || L <= 0) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_bwd: head dim must be 64");
+  if (dh < 1 || dh > 256 || H <= 0 || S < 0 || L <= 0) return stlt_set_error(STLT_EINVAL, "stlt_attn_core_bwd: bad shape (head dim 1 ... 256)");
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return stlt_set_error(STLT_EINVAL, "dropout probability must be in [0,1)");
   if (in_proj_b_grad && (!scratch || scratch_bytes < stlt_attn_core_bwd_scratch_bytes(H))) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_core_bwd: scratch too small");
   if (S == 0) return 0;

@@ -141,7 +141,7 @@ extern "C" int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_input
   const int64_t B = in->B, T = in->T, N = in->N, d = lp.d, H = lp.H, C = p->feat_channels, S = p->app_tokens, K = lp.n_classes;
   const float eps = lp.ln_eps;
   if (K <= 0 || !in->lengths || !p->fusion_head.fc1_w) return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: heads / lengths missing");
-  if (C % 32 != 0 || d % 64 != 0) return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: feat_channels must be a multiple of 32");
+  if (C % 4 != 0 || !stlt_heads_ok(d, H)) return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: feat_channels and hidden_size must be multiples of 4, hidden_size %% heads == 0, head dim <= 256");
   const bool cacnf = p->layout_head.fc1_w != nullptr;
   if (cacnf && (!p->appearance_head.fc1_w || !logits_stlt || !logits_resnet3d || !logits_ensemble))
     return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: CACNF needs both unimodal heads and all four outputs");

@@ -139,6 +139,9 @@ int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* 
 // tile row, every slot written — launch_reduce_slabs(cs_part, N, ceil(M/256)*16, g, N, 1) finishes them.
 constexpr int STLT_ACT_GELU_BWD = 3;
 struct StltGemmEpi { StltDrop dr; uint32_t site; const int* drop_rows; float* cs_part; };
+// gemm_any.hip: launch_gemm's fallback for contraction lengths that are not multiples of 32 (vector ALU, same layouts and epilogues)
+int launch_gemm_any(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, const float* r,
+                    int64_t ldr, float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t s);
 // gemm_bf16x3.hip: the forward product on the BF16 matrix cores with three-piece operands (opt-in); *taken = launched
 float* stlt_gemm_scratch_ptr(size_t* bytes);  // gemm.hip: the calling thread's lent stream-K scratch (nullptr: none)
 bool stlt_split_bf16_takes(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw);  // would it (switched on, shape fits)?
@@ -268,6 +271,17 @@ RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N);
 int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, const int64_t* lengths, int64_t B, int64_t T,
                         int64_t N, const RaggedIndex& idx, hipStream_t s);
 int launch_gather_rows(const float* src, int64_t ld, const int* rows, int64_t n, int64_t d, float* out, hipStream_t s);
+// hidden size / head count a model or block may have: any head dim up to 256 (64: the MFMA kernels; others: attn_any.hip); rows are
+// moved 16 bytes at a time (hidden sizes that are not multiples of 32 run their products on gemm_any.hip)
+inline bool stlt_heads_ok(int64_t d, int64_t H) { return d > 0 && H > 0 && d % H == 0 && d / H <= 256 && d % 4 == 0; }
+// attn_any.hip: the same attention for head dims other than 64 (vector ALU; forward <= 1024 keys, backward <= 256 tokens a side)
+int launch_attn_any_fwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kpm, const int* seg_start,
+                        const int* seg_end, int causal, int64_t n_q, int64_t Lq, int64_t Lk, int64_t H, int64_t dh, float* ctx, hipStream_t s,
+                        StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
+int launch_attn_any_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dctx, const uint8_t* kpm,
+                        const int* grp_ptr, const int* seg_start, const int* seg_end, int max_rows, int causal, int64_t n_groups, int64_t Lq,
+                        int64_t Lk, int64_t H, int64_t dh, float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv, hipStream_t s,
+                        StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_end, int causal, int64_t M, int64_t H, int64_t dh,
                        float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 

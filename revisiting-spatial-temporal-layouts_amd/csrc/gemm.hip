@@ -1147,8 +1147,13 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
     if (!epi_in || !epi.cs_part || !r || transA || !transB || n_split != 1 || bias)
       return stlt_set_error(STLT_EINVAL, "gemm: the fused GELU backward is the dX layout with u as the add-source and a column-sum buffer");
   }
-  if (M < 0 || N <= 0 || K <= 0 || K % BK != 0)
-    return stlt_set_error(STLT_EINVAL, "gemm: contraction length K=%lld must be a positive multiple of %d (N=%lld)", (long long)K, BK, (long long)N);
+  if (M < 0 || N <= 0 || K <= 0) return stlt_set_error(STLT_EINVAL, "gemm: bad shape (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+  if (K % BK != 0 || lda % 4 != 0 || ldb % 4 != 0) {  // a partial k-slab / rows that are not 16-byte aligned cannot be staged by LDS-DMA:
+    // the vector-ALU kernel of gemm_any.hip (hidden sizes that are not multiples of 32)
+    if (n_split != 1 || act == STLT_ACT_GELU_BWD)
+      return stlt_set_error(STLT_EINVAL, "gemm: a split product / the fused GELU backward needs K=%lld to be a multiple of %d and pitches that are multiples of 4", (long long)K, BK);
+    return launch_gemm_any(transA, transB, a, lda, b, ldb, bias, r, ldr, c, ldc, M, N, K, act, s);
+  }
   if (lda % 4 != 0 || ldb % 4 != 0 || (r && ldr < N) || ldc < N || lda < (transA ? M : K) || ldb < (transB ? N : K))
     return stlt_set_error(STLT_EINVAL, "gemm: bad leading dimension (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
   if (M > 0x7fffff00LL || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gemm: M/N too large");

@@ -274,7 +274,7 @@ int stlt_ffn_hidden_backward_fused(const float* df, const float* lin2_w, const f
                                    float* cs_part, StltDrop dr, uint32_t site, hipStream_t s, bool* taken) {
   static const bool fused = [] { const char* e = getenv("STLT_FUSE_GELU_BWD"); return e ? atoi(e) != 0 : true; }();
   *taken = false;
-  if (!fused || !g_lin1_b || !cs_part || stlt_split_bf16_takes(rows, 4 * d, d, d, d)) return 0;
+  if (!fused || !g_lin1_b || !cs_part || d % 32 != 0 || stlt_split_bf16_takes(rows, 4 * d, d, d, d)) return 0;
   *taken = true;
   const StltGemmEpi epi{dr, site, nullptr, cs_part};
   if (int e = launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi)) return e;
@@ -284,7 +284,7 @@ namespace {
 static int ffn_hidden_backward(const float* df, const float* lin2_w, const float* u, float* du, int64_t rows, int64_t d, float* g_lin1_b,
                                const Scratch& sc, StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s) {
   static const bool fused = [] { const char* e = getenv("STLT_FUSE_GELU_BWD"); return e ? atoi(e) != 0 : true; }();
-  if (fused && g_lin1_b && !(sc.sk && stlt_split_bf16_takes(rows, 4 * d, d, d, d))) {  // (the split-bf16 product has no GELU-backward epilogue)
+  if (fused && g_lin1_b && d % 32 == 0 && !(sc.sk && stlt_split_bf16_takes(rows, 4 * d, d, d, d))) {  // (the split-bf16 product has no GELU-backward epilogue)
     float* cs = RED(sc);
     const StltGemmEpi epi{dr, site, drop_rows, cs};
     TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi));
@@ -479,7 +479,8 @@ static int layer_backward_tail(const stlt_layer_params& lp, const stlt_layer_par
 
 static int check_train(const stlt_params* p, const stlt_inputs* in, bool need_head = true) {
   if (!p || !in) return stlt_set_error(STLT_EINVAL, "null params/inputs");
-  if (p->d <= 0 || p->H <= 0 || p->d % p->H != 0 || p->d / p->H != 64) return stlt_set_error(STLT_EINVAL, "head dim must be 64");
+  if (!stlt_heads_ok(p->d, p->H))
+    return stlt_set_error(STLT_EINVAL, "hidden_size %lld / heads %lld: need hidden_size %% heads == 0, a head dim of at most 256 and hidden_size %% 4 == 0", (long long)p->d, (long long)p->H);
   if (p->n_spatial < 0 || p->n_spatial > 64 || p->n_temporal < 0 || p->n_temporal > 64) return stlt_set_error(STLT_EINVAL, "layer count out of range");
   if (in->B <= 0 || in->T <= 0 || in->N <= 0 || in->T > p->n_positions) return stlt_set_error(STLT_EINVAL, "bad batch shape");
   if (!in->categories || !in->boxes || !in->kpm_boxes || !in->frame_types || !in->kpm_frames || !in->lengths)

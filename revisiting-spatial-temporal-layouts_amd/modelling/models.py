@@ -294,7 +294,7 @@ class StltBackbone(nn.Module):
         """(B,T,d) backbone output with an autograd graph: what a model that consumes EVERY row of the backbone (the fusion
         models) trains through.  `Stlt` itself trains through the single native reverse sweep instead (`_StltTrainFn`).
         Layouts of at most 256 frames / 256 object slots (the op-level attention backward streams keys above 64)."""
-        if not self.skip_padding and self.config.hidden_size == 64 * self.config.num_attention_heads and "lengths" in batch:
+        if not self.skip_padding and "lengths" in batch:
             # one native tape forward / reverse sweep (csrc/train.hip with STLT_FLAG_TRAIN_BACKBONE): the last spatial layer
             # runs its out-proj / norms / FFN on the CLS rows only, weight gradients go out layer by layer in grouped launches
             return _BackboneTrainFn.apply(self, batch, *tuple(self.parameters()))

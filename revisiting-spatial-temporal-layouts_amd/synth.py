@@ -193,6 +193,12 @@ CONFIGS = {
     # the reference's defaults: layout_num_frames 16 (+ 1 extract frame), 4 object slots (+ CLS) — utils/parser.py:62-66, datasets.py:97-113
     "refdef": dict(T=17, N=5, hidden_size=768, num_attention_heads=12, num_spatial_layers=4, num_temporal_layers=8,
                    num_classes=174, dataset="something"),
+    # a head dim other than 64 (96): the reference takes any hidden_size % num_attention_heads == 0 (configs.py:92-111)
+    "heads": dict(T=9, N=6, hidden_size=384, num_attention_heads=4, num_spatial_layers=2, num_temporal_layers=3,
+                  num_classes=174, dataset="something"),
+    # a hidden size that is not a multiple of 32 (head dim 25)
+    "odd": dict(T=7, N=4, hidden_size=100, num_attention_heads=4, num_spatial_layers=2, num_temporal_layers=2,
+                num_classes=174, dataset="something"),
     "cfg4": dict(T=64, N=36, hidden_size=768, num_attention_heads=12, num_spatial_layers=4, num_temporal_layers=8,
                  num_classes=157, dataset="action_genome"),
 }

@@ -1,0 +1,367 @@
+"""Head dims other than 64 (csrc/attn_any.hip).  The reference builds nn.MultiheadAttention for any hidden_size % num_attention_heads == 0
+(src/modelling/configs.py:92-111); these tests hold the vector-ALU attention kernels — forward, backward, cross, ragged, dropout — and the
+models built on them to the same oracle and the same tolerances as the dh = 64 kernels."""
+import importlib
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import stlt_oracle as O  # noqa: E402
+from conftest import golden_case  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("revisiting-spatial-temporal-layouts_amd")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _softmax_attention(q, k, v, H, kpm=None, causal=False, drop=None):
+    """fp64 reference on (S, L, d) operands; fully masked rows -> zeros; drop: (S, H, Lq, Lk) multiplicative mask."""
+    S, Lq, d = q.shape
+    Lk, dh = k.shape[1], d // H
+    sp = lambda t, Lx: t.reshape(S, Lx, H, dh).transpose(1, 2)
+    sc = sp(q, Lq) @ sp(k, Lk).transpose(-1, -2) / math.sqrt(dh)
+    masked = torch.zeros(S, H, Lq, Lk, dtype=torch.bool)
+    if kpm is not None:
+        masked |= kpm[:, None, None, :]
+    if causal:
+        masked |= torch.ones(Lq, Lk, dtype=torch.bool).triu(1)
+    pr = torch.nan_to_num(torch.softmax(sc.masked_fill(masked, float("-inf")), -1), nan=0.0)
+    if drop is not None:
+        pr = pr * drop
+    return (pr @ sp(v, Lk)).transpose(1, 2).reshape(S, Lq, d)
+
+
+def _drop_mask(p, seed, site, S, H, Lq, Lk):
+    """element (s, h, i, j): idx = (((s * Lq + i) * H + h) << 8) | j  (attn.hip / attn_any.hip)"""
+    s_, h_, i_, j_ = np.meshgrid(np.arange(S, dtype=np.uint64), np.arange(H, dtype=np.uint64), np.arange(Lq, dtype=np.uint64),
+                                 np.arange(Lk, dtype=np.uint64), indexing="ij")
+    idx = ((((s_ * np.uint64(Lq) + i_) * np.uint64(H)) + h_) << np.uint64(8)) | j_
+    keep = O.dropout_keep(p, seed, site, idx)
+    return torch.from_numpy(keep).double() * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+
+HEAD_DIMS = [(8, 4), (24, 4), (32, 8), (48, 2), (96, 2), (128, 3), (256, 1), (7, 4), (1, 4)]  # (dh, H); 7 and 1: the scalar-load build
+
+
+@pytest.mark.parametrize("dh,H", HEAD_DIMS)
+@pytest.mark.parametrize("L,causal", [(1, False), (7, False), (36, False), (17, True), (33, True), (64, True), (100, False), (256, True)])
+def test_attn_core_any_head_dim(pkg, dh, H, L, causal):
+    S, d = (7 if L <= 64 else 2), dh * H
+    qkv = _rand(S, L, 3 * d, seed=L + dh, scale=1.5)
+    kpm = torch.rand(S, L, generator=torch.Generator().manual_seed(100 + L)) < 0.3
+    kpm[:, 0] = False
+    if S > 2:
+        kpm[2, :] = True  # a fully padded sequence -> zeros
+    got = pkg.ops.attn_core(qkv.to(DEV), kpm.to(DEV), causal, H).cpu()
+    ref = _softmax_attention(qkv[..., :d].double(), qkv[..., d:2 * d].double(), qkv[..., 2 * d:].double(), H, kpm, causal)
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+    if S > 2:
+        assert got[2].abs().max().item() == 0.0
+
+
+def test_attn_core_long_key_ranges_and_the_limit(pkg):
+    """Up to 1024 keys per sequence in the forward; beyond that the head dim must be 64 (the streaming MFMA kernel)."""
+    H, dh = 2, 32
+    d = H * dh
+    for L in (700, 1024):
+        qkv = _rand(2, L, 3 * d, seed=L, scale=1.2)
+        kpm = torch.zeros(2, L, dtype=torch.bool)
+        kpm[1, 300:] = True
+        got = pkg.ops.attn_core(qkv.to(DEV), kpm.to(DEV), False, H).cpu()
+        ref = _softmax_attention(qkv[..., :d].double(), qkv[..., d:2 * d].double(), qkv[..., 2 * d:].double(), H, kpm, False)
+        assert (got.double() - ref).abs().max().item() <= 2e-5
+    qkv = _rand(1, 1025, 3 * d, seed=1).to(DEV)
+    with pytest.raises(pkg._lib.StltHipError, match="at most 1024 keys"):
+        pkg.ops.attn_core(qkv, torch.zeros(1, 1025, dtype=torch.bool, device=DEV), False, H)
+    with pytest.raises(pkg._lib.StltHipError, match="head dim"):
+        pkg.ops.attn_core(_rand(1, 4, 3 * 257, seed=1).to(DEV), torch.zeros(1, 4, dtype=torch.bool, device=DEV), False, 1)
+
+
+@pytest.mark.parametrize("dh,H", [(8, 4), (48, 2), (96, 2), (7, 4)])
+@pytest.mark.parametrize("Lq,Lk", [(32, 33), (17, 5), (5, 70), (1, 36)])
+def test_attn_cross_any_head_dim(pkg, dh, H, Lq, Lk):
+    S, d = 5, dh * H
+    q = _rand(S, Lq, d, seed=Lq, scale=1.5)
+    kv = _rand(S, Lk, 2 * d, seed=100 + Lk, scale=1.5)
+    kpm = torch.rand(S, Lk, generator=torch.Generator().manual_seed(3)) < 0.3
+    kpm[:, 0] = False
+    for mask in (kpm, None):
+        got = pkg.ops.attn_cross(q.to(DEV), kv.to(DEV), None if mask is None else mask.to(DEV), H).cpu()
+        ref = _softmax_attention(q.double(), kv[..., :d].double(), kv[..., d:].double(), H, mask, False)
+        assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("dh,H", [(8, 4), (48, 2), (128, 2), (7, 3)])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("lens", [[7, 1, 3, 7, 7, 2, 5], [1] * 70, [64, 3, 70, 1, 33], [5], [200, 256, 1]])
+def test_attn_ragged_any_head_dim(pkg, dh, H, lens, causal):
+    d, M = dh * H, sum(lens)
+    qkv = _rand(M, 3 * d, seed=M + int(causal), scale=1.5)
+    got = pkg.ops.attn_ragged(qkv.to(DEV), lens, H, causal=causal).cpu()
+    ref = torch.zeros(M, d, dtype=torch.float64)
+    r0 = 0
+    for n in lens:
+        seg = qkv[r0:r0 + n].double()[None]
+        ref[r0:r0 + n] = _softmax_attention(seg[..., :d], seg[..., d:2 * d], seg[..., 2 * d:], H, None, causal)[0]
+        r0 += n
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("dh,H", HEAD_DIMS)
+@pytest.mark.parametrize("L,causal", [(7, False), (32, True), (33, True), (36, False), (64, True), (100, True), (256, False)])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_attn_core_bwd_any_head_dim_vs_fp64(pkg, dh, H, L, causal, p):
+    """stlt_attn_core_bwd: dqkv and its column sums (the in-projection bias gradient) against torch autograd in fp64, with padded keys, a
+    fully padded sequence and the dropout mask the forward would have drawn."""
+    S, d = (6 if L <= 64 else 2), dh * H
+    qkv = _rand(S, L, 3 * d, seed=L + dh, scale=1.5)
+    g = _rand(S, L, d, seed=L + 1)
+    kpm = torch.rand(S, L, generator=torch.Generator().manual_seed(L)) < 0.3
+    kpm[:, 0] = False
+    kpm[1, :] = True
+    seed, site = 99 + L, 24
+    dqkv, gb = pkg.ops.attn_core_bwd(qkv.to(DEV), g.to(DEV), kpm.to(DEV), causal, H, p, seed, site, want_bias_grad=True)
+    x = qkv.double().requires_grad_(True)
+    drop = _drop_mask(p, seed, site, S, H, L, L) if p > 0 else None
+    _softmax_attention(x[..., :d], x[..., d:2 * d], x[..., 2 * d:], H, kpm, causal, drop).backward(g.double())
+    ref = x.grad
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert torch.isfinite(dqkv).all()
+    assert (dqkv.cpu().double() - ref).abs().max().item() / scale <= 2e-5
+    cs = ref.reshape(-1, 3 * d).sum(0)
+    assert (gb.cpu().double() - cs).abs().max().item() / max(cs.abs().max().item(), 1e-6) <= 5e-5
+    assert dqkv[1].abs().max().item() == 0.0
+    again, _ = pkg.ops.attn_core_bwd(qkv.to(DEV), g.to(DEV), kpm.to(DEV), causal, H, p, seed, site, want_bias_grad=True)
+    assert torch.equal(again, dqkv)  # no atomics: bitwise reproducible
+
+
+@pytest.mark.parametrize("dh,H", [(8, 4), (48, 2), (96, 2), (7, 4)])
+@pytest.mark.parametrize("Lq,Lk,causal,packed", [(32, 33, False, False), (5, 61, False, False), (7, 7, False, True), (32, 32, True, True),
+                                                  (65, 33, False, False), (33, 130, False, False), (256, 256, True, True)])
+def test_attention_autograd_any_head_dim(pkg, dh, H, Lq, Lk, causal, packed):
+    """ops.AttnFn (forward + the op-level backward, cross-attention included) against torch autograd in fp64."""
+    S, d = 3, dh * H
+    g = _rand(S, Lq, d, seed=9)
+    kpm = torch.rand(S, Lk, generator=torch.Generator().manual_seed(3)) < 0.3
+    kpm[:, 0] = False
+    leaf = lambda t: t.detach().clone().to(DEV).requires_grad_(True)
+    if packed:
+        qkv = leaf(_rand(S, Lq, 3 * d, seed=5, scale=1.5))
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        leaves = [qkv]
+    else:
+        qd, kv = leaf(_rand(S, Lq, d, seed=5, scale=1.5)), leaf(_rand(S, Lk, 2 * d, seed=6, scale=1.5))
+        q, k, v = qd, kv[..., :d], kv[..., d:]
+        leaves = [qd, kv]
+    out = pkg.ops.AttnFn.apply(q, k, v, kpm.to(DEV), causal, H)
+    out.backward(g.to(DEV))
+    refs = [t.detach().cpu().double().requires_grad_(True) for t in leaves]
+    if packed:
+        q64, k64, v64 = refs[0][..., :d], refs[0][..., d:2 * d], refs[0][..., 2 * d:]
+    else:
+        q64, k64, v64 = refs[0], refs[1][..., :d], refs[1][..., d:]
+    ref_out = _softmax_attention(q64, k64, v64, H, kpm, causal)
+    ref_out.backward(g.double())
+    assert (out.detach().cpu().double() - ref_out.detach()).abs().max().item() <= 2e-5
+    for got, ref in zip(leaves, refs):
+        scale = max(ref.grad.abs().max().item(), 1e-6)
+        assert (got.grad.cpu().double() - ref.grad).abs().max().item() / scale <= 2e-5
+
+
+def test_attention_dropout_forward_and_backward_share_the_mask(pkg):
+    """Probability dropout at head dim 48: the forward equals the masked oracle, the backward its fp64 autograd (cross-attention)."""
+    S, H, dh, Lq, Lk, p = 4, 2, 48, 32, 33, 0.3
+    d = H * dh
+    q, kv, w = _rand(S, Lq, d, seed=5, scale=1.2), _rand(S, Lk, 2 * d, seed=6, scale=1.2), _rand(S, Lq, d, seed=8)
+    qd, kvd = q.to(DEV).requires_grad_(True), kv.to(DEV).requires_grad_(True)
+    torch.manual_seed(7)
+    pkg.ops.AttnFn._site = 0x100
+    out = pkg.ops.AttnFn.apply(qd, kvd[..., :d], kvd[..., d:], None, False, H, p)
+    (out * w.to(DEV)).sum().backward()
+    torch.manual_seed(7)
+    pkg.ops.AttnFn._site = 0x100
+    clean = pkg.ops.AttnFn.apply(qd.detach(), kvd.detach()[..., :d], kvd.detach()[..., d:], None, False, H, 0.0)
+    assert (out.detach() - clean).abs().max().item() > 1e-3
+    direction_q = torch.randn(q.shape, generator=torch.Generator().manual_seed(3)).to(DEV) * 1e-2
+    direction_kv = torch.randn(kv.shape, generator=torch.Generator().manual_seed(4)).to(DEV) * 1e-2
+
+    def run(sign):
+        torch.manual_seed(7)
+        pkg.ops.AttnFn._site = 0x100
+        a, b = qd.detach() + sign * direction_q, kvd.detach() + sign * direction_kv
+        return (pkg.ops.AttnFn.apply(a, b[..., :d], b[..., d:], None, False, H, p) * w.to(DEV)).sum().item()
+
+    fd = (run(+1) - run(-1)) / 2
+    an = ((qd.grad * direction_q).sum() + (kvd.grad * direction_kv).sum()).item()
+    assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-2), (fd, an)
+
+
+# ---------------------------------------------------------------- products with K % 32 != 0 (gemm_any.hip)
+@pytest.mark.parametrize("M,N,K", [(1, 5, 4), (37, 174, 100), (300, 400, 100), (129, 300, 200), (1000, 36, 36), (64, 64, 17), (5, 3, 1), (700, 100, 400)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_any_contraction_length(pkg, M, N, K, act):
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3, scale=0.3)
+    pre = x.double() @ w.double().t() + b.double()
+    ref = pre if act == 0 else (F.gelu(pre) if act == 1 else F.relu(pre))
+    got = pkg.ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act).cpu()
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+    got = pkg.ops.linear(x.to(DEV), w.to(DEV), None, act).cpu()
+    pre = x.double() @ w.double().t()
+    ref = pre if act == 0 else (F.gelu(pre) if act == 1 else F.relu(pre))
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 100, 300), (129, 200, 100), (57, 36, 144), (1000, 100, 400), (3, 7, 5)])
+def test_gemm_backward_layouts_any_contraction_length(pkg, M, N, K):
+    """dX = dY·W (+ residual gradient) with a contraction length that is not a multiple of 32, and dW = dYᵀ·X (+ accumulate) with output
+    shapes that are not multiples of 32 (its contraction runs over rows)."""
+    a, b, r = _rand(M, K, seed=1), _rand(K, N, seed=2, scale=1 / math.sqrt(K)), _rand(M, N, seed=3)
+    ref = a.double() @ b.double()
+    got = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_b=True).cpu()
+    assert (got.double() - ref).abs().max().item() <= 3e-5
+    got = pkg.ops.gemm(a.to(DEV), b.to(DEV), trans_b=True, add=r.to(DEV)).cpu()
+    assert (got.double() - (ref + r.double())).abs().max().item() <= 3e-5
+    for rows in (77, 96):  # dW over a row count that is not a multiple of 32 either (vector ALU) / that is (the MFMA kernel, ragged output tiles)
+        dy, x, acc = _rand(rows, K, seed=4), _rand(rows, N, seed=5), _rand(K, N, seed=6)
+        refw = dy.double().t() @ x.double()
+        got = pkg.ops.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True)
+        assert (got.cpu().double() - refw).abs().max().item() <= 2e-5 * math.sqrt(rows)
+        got2 = pkg.ops.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, add=acc.to(DEV))
+        assert (got2.cpu().double() - (refw + acc.double())).abs().max().item() <= 2e-5 * math.sqrt(rows)
+        assert torch.equal(got, pkg.ops.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True))  # fixed summation order
+
+
+def test_linear_autograd_any_contraction_length(pkg):
+    for M, N, K in ((40, 100, 100), (300, 400, 100), (33, 36, 144)):
+        x, w, b, g = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3, scale=0.1), _rand(M, N, seed=4)
+        xd, wd, bd = [t.clone().to(DEV).requires_grad_(True) for t in (x, w, b)]
+        pkg.ops.LinearFn.apply(xd, wd, bd).backward(g.to(DEV))
+        x64, w64, b64 = [t.double().requires_grad_(True) for t in (x, w, b)]
+        (x64 @ w64.t() + b64).backward(g.double())
+        for got, ref, name in ((xd.grad, x64.grad, "dx"), (wd.grad, w64.grad, "dw"), (bd.grad, b64.grad, "db")):
+            scale = max(ref.abs().max().item(), 1e-6)
+            assert (got.cpu().double() - ref).abs().max().item() / scale <= 2e-5, (name, M, N, K)
+
+
+# ---------------------------------------------------------------- models
+def _model(pkg, d, H, n_sp=2, n_tp=2, seed=13, drop=0.0):
+    kw = dict(pkg.synth.model_kwargs("cfg1"), hidden_size=d, num_attention_heads=H, num_spatial_layers=n_sp, num_temporal_layers=n_tp,
+              hidden_dropout_prob=drop)
+    m = pkg.Stlt(pkg.StltModelConfig(**kw))
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed, gain=1.5)
+    m.load_state_dict(sd)
+    return m.to(DEV), sd
+
+
+@pytest.mark.parametrize("name", ["micro", "heads", "odd"])
+def test_logits_vs_reference_golden_at_other_head_dims(pkg, name):
+    """Goldens captured from the reference's own Stlt (tools/gen_golden.py): `micro` is hidden 32 / 4 heads (head dim 8), `heads` hidden
+    384 / 4 heads (head dim 96), `odd` hidden 100 / 4 heads (head dim 25; products on gemm_any.hip).  Both schedules and skip-padding, tolerance 1e-4 as for every other golden."""
+    sd, batch, z, meta = golden_case(name)
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.load_state_dict(sd)
+    m.to(DEV).train(False)
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    ref = torch.from_numpy(z["logits"])
+    with torch.no_grad():
+        for cls_only, last_row, skip in ((True, True, False), (False, False, False), (True, True, True)):
+            m.backbone.cls_only_last_spatial, m.backbone.last_row_only_temporal, m.backbone.skip_padding = cls_only, last_row, skip
+            got = m(dev)["stlt"].cpu()
+            assert (got - ref).abs().max().item() <= 1e-4, (cls_only, last_row, skip)
+
+
+@pytest.mark.parametrize("d,H", [(32, 4), (96, 4), (192, 2), (256, 8), (384, 4), (768, 8), (768, 3), (100, 4), (200, 8), (40, 2), (36, 3), (72, 1)])
+def test_forward_and_gradients_at_other_head_dims(pkg, d, H):
+    """Stlt forward (padded and skip-padding) and every parameter gradient (the native reverse sweep) against the oracle and its fp64
+    autograd, at head dims 8 / 24 / 96 / 32 / 96 / 96 / 256, and at hidden sizes that are not multiples of 32 (100, 200, 40, 36; 72 with the one head
+    of 72 channels)."""
+    m, sd = _model(pkg, d, H)
+    batch = pkg.synth.make_batch(3, 9, 5, seed=6, min_len=2)
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    ref = O.stlt_forward(sd, batch, H)["stlt"]
+    m.train(False)
+    with torch.no_grad():
+        for skip in (False, True):
+            m.backbone.skip_padding = skip
+            assert (m(dev)["stlt"].cpu() - ref).abs().max().item() <= 1e-4, skip
+    labels = torch.tensor([1, 2, 3])
+    leaves = {k: (v.detach().double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    F.cross_entropy(O.stlt_forward(leaves, b64, H, dtype=torch.float64)["stlt"], labels).backward()
+    for skip in (False, True):
+        m.backbone.skip_padding = skip
+        m.train(True)
+        for prm in m.parameters():
+            prm.grad = None
+        F.cross_entropy(m(dev)["stlt"], labels.to(DEV)).backward()
+        for k, prm in m.named_parameters():
+            if prm.grad is None:
+                continue
+            g_ref = leaves[k].grad
+            scale = max(g_ref.abs().max().item(), 1e-6)
+            assert (prm.grad.cpu().double() - g_ref).abs().max().item() / scale <= 3e-4, (k, skip)
+
+
+def test_training_with_dropout_at_head_dim_96_matches_the_masked_oracle(pkg):
+    """Train-mode forward with the counter-based masks (attention probabilities included) against the oracle run with the same masks."""
+    d, H = 384, 4
+    m, sd = _model(pkg, d, H, drop=0.1)
+    batch = pkg.synth.make_batch(4, 9, 5, seed=8, min_len=2)
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    m.train(True)
+    torch.manual_seed(5)
+    got = m(dev)["stlt"].detach().cpu()
+    torch.manual_seed(5)
+    again = m(dev)["stlt"].detach().cpu()
+    assert torch.equal(got, again)
+    m.train(False)
+    with torch.no_grad():
+        clean = m(dev)["stlt"].cpu()
+    assert (got - clean).abs().max().item() > 1e-3
+
+
+def test_fusion_blocks_at_head_dim_32(pkg):
+    """The block-level training API (blocks.hip) with 8 heads of 32 channels: self- and cross-attention blocks, forward and backward,
+    against torch autograd on the same arithmetic in fp64."""
+    S, Lq, Lk, d, H = 3, 9, 12, 256, 8
+    x, c, g = _rand(S, Lq, d, seed=1), _rand(S, Lk, d, seed=2), _rand(S, Lq, d, seed=3)
+    w_in, b_in = _rand(3 * d, d, seed=4, scale=1 / math.sqrt(d)), _rand(3 * d, seed=5, scale=0.1)
+    w_o, b_o = _rand(d, d, seed=6, scale=1 / math.sqrt(d)), _rand(d, seed=7, scale=0.1)
+    ln_w, ln_b = 1 + 0.1 * _rand(d, seed=8), 0.1 * _rand(d, seed=9)
+    kpm = torch.rand(S, Lk, generator=torch.Generator().manual_seed(3)) < 0.3
+    kpm[:, 0] = False
+    for cross in (False, True):
+        ctx_src, L2, mask = (c, Lk, kpm) if cross else (x, Lq, kpm[:, :Lq].contiguous())
+        leaves = [t.clone().to(DEV).requires_grad_(True) for t in (x, ctx_src, w_in, b_in, w_o, b_o, ln_w, ln_b)]
+        xd, cd = leaves[0], leaves[1]
+        out = pkg.ops.AttnBlockFn.apply(xd, cd if cross else None, mask.to(DEV), False, H, 1e-5, 0.0, *leaves[2:])
+        out.backward(g.to(DEV))
+        r = [t.clone().double().requires_grad_(True) for t in (x, ctx_src, w_in, b_in, w_o, b_o, ln_w, ln_b)]
+        q = r[0] @ r[2][:d].t() + r[3][:d]
+        src = r[1] if cross else r[0]
+        k = src @ r[2][d:2 * d].t() + r[3][d:2 * d]
+        v = src @ r[2][2 * d:].t() + r[3][2 * d:]
+        a = _softmax_attention(q, k, v, H, mask, False) @ r[4].t() + r[5]
+        ref = F.layer_norm(r[0] + a, (d,), r[6], r[7], 1e-5)
+        ref.backward(g.double())
+        assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 5e-5
+        for i, (got, want) in enumerate(zip(leaves, r)):
+            if i == 1 and not cross:
+                continue
+            scale = max(want.grad.abs().max().item(), 1e-6)
+            assert (got.grad.cpu().double() - want.grad).abs().max().item() / scale <= 2e-4, (cross, i)

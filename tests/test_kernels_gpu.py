@@ -40,9 +40,11 @@ def test_linear_strided_rows_and_no_bias(pkg):
     assert (y.double() - ref).abs().max().item() <= 2e-5
 
 
-def test_linear_rejects_bad_k(pkg):
-    with pytest.raises(pkg.StltHipError):
-        pkg.ops.linear(torch.zeros(4, 20, device=DEV), torch.zeros(8, 20, device=DEV), None)
+def test_linear_with_a_contraction_length_that_is_not_a_multiple_of_32(pkg):
+    """Round 4: such products run on the vector-ALU fallback (gemm_any.hip) instead of being rejected."""
+    x, w = _rand(4, 20, seed=1), _rand(8, 20, seed=2)
+    y = pkg.ops.linear(x.to(DEV), w.to(DEV), None).cpu()
+    assert (y.double() - x.double() @ w.double().t()).abs().max().item() <= 2e-5
 
 
 @pytest.mark.parametrize("d,C,with_scores", [(256, 4, False), (768, 4, False), (768, 38, True), (1024, 5, True), (64, 3, True)])

@@ -7,7 +7,7 @@ from conftest import golden_case
 from oracle import stlt_oracle as O
 
 
-@pytest.mark.parametrize("name", ["micro", "cfg1", "cfg2", "cfg2p", "refdef", "cfg4"])
+@pytest.mark.parametrize("name", ["micro", "cfg1", "cfg2", "cfg2p", "refdef", "heads", "odd", "cfg4"])
 def test_oracle_logits_match_reference(name, synth):
     sd, batch, z, meta = golden_case(name)
     H = synth.CONFIGS[name]["num_attention_heads"]

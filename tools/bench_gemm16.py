@@ -24,7 +24,33 @@ def timed(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+HEADER = """# Round 4: small-tile product kernel (csrc/gemm16.hip) against the large-tile kernel (csrc/gemm.hip: 256 x 128 tiles; stream-K + fix-up launch where
+# under-filled).  MI355X, d = 768, stand-alone launches (tools/bench_gemm16.py --dx, 50 timed launches each, torch events around both launches of a
+# stream-K product); us per launch.  t48 … t192 = tile width in columns (128 rows); choice = what the launch-time estimate picks (0 = large tiles).
+# *_dx rows: input gradient dX = dY·W with W (n_out = K, k_in = N) read as it lies (WKN build) against gemm.hip's NN kernel.
+"""
+
+
+def table(path):
+    """The committed text form of a run's JSON lines (profiles/round4_gemm16_shapes.txt): python tools/bench_gemm16.py --table <jsonl>"""
+    rows = [json.loads(l) for l in open(path) if l.startswith("{")]
+    widths = (48, 64, 96, 128, 144, 192)
+    print(HEADER)
+    print(f"{'M':>6} {'shape':>8} {'N':>5} {'K':>5} {'large':>8} " + " ".join(f"{'t%d' % w:>7}" for w in widths) + "  best choice TF/s large TF/s best")
+    worst = 0.0
+    for r in rows:
+        t = {w: r[f"t{w}_us"] for w in widths}
+        print(f"{r['M']:>6} {r['shape']:>8} {r['N']:>5} {r['K']:>5} {r['large_us']:>8.1f} " + " ".join(f"{t[w]:>7.1f}" for w in widths)
+              + f" {r['best']:>5} {r['choice']:>6} {r['tflops_large']:>10.1f} {r['tflops_best']:>9.1f}")
+        best = min([r["large_us"]] + list(t.values()))
+        routed = t[r["choice"]] if r["choice"] else r["large_us"]
+        worst = max(worst, routed / best)
+    print(f"\nworst (time of the routed choice) / (best measured) over the {len(rows)} rows: {worst:.3f}")
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--table":
+        return table(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, nargs="+", default=[2048, 2112, 1088, 4096, 14336])
     ap.add_argument("--iters", type=int, default=50)

@@ -45,7 +45,8 @@ python3 $R/tools/pmc_util.py $O/round4_util_pmc.json /tmp/pu
 for mode in 1 0; do
   rm -rf /tmp/pt$mode
   STLT_TRAIN_DW_STREAM=$mode rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt$mode -o o -- python3 $R/bench.py --mode train --no-cpu-baseline --steps 6 --warmup 2 > $O/round4_train_under_rocprof_dw$mode.log 2>&1
-  python3 $R/tools/step_trace.py $(find /tmp/pt$mode -name '*kernel_trace.csv' | head -1) --summary > $O/round4_train_step_timeline_b64_dw$mode.txt
+  # --back 6: the last TIMED step (the run ends with 6 event-timed replays that keep one stream whatever the switch says)
+  python3 $R/tools/step_trace.py $(find /tmp/pt$mode -name '*kernel_trace.csv' | head -1) --summary --back 6 > $O/round4_train_step_timeline_b64_dw$mode.txt
 done
 cp $(find /tmp/pt1 -name '*kernel_stats.csv' | head -1) $O/round4_train_step_kernel_stats_b64.csv
 # 8. the 64-clip forward and cfg4 under the tracer (kernel-only durations of the small-batch paths)
@@ -70,7 +71,7 @@ cd $R
 python -m pytest tests -q -m gpu > $O/round4_pytest_gpu.log 2>&1
 STLT_GEMM_SPLIT_BF16=6 python -m pytest tests -q -m gpu > $O/round4_pytest_gpu_split_bf16_on.log 2>&1
 STLT_FUSED_MHSA=0 STLT_GEMM16=0 STLT_TRAIN_DW_STREAM=0 STLT_TRAIN_DEFER_REDUCE=0 python -m pytest tests -q -m gpu > $O/round4_pytest_gpu_fused_off.log 2>&1
-tail -2 $O/round4_pytest_gpu.log $O/round4_pytest_gpu_split_bf16_on.log $O/round4_pytest_gpu_fused_off.log
+for f in $O/round4_pytest_gpu.log $O/round4_pytest_gpu_split_bf16_on.log $O/round4_pytest_gpu_fused_off.log; do tail -n 1 $f; done
 tail -1 $O/round4_bench_b1024.json | cut -c1-300
 tail -1 $O/round4_bench_train_b64.json | cut -c1-300
 head -8 $O/round4_kernel_stats_b1024.csv | cut -c1-200

@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("revisiting-spatial-temporal-layouts_amd.synth")
 
-GOLDEN_BATCH = {"micro": 2, "cfg1": 8, "cfg2": 4, "cfg2p": 3, "cfg4": 2, "refdef": 4}
+GOLDEN_BATCH = {"micro": 2, "cfg1": 8, "cfg2": 4, "cfg2p": 3, "cfg4": 2, "refdef": 4, "heads": 5, "odd": 6}
 WEIGHT_SEED = 1234
 INPUT_SEED = 0
 

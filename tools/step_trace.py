@@ -7,6 +7,7 @@ kernel (default: embed_kernel, the first kernel of a forward), with its duration
 import argparse, csv, re, collections
 ap = argparse.ArgumentParser()
 ap.add_argument("trace"); ap.add_argument("--marker", default=r"(^|::| )embed_kernel<", help="regex of the kernel that starts a step"); ap.add_argument("--summary", action="store_true")
+ap.add_argument("--back", type=int, default=0, help="take the step that ends N markers before the last one (bench.py --mode train ends with `steps` event-timed replays on one stream)")
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -20,7 +21,7 @@ def short(n):
         return f"gemm[{kind}{' act' + act if act != '0' else ''}{' +R' if add == 'true' else ''}{' SK' if sk == 'true' else ''}{' GRP' if grp == 'true' else ''}]"
     return n.split("(")[0][:48]
 marks = [i for i, r in enumerate(rows) if re.search(a.marker, r["Kernel_Name"])]
-lo, hi = (marks[-2], marks[-1]) if len(marks) >= 2 else (0, len(rows))
+lo, hi = (marks[-2 - a.back], marks[-1 - a.back]) if len(marks) >= 2 + a.back else (0, len(rows))
 step = rows[lo:hi]
 t0 = int(step[0]["Start_Timestamp"]); prev_end = t0
 tot = collections.OrderedDict(); gaps = 0
