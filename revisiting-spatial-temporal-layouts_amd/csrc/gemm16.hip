@@ -12,7 +12,7 @@
 // Structure = mhsa.hip's product phase: v_mfma_f32_16x16x4_f32, 8 MFMA waves each owning one 16-row block and all NT column tiles
 // (transposed accumulators: lane = row, registers = 4 consecutive columns -> 16-byte stores), 4 DMA-only loader waves two to five
 // k-steps ahead (LDS-DMA with the source-side bank swizzle, three to six stages, counted vmcnt, one barrier per k-step), bias as the accumulators'
-// initial value from a double-buffered LDS strip, persistent workgroups over XCD-contiguous tile ranges (column tile fastest, so
+// initial value from LDS strips DMA'd in front of each tile's first k-step, persistent workgroups over XCD-contiguous tile ranges (column tile fastest, so
 // that the workgroups of an XCD share X row panels).  NT (forward) layout only; K % 32 == 0, N % 4 == 0.
 #include <cstdlib>
 #include "common.h"
@@ -37,7 +37,8 @@ struct Gemm16Args {
 };
 
 template <int NT> constexpr int q_stage_floats() { return (QM + 16 * NT) * QK; }
-template <int NT> constexpr int q_smem_floats() { return q_nstage<NT>() * q_stage_floats<NT>() + 2 * 16 * NT; }
+constexpr int Q_BIAS_STRIPS = 4;  // see dma_bias
+template <int NT> constexpr int q_smem_floats() { return q_nstage<NT>() * q_stage_floats<NT>() + Q_BIAS_STRIPS * 16 * NT; }
 
 // WKN = false: W is (N, K) row-major (nn.Linear's weight; forward products).  WKN = true: W is (K, N) row-major — the input-gradient
 // product dX = dY·W of a Linear whose weight (n_out, k_in) is read as it lies, contraction over its rows: the W image in LDS is then
@@ -107,6 +108,11 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
         }
       }
     };
+    // Bias strip of tile `it` (its accumulators' initial value), issued IN FRONT of the tile's first k-step: the counter is in order, so
+    // the wait that publishes that k-step publishes the strip as well.  (Until the end of round 4 the strip was issued one k-step before
+    // it was read, behind up to LA - 1 newer steps the counted wait lets stay in flight: a race that was almost always won — the 3 KB of
+    // bias are L2-resident — and lost once in a 33 000-row launch of a test run.)  Four strips: the loaders are LA <= 5 steps ahead and a
+    // tile has nk >= 2 k-steps, so a strip is rewritten at the earliest 4 nk - LA >= 3 barriers after the MFMA waves read it.
     auto dma_bias = [&](int it) {  // loader 0 (and 1, 2 for wide tiles): BN bias values, 64 per instruction
       if (a.bias && Ld * 64 < BN) {
         int tm, tn;
@@ -114,12 +120,12 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
         int gn = tn * BN + Ld * 64 + lane;
         gn = gn < a.N ? gn : a.N - 1;
         if (Ld * 64 + lane < BN)
-          __builtin_amdgcn_global_load_lds((glb_void_ptr)(a.bias + gn), (lds_void_ptr)(bias_lds + (it & 1) * BN + Ld * 64), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds((glb_void_ptr)(a.bias + gn), (lds_void_ptr)(bias_lds + (it & (Q_BIAS_STRIPS - 1)) * BN + Ld * 64), 4, 0, 0);
       }
     };
     int l_it = 0, l_kt = 0, l_stage = 0;
     auto l_step = [&]() {
-      if (l_kt == 0) set_item(l_it);
+      if (l_kt == 0) { set_item(l_it); dma_bias(l_it); }
       float* sa = smem + l_stage * STAGE + (Ld * 32) * QK;
       float* sb = smem + l_stage * STAGE + QM * QK;
 #pragma unroll
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
       if (++l_stage == Q_NSTAGE) l_stage = 0;
     };
     // in-order counter: once at most the instructions of the newest LA - 1 steps are in flight, everything up to the step the MFMA
-    // waves read next has landed (a bias strip issued in between only makes the wait stricter).  The count per step is a per-loader
+    // waves read next has landed, and the bias strip in front of it (a strip among the newer instructions only makes the wait stricter).  The count per step is a per-loader
     // constant (4 + nbl), so the wait is one of two immediates.
     constexpr int WAIT_FULL = (LA - 1) * (4 + NBL_MAX), WAIT_LESS = (LA - 1) * (3 + NBL_MAX);
     static_assert(WAIT_FULL < 64, "vmcnt is a 6-bit counter");
@@ -140,7 +146,6 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
       if (nbl == NBL_MAX) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT_FULL) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT_LESS) : "memory");
     };
-    dma_bias(0);
     if (total_steps >= LA) {
 #pragma unroll
       for (int i = 0; i < LA; ++i) l_step();
@@ -150,9 +155,7 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    int w_it = 0, w_kt = 0;  // position of the MFMA waves
     for (int step = 0; step < total_steps; ++step) {
-      if (w_kt == nk - 1 && w_it + 1 < my_items) dma_bias(w_it + 1);
       if (step + LA < total_steps) {
         l_step();
         wait_ahead();
@@ -160,7 +163,6 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      if (++w_kt == nk) { ++w_it; w_kt = 0; }
     }
     return;
   }
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
   f32x4 acc[NT];
   auto init_acc = [&](int it) {
     if (a.bias) {
-      const float* src = bias_lds + (it & 1) * BN + 4 * lg;
+      const float* src = bias_lds + (it & (Q_BIAS_STRIPS - 1)) * BN + 4 * lg;
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
     } else {

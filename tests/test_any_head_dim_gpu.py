@@ -365,3 +365,56 @@ def test_fusion_blocks_at_head_dim_32(pkg):
                 continue
             scale = max(want.grad.abs().max().item(), 1e-6)
             assert (got.grad.cpu().double() - want.grad).abs().max().item() / scale <= 2e-4, (cross, i)
+
+
+@pytest.mark.parametrize("d,H", [(256, 8), (384, 4), (100, 4)])
+@pytest.mark.parametrize("model_name", ["caf", "cacnf", "lcf"])
+def test_fusion_models_at_other_head_dims(pkg, model_name, d, H):
+    """CAF / CACNF / LCF (native single-call inference, skip-padding, and the training path's logits and gradients) at head dims 32 / 96 and
+    at hidden size 100, against the CPU oracle and its autograd."""
+    from oracle import caf_oracle as CO
+    kw = dict(pkg.synth.model_kwargs("cfg1"), hidden_size=d, num_attention_heads=H, num_spatial_layers=1, num_temporal_layers=2,
+              appearance_num_frames=32, num_appearance_layers=1, num_fusion_layers=2)
+    m = pkg.models_factory[model_name](pkg.MultimodalModelConfig(**kw))
+    # weight seed 6: with seed 5 the 384 / 4 CAF case has an appearance-FFN pre-activation within an ulp of zero — a 2e-7 relative change of
+    # the appearance input moves linear1.weight's gradient by 0.5 - 1.4 % in the fp32 CPU oracle itself (a ReLU unit flips); with seed 6 the
+    # same perturbation moves no gradient of any of the nine cases by more than 2e-6, so the 5e-4 bar below tests the kernels, not a flip
+    sd = pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=6)
+    m.load_state_dict(sd)
+    m.train(False).to(DEV)
+    B = 3
+    batch = pkg.synth.make_batch(B, 9, 5, seed=8, min_len=2)
+    batch["appearance_features"] = pkg.synth.make_appearance_features(B, seed=9)
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    fwd = {"caf": CO.caf_forward, "cacnf": CO.cacnf_forward, "lcf": CO.lcf_forward}[model_name]
+    with torch.no_grad():
+        ref = fwd(sd, batch, H)
+        out = m(dev)
+        for k in ref:
+            assert (out[k].cpu() - ref[k]).abs().max().item() <= 1e-4, k
+        (branch,) = [mod for mod in m.modules() if isinstance(mod, pkg.StltBackbone)]
+        branch.skip_padding = True
+        out_sp = m(dev)
+        branch.skip_padding = False
+        for k in ref:
+            assert (out_sp[k].cpu() - ref[k]).abs().max().item() <= 1e-4, k
+    out = m(dev)  # autograd on: block-level native calls + the layout branch's native sweep
+    labels = torch.tensor([1, 2, 3])
+    loss = sum(F.cross_entropy(v, labels.to(DEV)) for v in out.values()) / len(out)
+    loss.backward()
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref = fwd(leaves, batch, H)
+    ref_loss = sum(F.cross_entropy(v, labels) for v in ref.values()) / len(ref)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5
+    checked = 0
+    for k, prm in m.named_parameters():
+        g_ref = leaves[k].grad if leaves[k].is_floating_point() else None
+        if prm.grad is None or g_ref is None:
+            assert g_ref is None or g_ref.abs().max().item() == 0.0, k
+            assert prm.grad is None or prm.grad.abs().max().item() == 0.0, k
+            continue
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        assert (prm.grad.cpu() - g_ref).abs().max().item() / scale <= 5e-4, k
+        checked += 1
+    assert checked > 40

@@ -541,6 +541,27 @@ def test_linear_small_tiles_vs_fp64(pkg, M, N, K, tile_cols):
 
 
 @pytest.mark.parametrize("tile_cols", [48, 64, 96, 128, 144, 192])
+@pytest.mark.parametrize("K", [64, 96, 128, 256])
+def test_linear_small_tiles_bias_strip_under_load(pkg, tile_cols, K):
+    """Many short tiles per workgroup (33 000 rows, 2 - 8 k-steps a tile): every tile's accumulators start from its own bias strip.  The
+    strip is DMA'd in front of the tile's first k-step, so the counted wait that publishes that step publishes it too; round 4's first
+    form issued it one k-step before it was read, behind loads the wait lets stay in flight, and lost that race once in a test run.
+    A stale strip is another column tile's bias: the bias here is large and different per column, so it cannot hide in the tolerance."""
+    M, N = 33000, 768
+    x = _rand(M, K, seed=K, scale=1.0)
+    w = _rand(N, K, seed=K + 1, scale=1.0 / math.sqrt(K))
+    b = (torch.arange(N, dtype=torch.float32) - N / 2) * 0.25
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ref = (x.double() @ w.double().t() + b.double()).float().to(DEV)
+    first = None
+    for rep in range(12):
+        got = pkg.ops.linear_small(xd, wd, bd, tile_cols)
+        assert (got - ref).abs().max().item() <= 1e-3, rep
+        first = got if first is None else first
+        assert torch.equal(got, first), rep
+
+
+@pytest.mark.parametrize("tile_cols", [48, 64, 96, 128, 144, 192])
 @pytest.mark.parametrize("M,n_out,k_in", [(2048, 768, 768), (2112, 2304, 768), (2048, 3072, 768), (2048, 768, 3072), (1000, 64, 1536), (77, 96, 52),
                                           (1, 64, 4), (20000, 128, 768)])
 def test_input_grad_small_tiles_vs_fp64(pkg, M, n_out, k_in, tile_cols):
