@@ -67,6 +67,8 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o o -- python3 $R/tools/bench_caf.py --train --batch 64 --steps 4 --warmup 2 > /dev/null 2>&1
 python3 $R/tools/step_trace.py $(find /tmp/pc -name '*kernel_trace.csv' | head -1) --marker sumsq_kernel --summary > $O/round4_caf_train_step_timeline_b64.txt
 cd $R
+# 9b. soak: 400 launches of every synchronisation-heavy kernel case, bit-identical and within tolerance
+python tools/soak.py --reps 400 > $O/round4_soak.jsonl 2>/dev/null
 # 10. the GPU suite on this box: default, with the opt-in split-bf16 products exported, and with the round-4 dispatches off
 python -m pytest tests -q -m gpu > $O/round4_pytest_gpu.log 2>&1
 STLT_GEMM_SPLIT_BF16=6 python -m pytest tests -q -m gpu > $O/round4_pytest_gpu_split_bf16_on.log 2>&1
