@@ -343,17 +343,18 @@ typedef struct {
  *   column sums of dy (nullable).  scratch: stlt_linear_bwd_scratch_bytes(N).
  * stlt_attn_bwd: backward of stlt_attn_cross_fwd (and, with q = qkv, k = qkv+d, v = qkv+2d, of stlt_attn_core_fwd):
  *   dq / dk / dv written (not accumulated) with their own leading dimensions; sequences of at most 256 tokens on either
- *   side (above 64 a streamed variant: query tiles of 32, keys / values in tiles through LDS).
+ *   side (above 64 a streamed variant: query tiles of 32, keys / values in tiles through LDS); head dims other than 64: attn_any.hip.
  * stlt_add_layernorm_bwd: out = LN_eps(x + res)·w + b.  ds = gradient wrt the sum (the gradient of both x and res);
  *   g_w / g_b accumulate (nullable).  scratch: stlt_add_layernorm_bwd_scratch_bytes(d).
  * stlt_gelu_fwd / stlt_gelu_bwd: exact-erf GELU and du = dh * gelu'(u), n a multiple of 4. */
 size_t stlt_linear_bwd_scratch_bytes(int64_t N);
 int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, float* dw, float* db,
                     void* scratch, size_t scratch_bytes, stlt_stream_t stream);
-/* Backward of K3 on the packed projection (what the training sweep runs per layer): dqkv (S*L, 3*H*64) from qkv and dctx, with
+/* Backward of K3 on the packed projection (what the training sweep runs per layer): dqkv (S*L, 3*H*dh) from qkv and dctx, with
  * the masks of stlt_attn_core_fwd, optional dropout of the probabilities (site as in stlt_train_forward) and, when in_proj_b_grad
- * is not NULL, in_proj_b_grad (3*H*64) += column sums of dqkv.  L <= 64: v_mfma_f32_16x16x4_f32 tiles (one wave per sequence and
- * head); up to 256: plain FMA, keys streamed through LDS.  scratch: stlt_attn_core_bwd_scratch_bytes(H) bytes. */
+ * is not NULL, in_proj_b_grad (3*H*dh) += column sums of dqkv.  dh == 64, L <= 64: v_mfma_f32_16x16x4_f32 tiles (one wave per
+ * sequence and head); up to 256: plain FMA, keys streamed through LDS.  Any other head dim (1 ... 256): the two-phase vector-ALU
+ * kernel of csrc/attn_any.hip (L <= 256, no atomics).  scratch: stlt_attn_core_bwd_scratch_bytes(H) bytes. */
 size_t stlt_attn_core_bwd_scratch_bytes(int64_t H);
 int stlt_attn_core_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                        float dropout_p, uint64_t seed, uint32_t site, float* dqkv, float* in_proj_b_grad, void* scratch, size_t scratch_bytes,
