@@ -139,6 +139,37 @@ int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* 
 // tile row, every slot written — launch_reduce_slabs(cs_part, N, ceil(M/256)*16, g, N, 1) finishes them.
 constexpr int STLT_ACT_GELU_BWD = 3;
 struct StltGemmEpi { StltDrop dr; uint32_t site; const int* drop_rows; float* cs_part; };
+// d/dx gelu(x) = Phi(x) + x phi(x), fixed cost like gelu_epilogue (same erf fit, two v_exp_f32)
+__device__ __forceinline__ float gelu_grad_epilogue(float x) {
+  const float z = x * 0.70710678118654752440f;
+  const float t = fminf(fabsf(z), 3.95f);
+  float q = 1.1830035617776957e-07f;
+  q = fmaf(q, t, -3.0875787615514128e-06f);
+  q = fmaf(q, t, 3.5860794014297426e-05f);
+  q = fmaf(q, t, -0.00024206875241361558f);
+  q = fmaf(q, t, 0.0010191010078415275f);
+  q = fmaf(q, t, -0.002435620641335845f);
+  q = fmaf(q, t, 0.00011764218652388081f);
+  q = fmaf(q, t, 0.027792135253548622f);
+  q = fmaf(q, t, -0.14836618304252625f);
+  q = fmaf(q, t, -0.9184255599975586f);
+  q = fmaf(q, t, -1.6279090642929077f);
+  q = fmaf(q, t, 2.831300349726007e-08f);
+  const float e = copysignf(1.0f - __builtin_amdgcn_exp2f(q), z);
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  return fmaf(x, pdf, 0.5f * (1.0f + e));
+}
+// dropout mask of the FFN hidden + gelu'(u) on four consecutive columns of row `drow`
+__device__ __forceinline__ f32x4 gelu_bwd4(f32x4 g, f32x4 u, const StltGemmEpi& epi, uint64_t key, uint64_t idx0) {
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = g[j];
+    if (epi.dr.thr) v = stlt_keep_k(epi.dr.thr, key, idx0 + j) ? v * epi.dr.scale : 0.f;
+    o[j] = v * gelu_grad_epilogue(u[j]);
+  }
+  return o;
+}
 // gemm_any.hip: launch_gemm's fallback for contraction lengths that are not multiples of 32 (vector ALU, same layouts and epilogues)
 int launch_gemm_any(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, const float* r,
                     int64_t ldr, float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t s);
@@ -156,7 +187,7 @@ int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw
 int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
                          int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken, int force_nt = 0);
 int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
-                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_nt = 0);  // dX = dY·W on the small tiles, W as it lies
+                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_nt = 0, const StltGemmEpi* gelu_bwd = nullptr);  // dX = dY·W on the small tiles, W as it lies
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
                 int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi = nullptr);

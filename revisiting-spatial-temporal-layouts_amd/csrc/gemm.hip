@@ -80,37 +80,6 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 #ifndef STLT_GEMM_WS_DEFAULT
 #define STLT_GEMM_WS_DEFAULT 1
 #endif
-// d/dx gelu(x) = Phi(x) + x phi(x), fixed cost like gelu_epilogue (same erf fit, two v_exp_f32)
-__device__ __forceinline__ float gelu_grad_epilogue(float x) {
-  const float z = x * 0.70710678118654752440f;
-  const float t = fminf(fabsf(z), 3.95f);
-  float q = 1.1830035617776957e-07f;
-  q = fmaf(q, t, -3.0875787615514128e-06f);
-  q = fmaf(q, t, 3.5860794014297426e-05f);
-  q = fmaf(q, t, -0.00024206875241361558f);
-  q = fmaf(q, t, 0.0010191010078415275f);
-  q = fmaf(q, t, -0.002435620641335845f);
-  q = fmaf(q, t, 0.00011764218652388081f);
-  q = fmaf(q, t, 0.027792135253548622f);
-  q = fmaf(q, t, -0.14836618304252625f);
-  q = fmaf(q, t, -0.9184255599975586f);
-  q = fmaf(q, t, -1.6279090642929077f);
-  q = fmaf(q, t, 2.831300349726007e-08f);
-  const float e = copysignf(1.0f - __builtin_amdgcn_exp2f(q), z);
-  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
-  return fmaf(x, pdf, 0.5f * (1.0f + e));
-}
-// dropout mask of the FFN hidden + gelu'(u) on four consecutive columns of row `drow`
-__device__ __forceinline__ f32x4 gelu_bwd4(f32x4 g, f32x4 u, const StltGemmEpi& epi, uint64_t key, uint64_t idx0) {
-  f32x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float v = g[j];
-    if (epi.dr.thr) v = stlt_keep_k(epi.dr.thr, key, idx0 + j) ? v * epi.dr.scale : 0.f;
-    o[j] = v * gelu_grad_epilogue(u[j]);
-  }
-  return o;
-}
 __device__ __forceinline__ float half_wave_sum(float x) {  // over the 32 lanes that share lane >> 5
   x += __shfl_xor(x, 1, 64);
   x += __shfl_xor(x, 2, 64);

@@ -34,6 +34,7 @@ struct Gemm16Args {
   float* Y;
   int64_t ldx, ldw, ldr, ldy;
   int M, N, K, tiles_m, tiles_n;
+  StltGemmEpi epi;  // ACT == STLT_ACT_GELU_BWD only (R = the pre-activation u, not added)
 };
 
 template <int NT> constexpr int q_stage_floats() { return (QM + 16 * NT) * QK; }
@@ -246,7 +247,41 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
       asm volatile("" : "+v"(eli), "+v"(elg));
       const int row = tm * QM + rb * 16 + eli;
       const int col0 = tn * BN + 4 * elg;
-      if (row < a.M) {
+      if constexpr (ACT == STLT_ACT_GELU_BWD) {
+        // the FFN hidden gradient: du = drop(dh) ∘ gelu'(u) (gemm.hip's fused epilogue, same helpers) + the column sums of du over the
+        // wave's 16 rows as one partial row of cs_part per 16-row block (16 partial rows per 256 rows, as gemm.hip leaves them:
+        // launch_reduce_slabs(cs_part, N, ceil(M / 256) * 16, ...) finishes the bias gradient); rows past M contribute zeros
+        const uint64_t key = stlt_drop_key(a.epi.dr, a.epi.site);
+        const bool row_ok = row < a.M;
+        const int srow = row_ok ? row : 0;
+        const uint64_t drow = a.epi.drop_rows ? (uint64_t)a.epi.drop_rows[srow] : (uint64_t)srow;
+        const float* urow = a.R + (int64_t)srow * a.ldr + col0;
+        float* yrow = a.Y + (int64_t)srow * a.ldy + col0;
+        float* cs_row = a.epi.cs_part + (size_t)(tm * 8 + rb) * (size_t)a.N + col0;
+        const bool pad_blocks = tm == a.tiles_m - 1 && (tm & 1) == 0;  // a last tile that is the first half of a 256-row group: zero the other half's partial rows
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bool col_ok = col0 + 16 * t < a.N;
+          f32x4 val = {0.f, 0.f, 0.f, 0.f};
+          if (row_ok && col_ok) {
+            val = gelu_bwd4(acc[t], *reinterpret_cast<const f32x4*>(urow + 16 * t), a.epi, key, drow * (uint64_t)a.N + (uint64_t)(col0 + 16 * t));
+            *reinterpret_cast<f32x4*>(yrow + 16 * t) = val;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {  // over the 16 lanes that share lane >> 4 (= the wave's 16 rows)
+            float x = val[j];
+            x += __shfl_xor(x, 1, 64);
+            x += __shfl_xor(x, 2, 64);
+            x += __shfl_xor(x, 4, 64);
+            x += __shfl_xor(x, 8, 64);
+            val[j] = x;
+          }
+          if (eli == 0 && col_ok) {
+            *reinterpret_cast<f32x4*>(cs_row + 16 * t) = val;
+            if (pad_blocks) *reinterpret_cast<f32x4*>(cs_row + (size_t)8 * a.N + 16 * t) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      } else if (row < a.M) {
         float* yrow = a.Y + (int64_t)row * a.ldy + col0;
         if (ADD) {
           const float* rrow = a.R + (int64_t)row * a.ldr + col0;
@@ -292,6 +327,7 @@ int launch16_as(const Gemm16Args& a, hipStream_t s) {
 
 template <int NT>
 int launch16_nt(const Gemm16Args& a, int act, bool add, bool wkn, hipStream_t s) {
+  if (wkn && act == STLT_ACT_GELU_BWD) return launch16_as<NT, STLT_ACT_GELU_BWD, false, true>(a, s);
   if (wkn) return add ? launch16_as<NT, STLT_ACT_NONE, true, true>(a, s) : launch16_as<NT, STLT_ACT_NONE, false, true>(a, s);
   if (add) return launch16_as<NT, STLT_ACT_NONE, true, false>(a, s);
   if (act == STLT_ACT_GELU) return launch16_as<NT, STLT_ACT_GELU, false, false>(a, s);
@@ -319,16 +355,19 @@ constexpr int NT_CHOICES[] = {3, 4, 6, 8, 9, 12};
 double est16_us(int64_t M, int64_t N, int64_t K, int nt, int64_t cus, bool wkn = false) {
   const int64_t tiles = ((M + QM - 1) / QM) * ((N + 16 * nt - 1) / (16 * nt));
   const int64_t rounds = (tiles + cus - 1) / cus;
-  const double step = 2.0 * QM * 16.0 * nt * QK / 0.54e6 * (wkn ? 1.38 : 1.0);
+  // the input-gradient build gathers its [k][n] fragments with ds_read_b32: x 1.38 per k-step on narrow tiles, less on wide ones (fitted to
+  // the *_dx rows of profiles/round4_gemm16_shapes.txt)
+  const double wkn_cost = nt <= 4 ? 1.38 : (nt == 6 ? 1.3 : (nt == 8 ? 1.2 : (nt == 9 ? 1.15 : 1.08)));
+  const double step = 2.0 * QM * 16.0 * nt * QK / 0.54e6 * (wkn ? wkn_cost : 1.0);
   return (double)rounds * ((double)(K / QK) * step + 7.0) + 1.0;
 }
 // gemm.hip's launch: 256 x 128 tiles at 3.62 us per k-step; whole-tile rounds when they fill >= 0.9 of the last round, else equal
 // k-step shares (stream-K) + the fixed cost of the partial tiles and the fix-up launch (24 us + 0.1 us per tile below one round,
 // ~30 us for the tail of a longer launch)
-double est_big_us(int64_t M, int64_t N, int64_t K, int64_t cus) {
+double est_big_us(int64_t M, int64_t N, int64_t K, int64_t cus, bool nn = false) {  // nn: the input-gradient (NN) build, ~6 % slower per k-step
   const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128);
   const int64_t rounds = (tiles + cus - 1) / cus;
-  const double step = 3.62, nk = (double)(K / QK);
+  const double step = nn ? 3.85 : 3.62, nk = (double)(K / QK);
   const double fill = (double)tiles / (double)(rounds * cus);
   if (fill >= 0.9) return (double)rounds * (nk * step + 10.0);
   return (double)tiles * nk / (double)cus * step + (tiles < cus ? 24.0 + 0.1 * (double)tiles : 30.0);
@@ -363,7 +402,8 @@ int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw
   }
   if (best == 0) return 0;
   if (mode == 1) return best;
-  return best_us < 0.97 * est_big_us(M, N, K, cus) ? best : 0;
+  // forward: the small tiles must win by 3 %; input gradient: a tie goes to the small tiles (no fix-up launch beside the side stream's products)
+  return best_us < (wkn ? 1.03 : 0.97) * est_big_us(M, N, K, cus, wkn) ? best : 0;
 }
 
 // Estimated duration (us) of the nn.Linear forward launch_linear would make for this shape: the faster of the two kernels' estimates
@@ -391,7 +431,7 @@ int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ld
   if (!x || !w || !y) return stlt_set_error(STLT_EINVAL, "gemm16: null pointer");
   if (ldx < K || ldw < K || ldy < N || (r && ldr < N) || ldy % 4 != 0 || (r && ldr % 4 != 0))
     return stlt_set_error(STLT_EINVAL, "gemm16: bad leading dimension (ldx=%lld ldw=%lld ldy=%lld ldr=%lld)", (long long)ldx, (long long)ldw, (long long)ldy, (long long)ldr);
-  Gemm16Args a;
+  Gemm16Args a{};
   a.X = x; a.W = w; a.bias = bias; a.R = r; a.Y = y;
   a.ldx = ldx; a.ldw = ldw; a.ldr = ldr; a.ldy = ldy;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
@@ -407,8 +447,11 @@ int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ld
 // C (rows, k_in; ldc) = dY (rows, n_out; ld_dy) · W (n_out, k_in) (+ R): the input gradient of a Linear on the small-tile kernel, W read
 // as it lies (WKN build).  *taken = false: the product stays on gemm.hip's NN kernel (shape not taken, or estimated slower).
 int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
-                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_nt) {
+                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_nt, const StltGemmEpi* gelu_bwd) {
+  // gelu_bwd != null: the FFN hidden gradient in the epilogue — c = drop(dy·w) ∘ gelu'(r) with r the pre-activation (not added), and the
+  // column sums of c left in gelu_bwd->cs_part (16 partial rows per 256 rows; train.hip: stlt_ffn_hidden_backward_fused)
   *taken = false;
+  if (gelu_bwd && (!r || !gelu_bwd->cs_part)) return stlt_set_error(STLT_EINVAL, "gemm16 (GELU backward): the pre-activation and a column-sum buffer are required");
   int nt = force_nt;
   if (nt == 0) nt = stlt_gemm16_choice(rows, k_in, n_out, ld_dy, k_in, true);
   else if (rows <= 0 || k_in <= 0 || n_out < 2 * QK || n_out % QK != 0 || k_in % 4 != 0 || ld_dy % 4 != 0 || rows > 0x3fffff00LL || k_in > 0x3fffff00LL ||
@@ -417,7 +460,8 @@ int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int
   if (nt == 0) return 0;
   if (!dy || !w || !c) return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): null pointer");
   if (ld_dy < n_out || ldc < k_in || (r && ldr < k_in) || ldc % 4 != 0 || (r && ldr % 4 != 0)) return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): bad leading dimension");
-  Gemm16Args a;
+  Gemm16Args a{};
+  if (gelu_bwd) a.epi = *gelu_bwd;
   a.X = dy; a.W = w; a.bias = nullptr; a.R = r; a.Y = c;
   a.ldx = ld_dy; a.ldw = k_in; a.ldr = ldr; a.ldy = ldc;
   a.M = (int)rows; a.N = (int)k_in; a.K = (int)n_out;
@@ -427,5 +471,5 @@ int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)rows * (double)k_in * (double)n_out);
   *taken = true;
-  return launch16_any(nt, a, STLT_ACT_NONE, r != nullptr, true, s);
+  return launch16_any(nt, a, gelu_bwd ? STLT_ACT_GELU_BWD : STLT_ACT_NONE, r != nullptr && !gelu_bwd, true, s);
 }

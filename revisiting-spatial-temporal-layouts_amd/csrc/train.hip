@@ -277,7 +277,9 @@ int stlt_ffn_hidden_backward_fused(const float* df, const float* lin2_w, const f
   if (!fused || !g_lin1_b || !cs_part || d % 32 != 0 || stlt_split_bf16_takes(rows, 4 * d, d, d, d)) return 0;
   *taken = true;
   const StltGemmEpi epi{dr, site, nullptr, cs_part};
-  if (int e = launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi)) return e;
+  bool small = false;  // under-filled launches (the fusion models' 2048 / 2112-row blocks): whole small tiles with the same epilogue (gemm16.hip)
+  if (int e = launch_input_grad_gemm16(df, d, lin2_w, d, 4 * d, u, 4 * d, du, 4 * d, rows, s, &small, 0, &epi)) return e;
+  if (!small) { if (int e = launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi)) return e; }
   return launch_reduce_slabs(cs_part, 4 * d, (int)((rows + 255) / 256 * 16), g_lin1_b, 4 * d, 1, s);
 }
 namespace {
@@ -287,7 +289,9 @@ static int ffn_hidden_backward(const float* df, const float* lin2_w, const float
   if (fused && g_lin1_b && d % 32 == 0 && !(sc.sk && stlt_split_bf16_takes(rows, 4 * d, d, d, d))) {  // (the split-bf16 product has no GELU-backward epilogue)
     float* cs = RED(sc);
     const StltGemmEpi epi{dr, site, drop_rows, cs};
-    TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi));
+    bool small = false;  // the temporal tower at the reference's default batch (2048 rows): whole small tiles with the same epilogue (gemm16.hip)
+    TRY(launch_input_grad_gemm16(df, d, lin2_w, d, 4 * d, u, 4 * d, du, 4 * d, rows, s, &small, 0, &epi));
+    if (!small) TRY(launch_gemm(0, 1, df, d, lin2_w, 4 * d, nullptr, u, 4 * d, du, 4 * d, 0, rows, 4 * d, d, 1, STLT_ACT_GELU_BWD, s, &epi));
     return launch_reduce_slabs(cs, 4 * d, (int)((rows + 255) / 256 * 16), g_lin1_b, 4 * d, 1, s);
   }
   TRY(dx_product(df, d, lin2_w, d, 4 * d, nullptr, 0, du, 4 * d, rows, sc, s));  // dh

@@ -604,6 +604,51 @@ def test_linear_dispatch_picks_small_tiles_for_the_under_filled_products(pkg):
         assert torch.equal(pkg.ops.linear(x, w, b, act=1), pkg.ops.linear_small(x, w, b, tc, act=1))
 
 
+@pytest.mark.parametrize("M", [2048, 2112, 1088, 4096, 300])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_ffn_block_backward_gelu_epilogue_on_small_tiles(pkg, M, p):
+    """The FFN hidden gradient du = drop(df·W2) ∘ gelu'(u) with its column sums (lin1_b's gradient) rides in the dX product's epilogue;
+    for under-filled launches that product now runs on gemm16.hip's whole small tiles (round 4) instead of stream-K + a fix-up launch.
+    Both builds draw the same masks: every gradient of the block must agree between them to rounding, and — without dropout — with
+    torch autograd in fp64.  2112 rows: a last 128-row tile that is the first half of a 256-row group (its partner's partial rows of the
+    column-sum buffer are zero-filled); 300 rows: three tile rows, the last one ragged."""
+    d = 768
+    lib = pkg._lib.load()
+    if os.environ.get("STLT_GEMM16") != "0":
+        assert lib.stlt_input_grad_small_choice(2048, d, 4 * d) > 0 and lib.stlt_input_grad_small_choice(14336, d, 4 * d) == 0
+    x, g = _rand(M, d, seed=1), _rand(M, d, seed=2)
+    w1, b1 = _rand(4 * d, d, seed=3, scale=1 / math.sqrt(d)), _rand(4 * d, seed=4, scale=0.1)
+    w2, b2 = _rand(d, 4 * d, seed=5, scale=1 / math.sqrt(4 * d)), _rand(d, seed=6, scale=0.1)
+    ln_w, ln_b = 1 + 0.1 * _rand(d, seed=7), 0.1 * _rand(d, seed=8)
+    host = (x, w1, b1, w2, b2, ln_w, ln_b)
+
+    def run(mode):
+        pkg.ops.set_gemm_small_tiles(mode)
+        try:
+            torch.manual_seed(5)
+            leaves = [t.clone().to(DEV).requires_grad_(True) for t in host]
+            out = pkg.ops.FfnBlockFn.apply(leaves[0], 1e-5, pkg._lib.ACT_GELU, True, p, *leaves[1:])
+            out.backward(g.to(DEV))
+            return [out.detach()] + [t.grad for t in leaves]
+        finally:
+            pkg.ops.set_gemm_small_tiles(-1)
+
+    small, large = run(-1), run(0)
+    names = ("out", "dx", "dw1", "db1", "dw2", "db2", "dln_w", "dln_b")
+    for a, b, name in zip(small, large, names):
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() / scale <= 2e-5, name
+    assert all(torch.equal(a, b) for a, b in zip(small, run(-1)))  # bitwise reproducible
+    if p == 0.0:
+        r = [t.double().requires_grad_(True) for t in host]
+        hid = torch.nn.functional.gelu(r[0] @ r[1].t() + r[2])
+        ref = torch.nn.functional.layer_norm(r[0] + hid @ r[3].t() + r[4], (d,), r[5], r[6], 1e-5)
+        ref.backward(g.double())
+        for a, want, name in zip(small[1:], r, names[1:]):
+            scale = max(want.grad.abs().max().item(), 1e-6)
+            assert (a.cpu().double() - want.grad).abs().max().item() / scale <= 1e-4, name
+
+
 def _mhsa_case(S, L, H, seed):
     d = 64 * H
     x = _rand(S, L, d, seed=seed, scale=1.5)

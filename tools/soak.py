@@ -110,6 +110,43 @@ def mhsa_cases(reps):
     return bad
 
 
+def block_cases(reps):
+    """The fusion models' block-level calls at their row counts: forward + backward of a feed-forward block (the GELU backward rides in the
+    small-tile input-gradient product's epilogue) and of self- / cross-attention blocks, same seed every repetition."""
+    bad = 0
+    d, H = 768, 12
+    for S, Lq in ((64, 32), (64, 33)):
+        M = S * Lq
+        x, g = rnd(S, Lq, d, seed=1), rnd(S, Lq, d, seed=2)
+        c = rnd(S, 33, d, seed=3)
+        w1, b1 = rnd(4 * d, d, seed=3, scale=1 / math.sqrt(d)), rnd(4 * d, seed=4, scale=0.1)
+        w2, b2 = rnd(d, 4 * d, seed=5, scale=1 / math.sqrt(4 * d)), rnd(d, seed=6, scale=0.1)
+        w_in, b_in = rnd(3 * d, d, seed=7, scale=1 / math.sqrt(d)), rnd(3 * d, seed=8, scale=0.1)
+        w_o, b_o = rnd(d, d, seed=9, scale=1 / math.sqrt(d)), rnd(d, seed=10, scale=0.1)
+        ln_w, ln_b = 1 + 0.1 * rnd(d, seed=11), 0.1 * rnd(d, seed=12)
+
+        def ffn():
+            torch.manual_seed(5)
+            leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, ln_w, ln_b)]
+            out = ops.FfnBlockFn.apply(leaves[0], 1e-5, L.ACT_GELU, True, 0.1, *leaves[1:])
+            out.backward(g)
+            return [out.detach()] + [t.grad for t in leaves]
+
+        def attn(cross):
+            def f():
+                torch.manual_seed(6)
+                leaves = [t.clone().requires_grad_(True) for t in (x, c, w_in, b_in, w_o, b_o, ln_w, ln_b)]
+                out = ops.AttnBlockFn.apply(leaves[0], leaves[1] if cross else None, None, not cross, H, 1e-5, 0.1, *leaves[2:])
+                out.backward(g)
+                return [out.detach()] + [t.grad for i, t in enumerate(leaves) if cross or i != 1]
+            return f
+
+        bad += loop(f"ffn block fwd+bwd {M} rows p=0.1", ffn, max(reps // 4, 4))
+        bad += loop(f"self-attention block fwd+bwd {M} rows p=0.1", attn(False), max(reps // 4, 4))
+        bad += loop(f"cross-attention block fwd+bwd {M} x {S * 33} rows p=0.1", attn(True), max(reps // 4, 4))
+    return bad
+
+
 def train_cases(reps):
     bad = 0
     for name, B in (("cfg2", 64), ("cfg2p", 16), ("cfg1", 256)):
@@ -152,7 +189,7 @@ def forward_cases(reps):
     return bad
 
 
-CASES = {"gemm16": gemm16_cases, "gemm": gemm_cases, "mhsa": mhsa_cases, "train": train_cases, "forward": forward_cases}
+CASES = {"gemm16": gemm16_cases, "gemm": gemm_cases, "mhsa": mhsa_cases, "blocks": block_cases, "train": train_cases, "forward": forward_cases}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
