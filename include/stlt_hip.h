@@ -91,7 +91,8 @@ int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_
                           int64_t ld_dx, int64_t M, int tile_cols, stlt_stream_t stream);
 int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in);  /* the tile width the routing picks for that input gradient (0: large tiles) */
 /* Process-wide routing switch: -1 = by the launch-time estimate (default; STLT_GEMM16 in the environment is the initial value),
- * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements). */
+ * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements), -2 = back to the
+ * initial value (what a test or tool that switched it should leave behind). */
 int stlt_set_gemm_small_tiles(int mode);
 
 /* Optional scratch for the calling thread's stlt_linear_fwd / stlt_gemm launches (torch's nn.Linear has no

@@ -380,8 +380,8 @@ double est_big_us(int64_t M, int64_t N, int64_t K, int64_t cus, bool nn = false)
 // launch-time estimates above decide.
 static int g_gemm16_mode = -2;  // -2: not read yet; -1: by estimate; 0: off; 1: every product the kernel can take
 int stlt_gemm16_set_mode(int mode) {
-  if (mode < -1 || mode > 1) return stlt_set_error(STLT_EINVAL, "small-tile products: mode -1 (by estimate), 0 (off) or 1 (always)");
-  g_gemm16_mode = mode;
+  if (mode < -2 || mode > 1) return stlt_set_error(STLT_EINVAL, "small-tile products: mode -1 (by estimate), 0 (off), 1 (always) or -2 (back to STLT_GEMM16 / the default)");
+  g_gemm16_mode = mode;  // -2: the next routing decision re-reads the environment
   return 0;
 }
 int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, bool wkn) {

@@ -113,7 +113,8 @@ def set_train_side_stream(on: bool) -> None:
 
 
 def set_gemm_small_tiles(mode: int) -> None:
-    """Routing of under-filled products to the small-tile kernel: -1 by estimate (default), 0 off, 1 always (stlt_set_gemm_small_tiles)."""
+    """Routing of under-filled products to the small-tile kernel: -1 by estimate (default), 0 off, 1 always, -2 back to the process's initial
+    setting (STLT_GEMM16 or the default) — what to restore after an A/B (stlt_set_gemm_small_tiles)."""
     L.check(L.load().stlt_set_gemm_small_tiles(int(mode)), "stlt_set_gemm_small_tiles")
 
 

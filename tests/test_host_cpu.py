@@ -111,6 +111,7 @@ def test_launch_time_dispatch_is_host_arithmetic(pkg):
     assert lib.stlt_set_gemm_small_tiles(0) == 0 and lib.stlt_linear_small_choice(2048, 768, 768) == 0
     assert lib.stlt_set_gemm_small_tiles(-1) == 0 and lib.stlt_linear_small_choice(2048, 768, 768) == 48
     assert lib.stlt_set_gemm_small_tiles(7) != 0
+    assert lib.stlt_set_gemm_small_tiles(-2) == 0  # back to the environment's / default setting
     # training scratch: sized for the second operand sets, refused above the category limit
     assert lib.stlt_train_scratch_bytes(64, 32, 7, 768, 4) > 0 and lib.stlt_train_scratch_bytes(64, 32, 7, 768, 129) == 0
 

@@ -631,7 +631,7 @@ def test_ffn_block_backward_gelu_epilogue_on_small_tiles(pkg, M, p):
             out.backward(g.to(DEV))
             return [out.detach()] + [t.grad for t in leaves]
         finally:
-            pkg.ops.set_gemm_small_tiles(-1)
+            pkg.ops.set_gemm_small_tiles(-2)  # back to the process's setting (a run with STLT_GEMM16=0 must stay on the large tiles)
 
     small, large = run(-1), run(0)
     names = ("out", "dx", "dw1", "db1", "dw2", "db2", "dln_w", "dln_b")

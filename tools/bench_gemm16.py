@@ -70,7 +70,7 @@ def main():
             pkg.ops.set_gemm_small_tiles(0)
             with pkg.ops.gemm_scratch(dev):
                 row["large_us"] = round(timed(lambda: pkg.ops.linear(x, w, b, act=act, out=y), a.iters), 1)
-            pkg.ops.set_gemm_small_tiles(-1)
+            pkg.ops.set_gemm_small_tiles(-2)
             best = None
             for tc in (48, 64, 96, 128, 144, 192):
                 us = round(timed(lambda: pkg.ops.linear_small(x, w, b, tc, act=act, out=y), a.iters), 1)

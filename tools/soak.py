@@ -53,7 +53,7 @@ def gemm16_cases(reps):
         with ops.gemm_scratch(DEV):
             ops.set_gemm_small_tiles(0)
             ref = ops.linear(x, w, b)       # the large-tile kernel
-            ops.set_gemm_small_tiles(-1)
+            ops.set_gemm_small_tiles(-2)
         tol = 3e-5 * math.sqrt(K) * max(1.0, ref.abs().max().item()) / 10
         for tc in (48, 64, 96, 128, 144, 192):
             bad += loop(f"gemm16 fwd {M}x{N}x{K} t{tc} bias", lambda: ops.linear_small(x, w, b, tc), reps, ref, tol)
@@ -86,7 +86,45 @@ def gemm_cases(reps):
                 if M % 32 == 0:
                     bad += loop(f"gemm stream-K dW {N}x{K} over {M} rows", lambda: ops.gemm(dy, x, trans_a=True, trans_b=True), reps)
         finally:
-            ops.set_gemm_small_tiles(-1)
+            ops.set_gemm_small_tiles(-2)
+    return bad
+
+
+def gemm_tiny_cases(reps):
+    """gemm.hip on the shapes of a 4-clip forward (896 / 128 / 4 rows): a handful of tiles, stream-K over a few dozen k-steps with
+    workgroups of ~4 k-steps each, segments of a single k-step, the fix-up launch."""
+    bad = 0
+    ops.set_gemm_small_tiles(0)
+    try:
+        for M in (4, 100, 128, 896, 1024):
+            for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (174, 768)):
+                x, w, b, r = rnd(M, K, seed=M + N), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3), rnd(M, N, seed=4)
+                plain = ops.linear(x, w, b)
+                tol = 3e-6 * math.sqrt(K) * max(1.0, plain.abs().max().item())
+                with ops.gemm_scratch(DEV):
+                    bad += loop(f"gemm tiny stream-K fwd {M}x{N}x{K}", lambda: ops.linear(x, w, b), reps, plain, tol)
+                    bad += loop(f"gemm tiny stream-K fwd+gelu {M}x{N}x{K}", lambda: ops.linear(x, w, b, act=1), max(reps // 2, 3))
+                    dy = rnd(M, N, seed=7)
+                    bad += loop(f"gemm tiny stream-K dX {M}x{N}->{K}", lambda: ops.gemm(dy, w, trans_b=True), max(reps // 2, 3))
+                    bad += loop(f"gemm tiny stream-K dX+R {M}x{N}->{K}", lambda: ops.gemm(dy, w, trans_b=True, add=x), max(reps // 2, 3))
+    finally:
+        ops.set_gemm_small_tiles(-2)
+    return bad
+
+
+def small_forward_cases(reps):
+    """The golden-sized forwards (2 - 8 clips): what the parity tests launch."""
+    bad = 0
+    for name, B in (("cfg2", 4), ("cfg1", 8), ("cfg2p", 3), ("cfg4", 2), ("refdef", 4)):
+        c = pkg.synth.CONFIGS[name]
+        m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+        m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234))
+        m.to(DEV).train(False)
+        batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(B, c["T"], c["N"], seed=0).items()}
+        for cls_only in (True, False):
+            m.backbone.cls_only_last_spatial = m.backbone.last_row_only_temporal = cls_only
+            with torch.no_grad():
+                bad += loop(f"forward {name} B={B} cls_only={cls_only}", lambda: m(batch)["stlt"], reps)
     return bad
 
 
@@ -189,7 +227,7 @@ def forward_cases(reps):
     return bad
 
 
-CASES = {"gemm16": gemm16_cases, "gemm": gemm_cases, "mhsa": mhsa_cases, "blocks": block_cases, "train": train_cases, "forward": forward_cases}
+CASES = {"gemm16": gemm16_cases, "gemm": gemm_cases, "gemm_tiny": gemm_tiny_cases, "small_forward": small_forward_cases, "mhsa": mhsa_cases, "blocks": block_cases, "train": train_cases, "forward": forward_cases}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
