@@ -56,14 +56,15 @@ int stlt_embed_fwd(const int64_t* categories, const float* boxes, const float* s
  * nn.TransformerEncoderLayer as configured at models.py:46-52,118-124; fc1/fc2 models.py:158-163).
  * y[m, n] = act( sum_k x[m*ldx + k] * w[n*K + k] + bias[n] ),  w is (N,K) row-major (torch (out,in)).
  * M, N arbitrary.  K % 32 == 0 (every hidden size the released checkpoints use): f32-input MFMA (v_mfma_f32_32x32x2_f32), fp32
- * accumulate.  Any other K (hidden sizes like 100 or 200, which configs.py:92-111 allows): the same product and epilogues on the
- * vector ALU (csrc/gemm_any.hip) — a compatibility path with the same tolerances, not a tuned one. */
+ * accumulate.  Any other K (hidden sizes like 100 or 200, which configs.py:92-111 allows): the same product and epilogues on
+ * csrc/gemm_any.hip (zero-filled tiles staged through LDS by ordinary loads) — a compatibility path with the same tolerances, not a
+ * tuned one. */
 int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias,
                     float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, stlt_stream_t stream);
 
 /* General product on the same kernel, used by the backward pass of nn.Linear (autograd of F.linear in the reference):
- *   c (M,N) = opA(a)·opB(b) [+ r]   with contraction length K (a multiple of 32 for the MFMA kernel; any other K runs on the vector
- *                                   ALU, n_split = 1 only)
+ *   c (M,N) = opA(a)·opB(b) [+ r]   with contraction length K (a multiple of 32 for the tuned kernel; any other K runs on the
+ *                                   fallback of csrc/gemm_any.hip, n_split = 1 only)
  *   transA=0: a is (M,K) row-major, lda;  transA=1: a is (K,M) row-major, lda   (dW = dY^T·X)
  *   transB=0: b is (N,K) row-major, ldb;  transB=1: b is (K,N) row-major, ldb   (dX = dY·W)
  * r (nullable, ldr) is added in the epilogue (residual gradient).  n_split > 1 splits the contraction: split s writes

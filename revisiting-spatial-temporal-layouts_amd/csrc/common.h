@@ -170,7 +170,7 @@ __device__ __forceinline__ f32x4 gelu_bwd4(f32x4 g, f32x4 u, const StltGemmEpi& 
   }
   return o;
 }
-// gemm_any.hip: launch_gemm's fallback for contraction lengths that are not multiples of 32 (vector ALU, same layouts and epilogues)
+// gemm_any.hip: launch_gemm's fallback for contraction lengths that are not multiples of 32 (tiles staged by ordinary loads, same layouts and epilogues)
 int launch_gemm_any(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, const float* r,
                     int64_t ldr, float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t s);
 // gemm_bf16x3.hip: the forward product on the BF16 matrix cores with three-piece operands (opt-in); *taken = launched

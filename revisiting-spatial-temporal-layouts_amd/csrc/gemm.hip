@@ -1118,7 +1118,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   }
   if (M < 0 || N <= 0 || K <= 0) return stlt_set_error(STLT_EINVAL, "gemm: bad shape (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
   if (K % BK != 0 || lda % 4 != 0 || ldb % 4 != 0) {  // a partial k-slab / rows that are not 16-byte aligned cannot be staged by LDS-DMA:
-    // the vector-ALU kernel of gemm_any.hip (hidden sizes that are not multiples of 32)
+    // the fallback kernel of gemm_any.hip (hidden sizes that are not multiples of 32)
     if (n_split != 1 || act == STLT_ACT_GELU_BWD)
       return stlt_set_error(STLT_EINVAL, "gemm: a split product / the fused GELU backward needs K=%lld to be a multiple of %d and pitches that are multiples of 4", (long long)K, BK);
     return launch_gemm_any(transA, transB, a, lda, b, ldb, bias, r, ldr, c, ldc, M, N, K, act, s);

@@ -1,77 +1,105 @@
 // Products whose contraction length is not a multiple of 32 (hidden sizes like 100 or 200: the reference takes any
 // hidden_size % num_attention_heads == 0, src/modelling/configs.py:92-111; every released checkpoint is 768).  The MFMA kernels of gemm.hip /
 // gemm16.hip stage 32-wide k-slabs by LDS-DMA, which cannot mask a partial slab; this file is the cold path launch_gemm falls back to:
-// a 64 x 64 tile per workgroup through LDS with bounds-checked loads, FMA on the vector ALU, the same epilogues (bias, exact-erf GELU /
+// a 64 x 64 tile per workgroup through LDS with bounds-checked (zero-filled) loads, v_mfma_f32_16x16x4_f32 on the LDS image, the same epilogues (bias, exact-erf GELU /
 // ReLU, add-source) and the same three operand layouts (forward x·Wᵀ, input gradient dY·W, weight gradient dYᵀ·X).  One fixed summation
 // order per output element: bitwise reproducible.
+#include <cstdint>
 #include "common.h"
 
 namespace {
 
-constexpr int GA_T = 64, GA_K = 16;
+constexpr int GA_T = 64, GA_K = 32;
 
 // C (M, N) = opA(A)·opB(B) [+ bias] [act] [+ R].  TA: A stored (K, M) (else (M, K)); TB: B stored (K, N) (else (N, K)).
-template <bool TA, bool TB>
+// 4 waves, each a 32 x 32 quadrant of the tile = 2 x 2 v_mfma_f32_16x16x4_f32 blocks: lane (li = lane & 15, lg = lane >> 4) feeds
+// A[row li][k lg] and B[k lg][col li] of a block and holds D[rows 4 lg .. 4 lg + 3][col li].
+// four consecutive floats at p, of which the first `n` (0 ... 4) exist; VEC: p is 16-byte aligned
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4_guarded(const float* p, int n) {
+  if (n >= 4 && VEC) return *reinterpret_cast<const f32x4*>(p);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (n > 0) v[0] = p[0];
+  if (n > 1) v[1] = p[1];
+  if (n > 2) v[2] = p[2];
+  if (n > 3) v[3] = p[3];
+  return v;
+}
+// one operand tile into its k-major LDS image img[k][row] (zeros beyond the matrix and beyond K).  T = false: the operand is stored
+// [row][k] — a lane takes four consecutive k of one row (lanes = consecutive rows: conflict-free LDS writes; a row's 128-byte line is
+// used up by the eight lane groups); T = true: stored [k][row] — four consecutive rows of one k, one 16-byte LDS write.
+template <bool T, bool VEC>
+__device__ __forceinline__ void stage_tile(float (*img)[GA_T + 4], const float* __restrict__ src, int64_t ld, int64_t row0, int rows, int k0, int K, int tid) {
+#pragma unroll
+  for (int e = 0; e < (GA_T * GA_K / 4) / 256; ++e) {
+    const int idx = tid + 256 * e;
+    if (!T) {
+      const int rr = idx & 63, kq = (idx >> 6) * 4;
+      const int64_t g = row0 + rr;
+      const int left = K - (k0 + kq);
+      const f32x4 v = g < rows ? load4_guarded<VEC>(src + g * ld + k0 + kq, left < 0 ? 0 : left) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) img[kq + j][rr] = v[j];
+    } else {
+      const int kk = idx >> 4, rq = (idx & 15) * 4;
+      const int64_t left = (int64_t)rows - (row0 + rq);
+      const f32x4 v = k0 + kk < K ? load4_guarded<VEC>(src + (int64_t)(k0 + kk) * ld + row0 + rq, left < 0 ? 0 : (left > 4 ? 4 : (int)left)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&img[kk][rq]) = v;
+    }
+  }
+}
+
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_any_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
                                                        const float* __restrict__ bias, const float* r, int64_t ldr,
                                                        float* c, int64_t ldc, int M, int N, int K, int act) {  // r may alias c (accumulation)
-  __shared__ float As[GA_K][GA_T + 4], Bs[GA_K][GA_T + 4];
+  __shared__ __attribute__((aligned(16))) float As[GA_K][GA_T + 4], Bs[GA_K][GA_T + 4];
   const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int64_t m0 = (int64_t)blockIdx.x * GA_T, n0 = (int64_t)blockIdx.y * GA_T;
-  float acc[4][4];
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < K; k0 += GA_K) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * e;  // 1024 elements of each operand tile
-      {
-        const int mm = TA ? (idx & 63) : (idx >> 4), kk = TA ? (idx >> 6) : (idx & 15);
-        const int64_t gm = m0 + mm;
-        const int gk = k0 + kk;
-        As[kk][mm] = (gm < M && gk < K) ? (TA ? a[(int64_t)gk * lda + gm] : a[gm * lda + gk]) : 0.f;
-      }
-      {
-        const int nn = TB ? (idx & 63) : (idx >> 4), kk = TB ? (idx >> 6) : (idx & 15);
-        const int64_t gn = n0 + nn;
-        const int gk = k0 + kk;
-        Bs[kk][nn] = (gn < N && gk < K) ? (TB ? b[(int64_t)gk * ldb + gn] : b[gn * ldb + gk]) : 0.f;
-      }
-    }
+    stage_tile<TA, VEC>(As, a, lda, m0, M, k0, K, tid);
+    stage_tile<TB, VEC>(Bs, b, ldb, n0, N, k0, K, tid);
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < GA_K; ++kk) {
-      float av[4], bv[4];
+    for (int k4 = 0; k4 < GA_K / 4; ++k4) {
+      float av[2], bv[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
+      for (int i = 0; i < 2; ++i) av[i] = As[4 * k4 + lg][wm + 16 * i + li];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
+      for (int j = 0; j < 2; ++j) bv[j] = Bs[4 * k4 + lg][wn + 16 * j + li];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t gm = m0 + ty * 4 + i;
-    if (gm >= M) continue;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t gn = n0 + tx * 4 + j;
+    for (int j = 0; j < 2; ++j) {
+      const int64_t gn = n0 + wn + 16 * j + li;
       if (gn >= N) continue;
-      float v = acc[i][j];
-      if (bias) v += bias[gn];
-      if (act == STLT_ACT_GELU) v = gelu_epilogue(v);
-      else if (act == STLT_ACT_RELU) v = fmaxf(v, 0.f);
-      if (r) v += r[gm * ldr + gn];
-      c[gm * ldc + gn] = v;
+      const float bn = bias ? bias[gn] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t gm = m0 + wm + 16 * i + 4 * lg + q;
+        if (gm >= M) continue;
+        float v = acc[i][j][q] + bn;
+        if (act == STLT_ACT_GELU) v = gelu_epilogue(v);
+        else if (act == STLT_ACT_RELU) v = fmaxf(v, 0.f);
+        if (r) v += r[gm * ldr + gn];
+        c[gm * ldc + gn] = v;
+      }
     }
-  }
 }
 
 }  // namespace
@@ -90,7 +118,10 @@ int launch_gemm_any(int transA, int transB, const float* a, int64_t lda, const f
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
   const dim3 grid((unsigned)gy, (unsigned)gx), block(256);
-#define GA_LAUNCH(TAV, TBV) hipLaunchKernelGGL((gemm_any_kernel<TAV, TBV>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, (int)M, (int)N, (int)K, act)
+  // 16-byte loads where every row start is 16-byte aligned (pitches that are multiples of 4 floats: hidden sizes that are multiples of 4)
+  const bool vec = lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0;
+#define GA_LAUNCH(TAV, TBV) do { if (vec) hipLaunchKernelGGL((gemm_any_kernel<TAV, TBV, true>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, (int)M, (int)N, (int)K, act); \
+  else hipLaunchKernelGGL((gemm_any_kernel<TAV, TBV, false>), grid, block, 0, s, a, lda, b, ldb, bias, r, ldr, c, ldc, (int)M, (int)N, (int)K, act); } while (0)
   if (transA) GA_LAUNCH(true, true);
   else if (transB) GA_LAUNCH(false, true);
   else GA_LAUNCH(false, false);

@@ -41,7 +41,7 @@ def test_linear_strided_rows_and_no_bias(pkg):
 
 
 def test_linear_with_a_contraction_length_that_is_not_a_multiple_of_32(pkg):
-    """Round 4: such products run on the vector-ALU fallback (gemm_any.hip) instead of being rejected."""
+    """Round 4: such products run on the fallback kernel (gemm_any.hip) instead of being rejected."""
     x, w = _rand(4, 20, seed=1), _rand(8, 20, seed=2)
     y = pkg.ops.linear(x.to(DEV), w.to(DEV), None).cpu()
     assert (y.double() - x.double() @ w.double().t()).abs().max().item() <= 2e-5
