@@ -335,6 +335,7 @@ def side_fusion_train_leg(pkg, torch, dev, B, steps, warmup):
     torch.cuda.synchronize(dev)
     sec = (time.perf_counter() - t0) / steps
     pkg.ops.prof_take_gemm_flops()
+    side_was = pkg.ops.get_train_side_stream()
     pkg.ops.set_train_side_stream(False)  # per-kernel events: with the weight gradients on the side stream the kernels' spans overlap and their sum is not the step
     pkg.ops.prof_enable(True)
     try:
@@ -345,7 +346,7 @@ def side_fusion_train_leg(pkg, torch, dev, B, steps, warmup):
         gflops = pkg.ops.prof_take_gemm_flops() / steps
     finally:
         pkg.ops.prof_enable(False)
-        pkg.ops.set_train_side_stream(True)
+        pkg.ops.set_train_side_stream(side_was)  # what the run started with (STLT_TRAIN_DW_STREAM=0 A/B runs keep one stream)
     k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -376,6 +377,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
     torch.cuda.synchronize(dev)
     sec = (time.perf_counter() - t0) / steps
     pkg.ops.prof_take_gemm_flops()
+    side_was = pkg.ops.get_train_side_stream()
     pkg.ops.set_train_side_stream(False)  # per-kernel events: with the weight gradients on the side stream the kernels' spans overlap and their sum is not the step
     pkg.ops.prof_enable(True)
     try:
@@ -386,7 +388,7 @@ def side_train_leg(pkg, torch, dev, config, B, steps, warmup):
         gflops = pkg.ops.prof_take_gemm_flops() / steps
     finally:
         pkg.ops.prof_enable(False)
-        pkg.ops.set_train_side_stream(True)
+        pkg.ops.set_train_side_stream(side_was)  # what the run started with (STLT_TRAIN_DW_STREAM=0 A/B runs keep one stream)
     k_ms = {k: (ms / steps, int(n / steps)) for k, (ms, n) in prof.items()}
     gemm_ms, gemm_n = k_ms.get("gemm", (0.0, 0))
     tf = gflops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -471,6 +473,7 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin=None):
     k_ms, gflops = {}, 0.0
     try:
         pkg.ops.prof_take_gemm_flops()
+        side_was = pkg.ops.get_train_side_stream()
         pkg.ops.set_train_side_stream(False)  # per-kernel events: on the side stream the kernels' spans overlap and their sum is not the step
         pkg.ops.prof_enable(rank == 0)
         try:
@@ -483,7 +486,7 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin=None):
                 k_ms = {k: (ms / args.steps, int(n / args.steps)) for k, (ms, n) in prof.items()}
         finally:
             pkg.ops.prof_enable(False)
-            pkg.ops.set_train_side_stream(True)
+            pkg.ops.set_train_side_stream(side_was)  # what the run started with (STLT_TRAIN_DW_STREAM=0 A/B runs keep one stream)
     except Exception as exc:  # the roofline leg must never cost the main line
         if world > 1:
             raise  # a rank that stops stepping would leave the others waiting in the all-reduce
@@ -880,6 +883,10 @@ def main():
                             # utils/parser.py:62-66): the released checkpoints' 32 + 1 frames x 8 slots, and the parser's default 16 + 1 x 5
                             ("cfg2p", lambda: side_forward_leg(pkg, torch, dev, "cfg2p", B, 8, 2, split_bf16=False)),
                             ("ref_default", lambda: side_forward_leg(pkg, torch, dev, "refdef", B, 8, 2, split_bf16=False)),
+                            # ... and the same two layouts at the reference's own batch size (--batch_size 64, utils/parser.py:92-96): the
+                            # operating point the reference trains and infers at, where launches are under-filled
+                            ("cfg2p_b64", lambda: side_forward_leg(pkg, torch, dev, "cfg2p", 64, 30, 10, split_bf16=False)),
+                            ("ref_default_b64", lambda: side_forward_leg(pkg, torch, dev, "refdef", 64, 30, 10, split_bf16=False)),
                             ("cfg5", lambda: side_fusion_leg(pkg, torch, dev, 256, 5, 2)),
                             ("cfg5_train", lambda: side_fusion_train_leg(pkg, torch, dev, 64, 5, 2))):
                 try:

@@ -15,8 +15,14 @@
  *   - asynchronous on `stream` (a hipStream_t passed as void*); no implicit synchronisation — the one exception
  *     is STLT_FLAG_SKIP_PADDING, which reads two row counts back (one stream synchronisation per call); everything
  *     else is a fixed launch sequence that can be captured in a hipGraph.
- *   - per-thread state only: the error string and the scratch lent with stlt_gemm_set_scratch (both thread-local);
- *     process-wide there are only write-once caches of device properties.  One model per process is the intended use.
+ *   - per-thread state: the error string and the scratch lent with stlt_gemm_set_scratch (both thread-local).
+ *     Process-wide: write-once caches of device properties; the routing switches (stlt_set_gemm_small_tiles,
+ *     stlt_set_gemm_split_bf16, stlt_set_train_side_stream: plain integers, set them before the calls they steer, not
+ *     concurrently with them); and ONE side stream + event set per device for stlt_train_backward's weight-gradient
+ *     products, owned by a call from its first fork to its join: concurrent sweeps of several host threads on the same
+ *     device are serialised on a per-device mutex for that span (host-side enqueue only; different devices do not
+ *     contend), and every exit path of the call — error returns included — joins the side stream back into `stream`.
+ *     One model per process is the intended use.
  *   - plain C: this header compiles as C99 and as C++ (tests/test_host_cpu.py builds a C client against the library).
  */
 #ifndef STLT_HIP_H
@@ -312,8 +318,10 @@ int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, cons
 #define STLT_TRAIN_MAX_CATEGORIES 128
 /* stlt_train_backward runs the weight-gradient products (off the dX chain) on a second, library-owned stream per device, forked
  * from and joined to the caller's stream with events inside the call; 0 keeps every launch on the caller's stream (A/B runs, per-kernel
- * event timing without overlap).  Process-wide; STLT_TRAIN_DW_STREAM in the environment is the initial value (default on). */
+ * event timing without overlap).  Process-wide; STLT_TRAIN_DW_STREAM in the environment is the initial value (default on);
+ * on < 0 goes back to that value.  stlt_get_train_side_stream returns the setting in force (1 / 0), so that a caller can restore it. */
 int stlt_set_train_side_stream(int on);
+int stlt_get_train_side_stream(void);
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal);
 size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_categories);
 /* flags: 0, or STLT_FLAG_SKIP_PADDING (the same value in both calls of a step): forward and reverse sweep run over the

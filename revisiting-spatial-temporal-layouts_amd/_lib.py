@@ -92,6 +92,7 @@ SIGNATURES = {
     "stlt_input_grad_small_choice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "stlt_set_gemm_small_tiles": (C.c_int, [C.c_int]),
     "stlt_set_train_side_stream": (C.c_int, [C.c_int]),
+    "stlt_get_train_side_stream": (C.c_int, []),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
     "stlt_weight_grad_group": (C.c_int, [_vp, C.c_int, _vp]),

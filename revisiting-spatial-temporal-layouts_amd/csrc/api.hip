@@ -465,6 +465,10 @@ static int encoder_tail_rows(const stlt_layer_params& lp, int64_t d, const float
 static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* workspace, const WsLayout& w, float* h0, float* out_btd,
                           hipStream_t s) {
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H;
+  // head dims other than 64 run the ragged attention on attn_any.hip, whose forward holds at most 1024 keys of a segment (a frame's N
+  // slots, a clip's T frames) in LDS: longer segments are refused here instead of being truncated in the kernel
+  if (d / H != 64 && (N > 1024 || T > 1024))
+    return stlt_set_error(STLT_EINVAL, "skip-padding with head dim %lld (not 64) takes at most 1024 object slots / frames per segment (N=%lld, T=%lld)", (long long)(d / H), (long long)N, (long long)T);
   char* base = (char*)workspace;
   float* x = (float*)(base + w.x);
   float* x1 = (float*)(base + w.x1);

@@ -416,7 +416,7 @@ int launch_attn_ragged(const float* qkv, const int* seg_start, const int* seg_en
   if (dh != DH) {
     StltProfScope ps(kid, s);
     const int64_t d = H * dh;
-    return launch_attn_any_fwd(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, nullptr, seg_start, seg_end, causal, M, 256, 256, H, dh, ctx, s, dr, site);  // segments: frames / clips, at most the position table's 256 rows
+    return launch_attn_any_fwd(qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, nullptr, seg_start, seg_end, causal, M, 256, 256, H, dh, ctx, s, dr, site);  // segments: frames / clips; the whole-path callers refuse layouts whose segments could exceed the kernel's 1024 keys (api.hip: forward_ragged)
   }
   if (H <= 0 || H > 65535 || M < 0 || M > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "attn_ragged: bad M/H");
   if (M == 0) return 0;

@@ -91,6 +91,13 @@ static float* RED(const Scratch& sc) {
 constexpr int MAX_SPLIT = 32;
 constexpr int AB_MAX_ROWS = 256;  // attention backward: longest sequence (backward.hip: 64 in LDS, up to 256 streamed)
 
+static bool dw_side_wanted();
+static bool defer_wanted() { static const bool on = [] { const char* e = getenv("STLT_TRAIN_DEFER_REDUCE"); return e ? atoi(e) != 0 : true; }(); return on; }
+
+// The optional parts follow the switches the sweep itself reads, so that callers of stlt_train_scratch_bytes do not pay for what a
+// configuration never touches: the spatial tower's second operand set (10 tokp d floats: +7 GB at 1024 clips of cfg2) only while the
+// side stream is wanted, the reduction pool (<= 256 MB) only while the partial-row reductions are deferred.  They sit BEHIND the fixed
+// part, so toggling a switch between two calls moves no fixed buffer; the size is asked again by every stlt_train_backward caller.
 static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, int64_t C) {
   Scratch s;
   const int64_t tokp = up32(B * T * N), btp = up32(B * T), bp = up32(B);
@@ -109,15 +116,17 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   if (eb > red) red = eb;
   s.red = take(red);
   s.red_floats = (size_t)red;
-  s.red_pool_floats = (size_t)red * 24 < ((size_t)64 << 20) ? (size_t)red * 24 : ((size_t)64 << 20);  // <= 256 MB
-  if (s.red_pool_floats < (size_t)red) s.red_pool_floats = 0;  // a chunk would not fit: no deferral
-  s.red_pool = s.red_pool_floats ? take((int64_t)s.red_pool_floats) : nullptr;
   s.sk = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
-  s.s2 = GradBufs{take(tokp * d), take(tokp * d), take(tokp * d), take(tokp * 3 * d), take(tokp * 4 * d)};
   s.t2 = GradBufs{take(btp * d), take(btp * d), take(btp * d), take(btp * 3 * d), take(btp * 4 * d)};
   s.n_tx = btp <= DW_DEFER_MAX_ROWS ? DW_EXTRA_SETS : 0;
   for (int i = 0; i < s.n_tx; ++i) s.tx[i] = GradBufs{take(btp * d), take(btp * d), take(btp * d), take(btp * 3 * d), take(btp * 4 * d)};
-  s.sk2 = take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float)));
+  // ---- optional parts
+  s.red_pool_floats = (size_t)red * 24 < ((size_t)64 << 20) ? (size_t)red * 24 : ((size_t)64 << 20);  // <= 256 MB
+  if (s.red_pool_floats < (size_t)red || !defer_wanted()) s.red_pool_floats = 0;  // a chunk would not fit, or no deferral
+  s.red_pool = s.red_pool_floats ? take((int64_t)s.red_pool_floats) : nullptr;
+  const bool side = dw_side_wanted();
+  s.s2 = side ? GradBufs{take(tokp * d), take(tokp * d), take(tokp * d), take(tokp * 3 * d), take(tokp * 4 * d)} : GradBufs{nullptr, nullptr, nullptr, nullptr, nullptr};
+  s.sk2 = side ? take((int64_t)(STLT_GEMM_SCRATCH_BYTES / sizeof(float))) : nullptr;
   s.bytes = off;
   return s;
 }
@@ -129,7 +138,9 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
 // end of the call.  The products fill the chip while the chain runs its row-wise kernels, fix-ups and under-filled launches.
 // STLT_TRAIN_DW_STREAM=0 keeps everything on the caller's stream (A/B runs); STLT_TRAIN_DW_WG / STLT_TRAIN_DX_WG cap the grids of
 // the side products / the chain's dX products (0 = uncapped) so that both persistent kernels can be resident at once.
+struct DwSideDevice;
 struct DwSide {
+  DwSideDevice* dev = nullptr;  // != nullptr: this sweep holds dev->busy (released by DwSideHold)
   hipStream_t s = nullptr;
   hipEvent_t chain[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
   bool pending[2] = {false, false};
@@ -137,7 +148,9 @@ struct DwSide {
   float* sk = nullptr;
   int flush_no = 0;
 };
-struct DwSideDevice { hipStream_t s = nullptr; hipEvent_t ev[4] = {}; bool tried = false, ok = false; };
+// `busy`: the stream and its four events are one set per device, so a sweep owns them from its first fork to its join — a second host
+// thread's sweep on the same device waits here instead of re-recording an event the first one is about to wait on (DwSideHold).
+struct DwSideDevice { hipStream_t s = nullptr; hipEvent_t ev[4] = {}; bool tried = false, ok = false; std::mutex busy; };
 static DwSideDevice g_dw_side[STLT_MAX_DEVICES];
 
 static int g_dw_side_wanted = -1;  // -1: not read yet (STLT_TRAIN_DW_STREAM, default on); stlt_set_train_side_stream overrides
@@ -152,8 +165,8 @@ static DwSide dw_side_open(const Scratch& sc) {
   DwSide sd;
   if (!dw_side_wanted() || !sc.sk2) return sd;
   DwSideDevice& dv = g_dw_side[stlt_current_device() & (STLT_MAX_DEVICES - 1)];
-  static std::mutex mu;  // one creation per device, whichever thread's sweep comes first
-  std::lock_guard<std::mutex> lk(mu);
+  dv.busy.lock();  // also serialises the one creation per device, whichever thread's sweep comes first
+  sd.dev = &dv;
   if (!dv.tried) {
     dv.tried = true;
     int lo = 0, hi = 0;
@@ -182,6 +195,19 @@ static int dw_side_join(DwSide* sd, hipStream_t s) {
   TRY(dw_side_wait(sd, 0, s));
   return dw_side_wait(sd, 1, s);
 }
+// Owner of a sweep's DwSide: on EVERY exit path of the call (error returns included) the caller's stream is made to wait for the
+// side products still in flight — they read caller-owned tape and scratch, which torch's allocator recycles by the caller's stream
+// alone, and a captured graph must see the fork joined — and the per-device stream / event set is handed back.
+struct DwSideHold {
+  DwSide* sd; hipStream_t s;
+  DwSideHold(DwSide* x, hipStream_t st) : sd(x), s(st) {}
+  ~DwSideHold() {
+    (void)dw_side_join(sd, s);
+    if (sd->dev) { sd->dev->busy.unlock(); sd->dev = nullptr; }
+  }
+  DwSideHold(const DwSideHold&) = delete;
+  DwSideHold& operator=(const DwSideHold&) = delete;
+};
 
 // The weight-gradient launches of one tower.  Layers take the operand-buffer sets in turn; the products of `group_layers` consecutive
 // layers are collected and flushed as one grouped launch — on the side stream when it is on (behind an event of the chain), else on the
@@ -365,13 +391,16 @@ static int dwq_flush(DwQueue& q, const Scratch& sc, hipStream_t s) {
     TRY(dwq_wait_parity(q, par, s));  // the events of this parity are re-recorded below: nothing may still be waiting on them
     if (hipError_t e = hipEventRecord(side->chain[par], s); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
     if (hipError_t e = hipStreamWaitEvent(side->s, side->chain[par], 0); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
+    int rc = 0;
     {
       StltGemmScratch lend(side->sk, STLT_GEMM_SCRATCH_BYTES);
       StltGemmWgCap cap(dw_side_wg_cap());
-      TRY(weight_grad_all(q.items, q.n_items, sc, side->s));
+      rc = weight_grad_all(q.items, q.n_items, sc, side->s);
     }
+    // also after a failed launch: whatever did get enqueued on the side stream is joined by the call's exit path (DwSideHold)
     if (hipError_t e = hipEventRecord(side->done[par], side->s); e != hipSuccess) return stlt_set_error((int)e, "train_backward: %s", hipGetErrorString(e));
     side->pending[par] = true;
+    TRY(rc);
     for (int i = 0; i < q.layers_in_chunk; ++i) q.set_flush[q.chunk_sets[i]] = par;
   } else {
     TRY(weight_grad_all(q.items, q.n_items, sc, s));
@@ -499,7 +528,8 @@ static int check_train(const stlt_params* p, const stlt_inputs* in, bool need_he
 
 extern "C" {
 
-int stlt_set_train_side_stream(int on) { g_dw_side_wanted = on != 0; return 0; }
+int stlt_set_train_side_stream(int on) { g_dw_side_wanted = on < 0 ? -1 : (on != 0); return 0; }  // < 0: back to STLT_TRAIN_DW_STREAM / the default
+int stlt_get_train_side_stream(void) { return dw_side_wanted() ? 1 : 0; }
 
 size_t stlt_train_tape_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int64_t n_spatial, int64_t n_temporal) {
   if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || n_spatial < 0 || n_spatial > 64 || n_temporal < 0 || n_temporal > 64) return 0;
@@ -544,6 +574,8 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
   int64_t tok = B * T * N, BT = B * T;
   const RaggedIndex ix = ragged_index_carve(t.ridx, B, T, N);
   if (ragged) {
+    if (N > AB_MAX_ROWS || T > AB_MAX_ROWS)  // the reverse sweep would refuse the tape anyway; head dims other than 64 hold a segment's keys in LDS
+      return stlt_set_error(STLT_EINVAL, "skip-padding training supports sequences of at most %d tokens (N=%lld, T=%lld)", AB_MAX_ROWS, (long long)N, (long long)T);
     TRY(launch_ragged_index(in->kpm_boxes, in->kpm_frames, in->lengths, B, T, N, ix, s));
     TRY(read_ragged_counts(ix, tok, BT, s));
   } else {
@@ -614,7 +646,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   if (scratch_bytes < sc.bytes) return stlt_set_error(STLT_EWORKSPACE, "scratch %zu B < required %zu B", scratch_bytes, sc.bytes);
   // the sweep's ~55 partial-row reductions (LayerNorm / bias gradients) are collected and run as a few batched launches
   // (STLT_TRAIN_DEFER_REDUCE=0: one launch each, A/B runs)
-  static const bool defer_on = [] { const char* e = getenv("STLT_TRAIN_DEFER_REDUCE"); return e ? atoi(e) != 0 : true; }();
+  const bool defer_on = defer_wanted();
   StltReduceDefer defer;
   defer.s = (hipStream_t)stream;
   defer.pool = sc.red_pool;
@@ -622,7 +654,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   struct DeferGuard {
     StltReduceDefer* d;
     explicit DeferGuard(StltReduceDefer* x) : d(x) { stlt_reduce_defer_set(d); }
-    ~DeferGuard() { stlt_reduce_defer_set(nullptr); }
+    ~DeferGuard() { if (d && d->n > 0) (void)stlt_reduce_defer_flush(d); stlt_reduce_defer_set(nullptr); }  // error exits: what the producers left is still reduced
   } defer_guard(defer_on && sc.red_pool ? &defer : nullptr);
   if (defer_on && sc.red_pool) sc.defer = &defer;
   int64_t tok = B * T * N, BT = B * T;
@@ -654,12 +686,13 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // (the fusion models' layout branch — STLT_FLAG_TRAIN_BACKBONE — keeps one stream: measured 43.75 against 44.1 ms per CACNF step at 64
   // clips; the block-level calls around the sweep are single-stream and the side launches only delay their small kernels)
   DwSide side = backbone_only ? DwSide{} : dw_side_open(sc);
+  DwSideHold side_hold(&side, s);
   // weight-gradient queues: the spatial tower flushes per layer over two sets; the temporal tower, when it has few rows, collects up to
   // eight layers (32 products) per grouped launch over eight sets (STLT_TRAIN_DW_GROUP_LAYERS=1: per layer, A/B runs)
   static const int group_env = [] { const char* e = getenv("STLT_TRAIN_DW_GROUP_LAYERS"); return e ? atoi(e) : 8; }();
   DwQueue q_sp, q_tp;
   q_sp.side = q_tp.side = &side;
-  q_sp.sets[0] = GradBufs{sc.sB, sc.sD, sc.sE, sc.sQKV, sc.sH}; q_sp.sets[1] = sc.s2; q_sp.n_sets = 2;
+  q_sp.sets[0] = GradBufs{sc.sB, sc.sD, sc.sE, sc.sQKV, sc.sH}; q_sp.sets[1] = sc.s2; q_sp.n_sets = sc.s2.B ? 2 : 1;  // one stream: a layer's products are flushed before the next layer rewrites the set
   q_tp.sets[0] = GradBufs{sc.tB, sc.tD, sc.tE, sc.tQKV, sc.tH}; q_tp.sets[1] = sc.t2; q_tp.n_sets = 2;
   if (sc.n_tx > 0 && group_env > 1 && sc.sk) {
     for (int i = 0; i < sc.n_tx; ++i) q_tp.sets[2 + i] = sc.tx[i];
@@ -667,9 +700,11 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
     q_tp.group_layers = group_env < q_tp.n_sets ? group_env : q_tp.n_sets;
   }
   if (do_lower) {
-    for (float* b : {sc.sB, sc.sD, sc.sE, sc.s2.B, sc.s2.D, sc.s2.E}) TRY(zero_rows(b, d, tok, tokp, s));
-    for (float* b : {sc.sQKV, sc.s2.Q}) TRY(zero_rows(b, 3 * d, tok, tokp, s));
-    for (float* b : {sc.sH, sc.s2.H}) TRY(zero_rows(b, 4 * d, tok, tokp, s));
+    for (int k = 0; k < q_sp.n_sets; ++k) {
+      for (float* b : {q_sp.sets[k].B, q_sp.sets[k].D, q_sp.sets[k].E}) TRY(zero_rows(b, d, tok, tokp, s));
+      TRY(zero_rows(q_sp.sets[k].Q, 3 * d, tok, tokp, s));
+      TRY(zero_rows(q_sp.sets[k].H, 4 * d, tok, tokp, s));
+    }
   }
   if (do_upper) {
     for (int k = 0; k < q_tp.n_sets; ++k) {

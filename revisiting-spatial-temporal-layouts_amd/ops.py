@@ -107,9 +107,15 @@ def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual
     return dx
 
 
-def set_train_side_stream(on: bool) -> None:
-    """stlt_train_backward's weight-gradient products on the library's side stream (default) or on the caller's stream."""
-    L.check(L.load().stlt_set_train_side_stream(int(bool(on))), "stlt_set_train_side_stream")
+def set_train_side_stream(on) -> None:
+    """stlt_train_backward's weight-gradient products on the library's side stream (default) or on the caller's stream; None: back to
+    STLT_TRAIN_DW_STREAM / the default."""
+    L.check(L.load().stlt_set_train_side_stream(-1 if on is None else int(bool(on))), "stlt_set_train_side_stream")
+
+
+def get_train_side_stream() -> bool:
+    """The setting in force (what an A/B restores afterwards)."""
+    return bool(L.load().stlt_get_train_side_stream())
 
 
 def set_gemm_small_tiles(mode: int) -> None:

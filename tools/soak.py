@@ -208,7 +208,7 @@ def train_cases(reps):
                 return [loss.detach()] + [p.grad for p in m.parameters() if p.grad is not None]
 
             bad += loop(f"train forward+backward {name} B={B} side_stream={side}", step, max(reps // 3, 4))
-            ops.set_train_side_stream(True)
+            ops.set_train_side_stream(None)  # back to STLT_TRAIN_DW_STREAM / the default
     return bad
 
 
