@@ -80,26 +80,27 @@ int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* 
               const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride,
               int64_t M, int64_t N, int64_t K, int n_split, stlt_stream_t stream);
 /* The same nn.Linear forward (plus an optional add-source r: y = act(x·Wᵀ + b) + r, r only with STLT_ACT_NONE) on the small-tile
- * kernel (csrc/gemm16.hip): whole tiles of 128 rows x tile_cols columns (48, 64, 96, 128, 144 or 192), no stream-K, no fix-up
- * launch.  stlt_linear_fwd and every whole-path / training / block entry point route a product here by themselves when its launch
+ * kernel (csrc/gemm16.hip): whole tiles, no stream-K, no fix-up launch.  The `tile` parameter is columns | rows << 16 with rows 0 = 128:
+ * 128 rows x {48, 64, 96, 128, 144, 192} columns, 64 rows x {64, 96, 128, 160, 192, 256}, 32 rows x {128, 192, 256}.  stlt_linear_fwd and every whole-path / training / block entry point route a product here by themselves when its launch
  * would be under-filled on the 256 x 128 tiles and the small tiles are estimated faster (few rows: the temporal tower at the
- * reference's default batch of 64 clips, the fusion models' 2048 / 2112-row blocks); stlt_linear_small_choice returns the tile width
- * that dispatch picks for (M, N, K) — 0: the product stays on the large tiles; STLT_GEMM16=0 in the environment disables the routing.
- * This entry point runs the kernel on any shape it can take (K % 32 == 0, K >= 64, N % 4 == 0, pitches % 4 == 0) with the tile width
+ * reference's default batch of 64 clips, the fusion models' 2048 / 2112-row blocks); stlt_linear_small_choice returns the tile
+ * (same encoding) that dispatch picks for (M, N, K) — 0: the product stays on the large tiles; STLT_GEMM16=0 in the environment disables the routing.
+ * This entry point runs the kernel on any shape it can take (K % 32 == 0, K >= 64, N % 4 == 0, pitches % 4 == 0) with the tile
  * given (tests, A/B measurements); other shapes return STLT_EINVAL.  Same result as stlt_linear_fwd to fp32 rounding. */
 int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y, int64_t ldy,
-                          int64_t M, int64_t N, int64_t K, int act, int tile_cols, stlt_stream_t stream);
+                          int64_t M, int64_t N, int64_t K, int act, int tile, stlt_stream_t stream);
 int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K);
 /* The input gradient of that Linear on the same kernel: dx (M, k_in; ld_dx) = dy (M, n_out; ld_dy) · w (n_out, k_in) (+ r), the weight
  * read as it lies (no transposed copy: the [k][n] image is gathered inside the kernel).  The training sweeps (stlt_train_backward,
  * the block backwards, stlt_linear_bwd) route their under-filled dX products here by the same launch-time estimate; this entry point
  * runs it with the tile width given (n_out % 32 == 0, n_out >= 64, k_in % 4 == 0).  Same result as stlt_gemm(0, 1, ...) to rounding. */
 int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* dx,
-                          int64_t ld_dx, int64_t M, int tile_cols, stlt_stream_t stream);
+                          int64_t ld_dx, int64_t M, int tile, stlt_stream_t stream);
 int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in);  /* the tile width the routing picks for that input gradient (0: large tiles) */
 /* Process-wide routing switch: -1 = by the launch-time estimate (default; STLT_GEMM16 in the environment is the initial value),
- * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements), -2 = back to the
- * initial value (what a test or tool that switched it should leave behind). */
+ * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements), 128 / 64 / 32 = by
+ * the estimate over tiles of that height only (tests, A/B; STLT_GEMM16_ROWS is the environment's form), -2 = back to the initial value
+ * (what a test or tool that switched it should leave behind). */
 int stlt_set_gemm_small_tiles(int mode);
 
 /* Optional scratch for the calling thread's stlt_linear_fwd / stlt_gemm launches (torch's nn.Linear has no

@@ -153,23 +153,25 @@ int stlt_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bi
 }
 
 int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y, int64_t ldy, int64_t M,
-                          int64_t N, int64_t K, int act, int tile_cols, stlt_stream_t stream) {
-  if (tile_cols % 16 != 0) return stlt_set_error(STLT_EINVAL, "stlt_linear_small_fwd: tile_cols must be 48, 64, 96, 128, 144 or 192");
+                          int64_t N, int64_t K, int act, int tile, stlt_stream_t stream) {
+  const int code = stlt_gemm16_tile_from_public(tile);
+  if (code == 0) return stlt_set_error(STLT_EINVAL, "stlt_linear_small_fwd: tile = columns | rows << 16: 128 rows (or 0) x {48,64,96,128,144,192}, 64 x {64,96,128,160,192,256}, 32 x {128,192,256}");
   bool taken = false;
-  if (int e = launch_linear_gemm16(x, ldx, w, K, bias, r, ldr, y, ldy, M, N, K, act, (hipStream_t)stream, &taken, tile_cols / 16)) return e;
+  if (int e = launch_linear_gemm16(x, ldx, w, K, bias, r, ldr, y, ldy, M, N, K, act, (hipStream_t)stream, &taken, code)) return e;
   return taken || M == 0 ? 0 : stlt_set_error(STLT_EINVAL, "stlt_linear_small_fwd: shape or activation not taken by the small-tile kernel");
 }
 
 int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* dx, int64_t ld_dx,
-                          int64_t M, int tile_cols, stlt_stream_t stream) {
-  if (tile_cols % 16 != 0) return stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: tile_cols must be 48, 64, 96, 128, 144 or 192");
+                          int64_t M, int tile, stlt_stream_t stream) {
+  const int code = stlt_gemm16_tile_from_public(tile);
+  if (code == 0) return stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: tile = columns | rows << 16: 128 rows (or 0) x {48,64,96,128,144,192}, 64 x {64,96,128,160,192,256}, 32 x {128,192,256}");
   bool taken = false;
-  if (int e = launch_input_grad_gemm16(dy, ld_dy, w, n_out, k_in, r, ldr, dx, ld_dx, M, (hipStream_t)stream, &taken, tile_cols / 16)) return e;
+  if (int e = launch_input_grad_gemm16(dy, ld_dy, w, n_out, k_in, r, ldr, dx, ld_dx, M, (hipStream_t)stream, &taken, code)) return e;
   return taken || M == 0 ? 0 : stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: shape not taken by the small-tile kernel");
 }
 
-int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K) { return 16 * stlt_gemm16_choice(M, N, K, K, K); }
-int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in) { return 16 * stlt_gemm16_choice(M, k_in, n_out, n_out, k_in, true); }
+int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K) { return stlt_gemm16_tile_to_public(stlt_gemm16_choice(M, N, K, K, K)); }
+int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in) { return stlt_gemm16_tile_to_public(stlt_gemm16_choice(M, k_in, n_out, n_out, k_in, true)); }
 int stlt_set_gemm_small_tiles(int mode) { return stlt_gemm16_set_mode(mode); }
 
 int stlt_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* r, int64_t ldr,

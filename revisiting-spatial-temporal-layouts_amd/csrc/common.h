@@ -42,6 +42,25 @@ struct StltProfScope {  // scopes nest: only the outermost one of a thread recor
   ~StltProfScope() { stlt_prof_end(kid, s); }
 };
 
+// One LDS-DMA instruction in its scalar-base form: 16 (4) bytes per lane from (wave-uniform 64-bit base in SGPRs) + (per-lane unsigned 32-bit
+// byte offset) to LDS byte address lds_addr + 16 (4) * lane.  hipcc's builtin takes a 64-bit per-lane pointer and only sometimes folds
+// base + zext(offset) back into this form (it keeps zero-extended offsets in register pairs and adds the base with v_lshl_add_u64 per
+// instruction: a vector-ALU instruction beside the MFMA waves for every DMA).  The instruction is invisible to the compiler's vmcnt
+// bookkeeping: callers wait with explicit s_waitcnt vmcnt(N), as the loader waves do anyway; M0 is declared clobbered (hipcc warns that it is a
+// reserved register: a wave that uses these helpers issues none of its LDS-DMA through the builtin, so nothing else of it lives in M0).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void stlt_dma16(const void* uniform_base, uint32_t lane_byte_offset, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_byte_offset), "s"(uniform_base), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void stlt_dma4(const void* uniform_base, uint32_t lane_byte_offset, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane_byte_offset), "s"(uniform_base), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ uint32_t stlt_lds_addr(const void* lds_ptr) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)lds_ptr;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -183,11 +202,13 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
 // gemm16.hip: the same product on 128 x (16 NT) whole tiles for under-filled launches (no stream-K, no fix-up); *taken = launched
 double stlt_linear_est_us(int64_t M, int64_t N, int64_t K);  // launch-time estimate of launch_linear's duration (us)
 int stlt_gemm16_set_mode(int mode);  // -1 by estimate (default), 0 off, 1 always
-int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, bool wkn = false);  // 0 = gemm.hip keeps the product, else the tile's NT (wkn: the input-gradient build)
+int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, bool wkn = false);  // 0 = gemm.hip keeps the product, else the tile code (row blocks << 5 | column tiles; wkn: the input-gradient build)
+int stlt_gemm16_tile_from_public(int tile);  // C-ABI tile parameter (columns | rows << 16, rows 0 = 128) -> tile code, 0 = not a tile of the kernel
+int stlt_gemm16_tile_to_public(int code);
 int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* r, int64_t ldr, float* y,
-                         int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken, int force_nt = 0);
+                         int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken, int force_tile = 0);
 int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,
-                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_nt = 0, const StltGemmEpi* gelu_bwd = nullptr);  // dX = dY·W on the small tiles, W as it lies
+                             int64_t ldc, int64_t rows, hipStream_t s, bool* taken, int force_tile = 0, const StltGemmEpi* gelu_bwd = nullptr);  // dX = dY·W on the small tiles, W as it lies
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
                 int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi = nullptr);

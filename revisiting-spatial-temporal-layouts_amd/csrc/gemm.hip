@@ -273,11 +273,17 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
   //   contraction-major    : image [32 k][256 m | 128 n]; an instruction covers one 1-KB k-row (A) / two 512-B k-rows (B)
   const int drow = lane >> 3, dslot = lane & 7;
   constexpr int NV = WS ? 2 : 1;  // a loader wave does the DMA share of MFMA waves 2j and 2j+1
-  const float* pa[NV][4];
-  const float* pb[NV][2];
+  // Addresses = a wave-uniform base per operand (the tile's origin: scalar registers; the k offset is added with scalar arithmetic) + a
+  // per-lane 32-bit byte offset fixed for the tile, so that a k-step's DMA issue costs no vector-ALU instruction (round 5: with 64-bit
+  // per-lane pointers every instruction paid a 64-bit vector add, issued beside the MFMA waves of the loader's SIMD; the small-tile
+  // kernel's loaders cost its MFMA waves 4 - 6 % that way, profiles/round5_gemm16_ablation.txt)
+  uint32_t voa[NV][4];
+  uint32_t vob[NV][2];
+  const char* base_a = nullptr;
+  const char* base_b = nullptr;
   const int vw0 = WS ? 2 * (wave - GEMM_WAVES) : wave;  // first "virtual wave" whose DMA share this wave issues (WS: loaders only)
-  int64_t a_kstep = TA ? (int64_t)BK * ldx : BK;
-  int64_t b_kstep = TB ? (int64_t)BK * ldw : BK;
+  int64_t a_kstep = (TA ? (int64_t)BK * ldx : BK) * (int64_t)sizeof(float);  // bytes per k-step
+  int64_t b_kstep = (TB ? (int64_t)BK * ldw : BK) * (int64_t)sizeof(float);
   auto dma_set_tile = [&](int it) {
     int m0, n0, split;
     tile_origin(it, m0, n0, split);
@@ -285,10 +291,16 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
       int pi, lt;
       group_tile(it, pi, lt);
       X = grp.p[pi].a; ldx = grp.p[pi].lda; W = grp.p[pi].b; ldw = grp.p[pi].ldb; M = grp.p[pi].M; N = grp.p[pi].N; nk = grp.p[pi].nk;
-      a_kstep = TA ? (int64_t)BK * ldx : BK;
-      b_kstep = TB ? (int64_t)BK * ldw : BK;
+      a_kstep = (TA ? (int64_t)BK * ldx : BK) * (int64_t)sizeof(float);
+      b_kstep = (TB ? (int64_t)BK * ldw : BK) * (int64_t)sizeof(float);
     }
     const int64_t kbase = GROUP ? 0 : (int64_t)split * nk * BK;  // first contraction index of this split
+    const uint32_t ldx32 = (uint32_t)ldx, ldw32 = (uint32_t)ldw;  // launch_gemm keeps 256 rows x the pitch below 4 GB
+    // contraction-major operands: a 16-B read is kept inside its row (those output rows / columns are never stored)
+    const int cmax_a = M >= 4 ? ((M - 4) & ~3) : 0, cb_a = m0 < cmax_a ? m0 : cmax_a;
+    const int cmax_b = N >= 4 ? ((N - 4) & ~3) : 0, cb_b = n0 < cmax_b ? n0 : cmax_b;
+    base_a = reinterpret_cast<const char*>(TA ? X + kbase * ldx + cb_a : X + (int64_t)m0 * ldx + kbase);
+    base_b = reinterpret_cast<const char*>(TB ? W + kbase * ldw + cb_b : W + (int64_t)n0 * ldw + kbase);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int vw = vw0 + u;
@@ -297,13 +309,12 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         if (TA) {
           const int kr = vw * 4 + i;                 // k-row inside the step
           int col = m0 + lane * 4;
-          col = col + 4 <= M ? col : (M >= 4 ? ((M - 4) & ~3) : 0);  // keep the 16-B read inside the row; those output rows are never stored
-          pa[u][i] = X + (kbase + kr) * ldx + col;
+          col = col < cmax_a ? col : cmax_a;
+          voa[u][i] = ((uint32_t)kr * ldx32 + (uint32_t)(col - cb_a)) * 4u;
         } else {
           const int r = vw * 32 + i * 8 + drow;      // row inside the A tile
-          int gm = m0 + r;
-          gm = gm < M ? gm : M - 1;                  // ragged tiles re-read the last row; stores are guarded
-          pa[u][i] = X + (int64_t)gm * ldx + kbase + (dslot ^ ((r >> 1) & 7)) * 4;  // source-side swizzle
+          const int rr = r < M - m0 ? r : M - 1 - m0;  // ragged tiles re-read the last row; stores are guarded
+          voa[u][i] = ((uint32_t)rr * ldx32 + (uint32_t)((dslot ^ ((r >> 1) & 7)) * 4)) * 4u;  // source-side swizzle
         }
       }
 #pragma unroll
@@ -311,13 +322,12 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
         if (TB) {
           const int kr = vw * 4 + i * 2 + (lane >> 5);
           int col = n0 + (lane & 31) * 4;
-          col = col + 4 <= N ? col : (N >= 4 ? ((N - 4) & ~3) : 0);
-          pb[u][i] = W + (kbase + kr) * ldw + col;
+          col = col < cmax_b ? col : cmax_b;
+          vob[u][i] = ((uint32_t)kr * ldw32 + (uint32_t)(col - cb_b)) * 4u;
         } else {
           const int r = vw * 16 + i * 8 + drow;      // row inside the B tile
-          int gn = n0 + r;
-          gn = gn < N ? gn : N - 1;
-          pb[u][i] = W + (int64_t)gn * ldw + kbase + (dslot ^ ((r >> 1) & 7)) * 4;
+          const int rr = r < N - n0 ? r : N - 1 - n0;
+          vob[u][i] = ((uint32_t)rr * ldw32 + (uint32_t)((dslot ^ ((r >> 1) & 7)) * 4)) * 4u;
         }
       }
     }
@@ -332,15 +342,13 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int q = 2 * part + i;
-        const float* src = TA ? pa[u][q] + kt * a_kstep : pa[u][q] + kt * BK;
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(sa + q * (TA ? BM : 8 * BK)), 16, 0, 0);
+        stlt_dma16(base_a + (int64_t)kt * a_kstep, voa[u][q], stlt_lds_addr(sa + q * (TA ? BM : 8 * BK)));
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
       {
-        const float* src = TB ? pb[u][i] + kt * b_kstep : pb[u][i] + kt * BK;
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(sb + i * (TB ? 2 * BN : 8 * BK)), 16, 0, 0);
+        stlt_dma16(base_b + (int64_t)kt * b_kstep, vob[u][i], stlt_lds_addr(sb + i * (TB ? 2 * BN : 8 * BK)));
       }
     }
   };
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(WS ? GEMM_THREADS_WS : GEMM_THREADS, WS ? 3 : 2) vo
       for (int i = 0; i < 2; ++i) {
         int n = n0 + i * 64 + lane;
         n = n < N ? n : N - 1;  // columns past N are never stored
-        __builtin_amdgcn_global_load_lds((glb_void_ptr)(bias + n), (lds_void_ptr)(dst + i * 64), 4, 0, 0);
+        stlt_dma4(bias, (uint32_t)n * 4u, stlt_lds_addr(dst + i * 64));  // N < 2^30 here (bias only with the forward layout; launch_gemm checks): the byte offset fits 32 bits
       }
     }
   };
@@ -1125,7 +1133,9 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   }
   if (lda % 4 != 0 || ldb % 4 != 0 || (r && ldr < N) || ldc < N || lda < (transA ? M : K) || ldb < (transB ? N : K))
     return stlt_set_error(STLT_EINVAL, "gemm: bad leading dimension (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
-  if (M > 0x7fffff00LL || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gemm: M/N too large");
+  if (M > 0x7fffff00LL || N > 0x7fffff00LL || (bias && N > 0x3fffff00LL)) return stlt_set_error(STLT_EINVAL, "gemm: M/N too large");
+  if (lda > 0x3fffffLL || ldb > 0x3fffffLL)  // the DMA addresses a tile's 256 rows with 32-bit byte offsets from the tile's origin
+    return stlt_set_error(STLT_EINVAL, "gemm: row pitch too large (lda=%lld ldb=%lld, at most 4194303 floats)", (long long)lda, (long long)ldb);
   if (act != STLT_ACT_NONE && act != STLT_ACT_GELU && act != STLT_ACT_RELU && act != STLT_ACT_GELU_BWD) return stlt_set_error(STLT_EINVAL, "gemm: unknown activation %d", act);
   if (n_split < 1 || (K / BK) % n_split != 0) return stlt_set_error(STLT_EINVAL, "gemm: n_split=%d must divide K/32=%lld", n_split, (long long)(K / BK));
   if (transA && !transB) return stlt_set_error(STLT_EINVAL, "gemm: the (transA, !transB) layout is not built");
@@ -1235,7 +1245,7 @@ int launch_weight_grad_group(const StltWeightGradItem* items, int n_items, hipSt
     if (!it.dy || !it.x || it.n_out <= 0 || it.k_in <= 0 || it.rows < 0 || it.rows % BK != 0 || it.n_out % 4 != 0 || it.k_in % 4 != 0)
       return stlt_set_error(STLT_EINVAL, "weight_grad_group: item %d: rows=%lld must be a multiple of %d, n_out=%lld / k_in=%lld multiples of 4", i,
                             (long long)it.rows, BK, (long long)it.n_out, (long long)it.k_in);
-    if (it.n_out > 0x7fffff00LL || it.k_in > 0x7fffff00LL || it.rows > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "weight_grad_group: item too large");
+    if (it.n_out > 0x3fffffLL || it.k_in > 0x3fffffLL || it.rows > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "weight_grad_group: item too large");
     const int64_t tm = (it.n_out + BM - 1) / BM, tn = (it.k_in + BN - 1) / BN;
     StltGemmProblem& q = grp.p[n];
     q.a = it.dy; q.lda = (int)it.n_out; q.b = it.x; q.ldb = (int)it.k_in; q.r = it.g_w; q.ldr = (int)it.k_in; q.c = it.g_w; q.ldc = (int)it.k_in;

@@ -12,6 +12,9 @@
 
 namespace {
 
+#ifndef STLT_MHSA_LOADER
+#define STLT_MHSA_LOADER 2
+#endif
 constexpr int FM = 128, FN = 192, FK = 32;
 constexpr int F_WAVES = 8, F_LOADERS = 4;
 constexpr int F_THREADS = 64 * (F_WAVES + F_LOADERS);
@@ -104,23 +107,40 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     // ---- loader waves: loader Ld issues A rows [32 Ld, 32 Ld + 32) and B rows [48 Ld, 48 Ld + 48); B image row r = (q|k|v = r / 64, channel r % 64)
     const int Ld = wave - F_WAVES;
     const int drow = lane >> 3, dslot = lane & 7;
+    // addresses = a wave-uniform base (scalar registers, advanced per k-step by scalar adds) + a per-lane 32-bit byte offset fixed for
+    // the item: no vector-ALU instruction in the steady state (see gemm16_kernel.h).  An instruction's 8 rows of the W image lie in one
+    // of the head's q / k / v blocks (8 divides 64), so that block's first row goes into the instruction's base.
+    // STLT_MHSA_LOADER (A/B builds): 0 = round 4's 64-bit per-lane pointers + a vector add per instruction, 1 = the compiler's builtin on base + offset
+    // (it folds the X image's into the scalar-base form and keeps a vector add for the W image's), 2 = stlt_dma16 for every instruction
+    uint32_t voa[4], vob[6];
+    const char* bx = nullptr;
+    const char* bw = nullptr;
+#if STLT_MHSA_LOADER == 0
     const float* pa[4];
     const float* pb[6];
+#endif
     auto set_item = [&](int it) {
       int grp, head;
       item_of(it, grp, head);
+      const int row0 = grp * a.rows_per_item;
+      bx = reinterpret_cast<const char*>(a.X + (int64_t)row0 * d);
+      bw = reinterpret_cast<const char*>(a.Win + (int64_t)head * 64 * d);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = Ld * 32 + i * 8 + drow;
-        int gm = grp * a.rows_per_item + r;
-        gm = gm < M ? gm : M - 1;  // rows past the batch re-read the last row; nothing of theirs is stored
-        pa[i] = a.X + (int64_t)gm * d + (dslot ^ ((r >> 1) & 7)) * 4;
+        const int rr = r < M - row0 ? r : M - 1 - row0;  // rows past the batch re-read the last row; nothing of theirs is stored
+        voa[i] = ((uint32_t)rr * (uint32_t)d + (uint32_t)((dslot ^ ((r >> 1) & 7)) * 4)) * 4u;
+#if STLT_MHSA_LOADER == 0
+        pa[i] = a.X + (int64_t)(row0 + rr) * d + (dslot ^ ((r >> 1) & 7)) * 4;
+#endif
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int r = Ld * 48 + i * 8 + drow;
-        const int wrow = (r >> 6) * d + head * 64 + (r & 63);
-        pb[i] = a.Win + (int64_t)wrow * d + (dslot ^ ((r >> 1) & 7)) * 4;
+        vob[i] = ((uint32_t)(r & 63) * (uint32_t)d + (uint32_t)((dslot ^ ((r >> 1) & 7)) * 4)) * 4u;
+#if STLT_MHSA_LOADER == 0
+        pb[i] = a.Win + (int64_t)((r >> 6) * d + head * 64 + (r & 63)) * d + (dslot ^ ((r >> 1) & 7)) * 4;
+#endif
       }
     };
     auto dma_bias = [&](int it) {
@@ -129,8 +149,10 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
         item_of(it, grp, head);
         float* dst = bias_lds + (it & 1) * FN;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          __builtin_amdgcn_global_load_lds((glb_void_ptr)(a.bin + i * d + head * 64 + lane), (lds_void_ptr)(dst + i * 64), 4, 0, 0);
+        for (int i = 0; i < 3; ++i) {
+          if (STLT_MHSA_LOADER == 2) stlt_dma4(a.bin + i * d + head * 64, (uint32_t)lane * 4u, stlt_lds_addr(dst + i * 64));
+          else __builtin_amdgcn_global_load_lds((glb_void_ptr)(a.bin + i * d + head * 64 + lane), (lds_void_ptr)(dst + i * 64), 4, 0, 0);
+        }
       }
     };
     int l_it = 0, l_kt = 0, l_stage = 0;
@@ -138,10 +160,28 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
       if (l_kt == 0) set_item(l_it);
       float* sa = smem + l_stage * F_STAGE + (Ld * 32) * FK;
       float* sb = smem + l_stage * F_STAGE + FM * FK + (Ld * 48) * FK;
+#if STLT_MHSA_LOADER == 0
 #pragma unroll
       for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_void_ptr)(pa[i] + l_kt * FK), (lds_void_ptr)(sa + i * 8 * FK), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < 6; ++i) __builtin_amdgcn_global_load_lds((glb_void_ptr)(pb[i] + l_kt * FK), (lds_void_ptr)(sb + i * 8 * FK), 16, 0, 0);
+#else
+      const uint32_t la = stlt_lds_addr(sa), lb = stlt_lds_addr(sb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (STLT_MHSA_LOADER == 1) __builtin_amdgcn_global_load_lds((glb_void_ptr)(bx + voa[i]), (lds_void_ptr)(sa + i * 8 * FK), 16, 0, 0);
+        else stlt_dma16(bx, voa[i], la + i * 8 * FK * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int qkv = (Ld * 48 + i * 8) >> 6;  // wave-uniform: the q / k / v block of this instruction's 8 rows
+        const char* bwi = bw + (int64_t)qkv * d * d * (int64_t)sizeof(float);
+        if (STLT_MHSA_LOADER == 1) __builtin_amdgcn_global_load_lds((glb_void_ptr)(bwi + vob[i]), (lds_void_ptr)(sb + i * 8 * FK), 16, 0, 0);
+        else stlt_dma16(bwi, vob[i], lb + i * 8 * FK * 4);
+      }
+      bx += FK * sizeof(float);
+      bw += FK * sizeof(float);
+#endif
       if (++l_kt == nk) { ++l_it; l_kt = 0; }
       if (++l_stage == F_NSTAGE) l_stage = 0;
     };
@@ -424,20 +464,21 @@ static int launch_mhsa16_nkb(int nkb, const Mhsa16Args& a, hipStream_t s) {
 // Does the fused kernel take this shape?  Sequences of 1..64 tokens, 64-channel heads, d a multiple of the 32-wide k-step, and at
 // most 5 key blocks per query block (always true for causal sequences; non-causal: up to ~36 tokens).
 bool stlt_mhsa_fused_takes(int64_t L, int64_t H, int64_t d, int causal) {
-  if (L < 1 || L > 64 || H <= 0 || H > 65535 || d != H * 64 || d % FK != 0) return false;
+  if (L < 1 || L > 64 || H <= 0 || H > 256 || d != H * 64 || d % FK != 0) return false;  // (H <= 256: the loaders' 32-bit weight offsets)
   const int rows = (int)(FM / L * L);
   return mhsa16_key_blocks((int)L, rows, causal != 0) <= 5;
 }
 
 // Is the fused launch the faster form for S sequences?  Launch-time estimates fitted to stand-alone measurements on MI355X
-// (profiles/round4_mhsa_fused_ab.txt, round4_gemm16_shapes.txt):
-//   fused  = rounds of items x (k-steps x 2.91 us + 2.2 us per key block - 0.9) + 6 us — whole sequences per 128-row item, so
-//            33 tokens fill 99 rows and pay for 128 (1227 us against the pair's 1031 at 1024 clips), and a launch pays for whole
+// (profiles/round5_mhsa_fused_ab.txt, round5_gemm16_shapes.txt):
+//   fused  = rounds of items x (k-steps x 2.89 us + 0.7 us per key block + 0.6) + 6 us — whole sequences per 128-row item, so
+//            33 tokens fill 99 rows and pay for 128 (1219 us against the pair's 981 at 1024 clips), and a launch pays for whole
 //            rounds of workgroups (64 frames x 64 clips: 1.5 rounds = 2);
 //   pair   = the in-projection as launch_linear would run it (large tiles, stream-K, or gemm16's small tiles) + the attention core
 //            at ~5.2 TB/s of its 16 bytes per token and channel + 6 us.
-// Fused wins from ~256 clips on for 17 / 32 / 64 frames and for 5 - 8 object slots at bench sizes; the pair wins at 64 clips (small
-// tiles: 63 + 10 us against 79), for 33 frames and for 36 objects.  STLT_FUSED_MHSA_FORCE=1: whenever the shape is taken (A/B runs).
+// Fused wins from ~256 clips on for 17 / 32 / 64 frames (854 against 917 us at 1024 clips of 32 frames, 434 against 460 at 256 clips of 64)
+// and for 5 - 8 object slots at bench sizes (6180 against 6251 us at 32768 frames of 7); the pair wins at 64 clips (small tiles: 65 + 10 us
+// against 79), for 33 frames and for 36 objects.  STLT_FUSED_MHSA_FORCE=1: whenever the shape is taken (A/B runs).
 bool stlt_mhsa_fused_pays(int64_t S, int64_t L, int64_t H, int64_t d, int causal) {
   if (!stlt_mhsa_fused_takes(L, H, d, causal)) return false;
   static const int force = [] { const char* e = getenv("STLT_FUSED_MHSA_FORCE"); return e ? atoi(e) : 0; }();
@@ -447,7 +488,7 @@ bool stlt_mhsa_fused_pays(int64_t S, int64_t L, int64_t H, int64_t d, int causal
   const int64_t cus = stlt_device_cus();
   const int64_t rounds = (n_items + cus - 1) / cus;
   const int nkb = mhsa16_key_blocks((int)L, (int)(seq_per_item * L), causal != 0);
-  const double fused = (double)rounds * ((double)(d / FK) * 2.91 + 2.2 * nkb - 0.9) + 6.0;
+  const double fused = (double)rounds * ((double)(d / FK) * 2.89 + 0.7 * nkb + 0.6) + 6.0;
   const double pair = stlt_linear_est_us(S * L, 3 * d, d) + 6.0 + 16.0 * (double)(S * L) * (double)d / 5.2e6;
   return fused < pair;
 }

@@ -79,22 +79,32 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: 
     return out
 
 
+def small_tile(tile_cols: int, tile_rows: int = 128) -> int:
+    """The C-ABI's tile parameter: columns | rows << 16, 128 rows as plain columns (include/stlt_hip.h: stlt_linear_small_fwd)."""
+    if int(tile_cols) >> 16:  # already in the C-ABI's form (what stlt_linear_small_choice returns)
+        return int(tile_cols)
+    return int(tile_cols) if int(tile_rows) == 128 else (int(tile_cols) | (int(tile_rows) << 16))
+
+
+SMALL_TILES = tuple((128, c) for c in (48, 64, 96, 128, 144, 192)) + tuple((64, c) for c in (64, 96, 128, 160, 192, 256)) + tuple((32, c) for c in (128, 192, 256))
+
+
 def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], tile_cols: int, act: int = L.ACT_NONE,
-                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """The same product on the small-tile kernel (csrc/gemm16.hip; include/stlt_hip.h: stlt_linear_small_fwd): whole tiles of 128 rows x
-    tile_cols columns; `residual` (M, N) is added after the bias (act must then be ACT_NONE)."""
+                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tile_rows: int = 128):
+    """The same product on the small-tile kernel (csrc/gemm16.hip; include/stlt_hip.h: stlt_linear_small_fwd): whole tiles of tile_rows x
+    tile_cols (one of SMALL_TILES); `residual` (M, N) is added after the bias (act must then be ACT_NONE)."""
     lib = L.load()
     _chk(x, torch.float32, "x"); _chk(w, torch.float32, "w")
     N, K = w.shape
     M = x.numel() // K
     if out is None:
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-    L.check(lib.stlt_linear_small_fwd(_p(x), K, _p(w), _p(bias), _p(residual), N, _p(out), N, M, N, K, act, int(tile_cols), _stream()),
+    L.check(lib.stlt_linear_small_fwd(_p(x), K, _p(w), _p(bias), _p(residual), N, _p(out), N, M, N, K, act, small_tile(tile_cols, tile_rows), _stream()),
             "stlt_linear_small_fwd")
     return out
 
 
-def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual: Optional[torch.Tensor] = None):
+def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual: Optional[torch.Tensor] = None, tile_rows: int = 128):
     """dx (M, k_in) = dy (M, n_out) · w (n_out, k_in) (+ residual) on the small-tile kernel, the weight read as it lies
     (include/stlt_hip.h: stlt_input_grad_small)."""
     lib = L.load()
@@ -102,7 +112,7 @@ def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual
     n_out, k_in = w.shape
     M = dy.numel() // n_out
     dx = torch.empty(*dy.shape[:-1], k_in, device=dy.device, dtype=torch.float32)
-    L.check(lib.stlt_input_grad_small(_p(dy), n_out, _p(w), n_out, k_in, _p(residual), k_in, _p(dx), k_in, M, int(tile_cols), _stream()),
+    L.check(lib.stlt_input_grad_small(_p(dy), n_out, _p(w), n_out, k_in, _p(residual), k_in, _p(dx), k_in, M, small_tile(tile_cols, tile_rows), _stream()),
             "stlt_input_grad_small")
     return dx
 
@@ -119,7 +129,8 @@ def get_train_side_stream() -> bool:
 
 
 def set_gemm_small_tiles(mode: int) -> None:
-    """Routing of under-filled products to the small-tile kernel: -1 by estimate (default), 0 off, 1 always, -2 back to the process's initial
+    """Routing of under-filled products to the small-tile kernel: -1 by estimate (default), 0 off, 1 always, 128 / 64 / 32 by estimate over tiles
+    of that height only, -2 back to the process's initial
     setting (STLT_GEMM16 or the default) — what to restore after an A/B (stlt_set_gemm_small_tiles)."""
     L.check(L.load().stlt_set_gemm_small_tiles(int(mode)), "stlt_set_gemm_small_tiles")
 

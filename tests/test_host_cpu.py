@@ -88,16 +88,25 @@ def test_launch_time_dispatch_is_host_arithmetic(pkg):
     if os.environ.get("STLT_GEMM16") == "0" or os.environ.get("STLT_FUSED_MHSA") == "0":
         pytest.skip("dispatch switched off in the environment")
     lib = pkg._lib.load()
-    # 64-clip batches of cfg2 (M = 2048): whole small tiles of 48 / 144 / 192 columns = 256 tiles; bench-sized launches stay on 256 x 128
+    # 64-clip batches of cfg2 (M = 2048): whole small tiles of 128 x 48 / 144 / 192 = 256 tiles; bench-sized launches stay on 256 x 128.
+    # The tile is returned as columns | rows << 16 (128 rows: plain columns)
+    tile = lambda rows, cols: cols if rows == 128 else (cols | (rows << 16))
     assert lib.stlt_linear_small_choice(2048, 768, 768) == 48
     assert lib.stlt_linear_small_choice(2048, 2304, 768) == 144
     assert lib.stlt_linear_small_choice(2048, 3072, 768) == 192
     assert lib.stlt_linear_small_choice(229376, 2304, 768) == 0 and lib.stlt_linear_small_choice(32768, 768, 3072) == 0
     assert lib.stlt_linear_small_choice(2048, 174, 768) == 0          # N % 4 != 0: not the kernel's shape
-    # input gradients (weight read as it lies: 1.38x the k-step time): the out-projection's goes to the small tiles, FFN1's (K = 3072) stays
-    assert lib.stlt_input_grad_small_choice(2048, 768, 768) == 48 and lib.stlt_input_grad_small_choice(2048, 3072, 768) == 0
-    # fused MHSA: from ~256 clips on for 17 / 32 / 64 frames, never for 33 frames (99 of an item's 128 rows) or 36 objects; 64-clip
-    # launches go to the pair (small-tile in-projection + attention core)
+    # round 5, tile heights of 64 / 32 rows: the reference's default layout at its default batch (17 frames x 5 slots x 64 clips:
+    # M = 5440 spatial rows = 85 x 64 -> 64 x 256 tiles = 255 / 765 / 1020 for N = 768 / 2304 / 3072; M = 1088 temporal rows = 17 x 64)
+    assert lib.stlt_linear_small_choice(5440, 768, 768) == tile(64, 256) and lib.stlt_linear_small_choice(5440, 2304, 768) == tile(64, 256)
+    assert lib.stlt_linear_small_choice(5440, 3072, 768) == tile(64, 256) and lib.stlt_linear_small_choice(5440, 768, 3072) == tile(64, 256)
+    assert (lib.stlt_linear_small_choice(1088, 768, 768) >> 16) in (32, 64) and lib.stlt_linear_small_choice(1088, 2304, 768) == tile(64, 160)
+    assert lib.stlt_linear_small_choice(14336, 768, 768) == tile(64, 96)   # 1.31 rounds of large tiles (stream-K + fix-up) against 7 whole rounds
+    # input gradients (weight read as it lies: the [k][n] gather costs 5 - 15 % per k-step): 2048-row products go to the small tiles
+    assert lib.stlt_input_grad_small_choice(2048, 768, 768) == 48 and lib.stlt_input_grad_small_choice(2048, 3072, 768) == 48
+    assert lib.stlt_input_grad_small_choice(14336, 768, 3072) == 0
+    # fused MHSA: from ~256 clips on for 32 / 64 frames (17 frames: from 1024), never for 33 frames (99 of an item's 128 rows) or 36
+    # objects; 64-clip launches go to the pair (small-tile in-projection + attention core)
     used = lambda S, L, causal: int(lib.stlt_fused_mhsa_used(S, L, 768, 12, causal))
     assert [used(S, 32, 1) for S in (64, 256, 1024)] == [0, 1, 1]
     assert [used(S, 64, 1) for S in (64, 256, 1024)] == [0, 1, 1]

@@ -508,11 +508,15 @@ def test_attn_core_short_sequences_many_items_and_masked_rows(pkg, S, L, causal)
     assert (got.double() - ref).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("tile_cols", [48, 64, 96, 128, 144, 192])
-@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (2112, 2304, 768), (2048, 3072, 768), (2048, 768, 3072), (1000, 1536, 64), (77, 52, 96),
+SMALL_TILES = [(128, 48), (128, 64), (128, 96), (128, 128), (128, 144), (128, 192), (64, 64), (64, 96), (64, 128), (64, 160), (64, 192), (64, 256),
+               (32, 128), (32, 192), (32, 256)]  # csrc/gemm16*.hip: tile rows x columns
+
+
+@pytest.mark.parametrize("tile_rows,tile_cols", SMALL_TILES)
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (2112, 2304, 768), (2048, 3072, 768), (1088, 768, 3072), (1000, 1536, 64), (77, 52, 96),
                                    (1, 4, 64), (33000, 768, 128)])
-def test_linear_small_tiles_vs_fp64(pkg, M, N, K, tile_cols):
-    """csrc/gemm16.hip: the nn.Linear forward on whole 128 x tile_cols tiles (under-filled launches), every tile width on ragged
+def test_linear_small_tiles_vs_fp64(pkg, M, N, K, tile_rows, tile_cols):
+    """csrc/gemm16.hip: the nn.Linear forward on whole tile_rows x tile_cols tiles (under-filled launches), every tile on ragged
     and exact shapes, with bias / GELU / ReLU / residual, against an fp64 product and against the large-tile kernel."""
     x = _rand(M, K, seed=M + K, scale=1.5)
     w = _rand(N, K, seed=N + 1, scale=2.0 / math.sqrt(K))
@@ -522,8 +526,8 @@ def test_linear_small_tiles_vs_fp64(pkg, M, N, K, tile_cols):
     ref = x.double() @ w.double().t()
     tol = 3e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item())
     for act, bias, res in ((0, bd, None), (1, bd, None), (2, bd, None), (0, None, None), (0, bd, rd)):
-        got = pkg.ops.linear_small(xd, wd, bias, tile_cols, act=act, residual=res)
-        again = pkg.ops.linear_small(xd, wd, bias, tile_cols, act=act, residual=res)
+        got = pkg.ops.linear_small(xd, wd, bias, tile_cols, act=act, residual=res, tile_rows=tile_rows)
+        again = pkg.ops.linear_small(xd, wd, bias, tile_cols, act=act, residual=res, tile_rows=tile_rows)
         want = ref + (b.double() if bias is not None else 0.0)
         if act == 1:
             want = torch.nn.functional.gelu(want)
@@ -537,12 +541,14 @@ def test_linear_small_tiles_vs_fp64(pkg, M, N, K, tile_cols):
             big = pkg.ops.linear(xd, wd, bias, act=act)
             assert (got - big).abs().max().item() <= tol
     with pytest.raises(pkg._lib.StltHipError):
-        pkg.ops.linear_small(xd[:, :K - 8].contiguous(), wd[:, :K - 8].contiguous(), bd, tile_cols)  # K % 32 != 0
+        pkg.ops.linear_small(xd[:, :K - 8].contiguous(), wd[:, :K - 8].contiguous(), bd, tile_cols, tile_rows=tile_rows)  # K % 32 != 0
+    with pytest.raises(pkg._lib.StltHipError):
+        pkg.ops.linear_small(xd, wd, bd, tile_cols + 16 if (tile_rows, tile_cols + 16) not in SMALL_TILES else 80, tile_rows=tile_rows)  # not a tile of this height
 
 
-@pytest.mark.parametrize("tile_cols", [48, 64, 96, 128, 144, 192])
+@pytest.mark.parametrize("tile_rows,tile_cols", SMALL_TILES)
 @pytest.mark.parametrize("K", [64, 96, 128, 256])
-def test_linear_small_tiles_bias_strip_under_load(pkg, tile_cols, K):
+def test_linear_small_tiles_bias_strip_under_load(pkg, tile_rows, tile_cols, K):
     """Many short tiles per workgroup (33 000 rows, 2 - 8 k-steps a tile): every tile's accumulators start from its own bias strip.  The
     strip is DMA'd in front of the tile's first k-step, so the counted wait that publishes that step publishes it too; round 4's first
     form issued it one k-step before it was read, behind loads the wait lets stay in flight, and lost that race once in a test run.
@@ -555,16 +561,16 @@ def test_linear_small_tiles_bias_strip_under_load(pkg, tile_cols, K):
     ref = (x.double() @ w.double().t() + b.double()).float().to(DEV)
     first = None
     for rep in range(12):
-        got = pkg.ops.linear_small(xd, wd, bd, tile_cols)
+        got = pkg.ops.linear_small(xd, wd, bd, tile_cols, tile_rows=tile_rows)
         assert (got - ref).abs().max().item() <= 1e-3, rep
         first = got if first is None else first
         assert torch.equal(got, first), rep
 
 
-@pytest.mark.parametrize("tile_cols", [48, 64, 96, 128, 144, 192])
-@pytest.mark.parametrize("M,n_out,k_in", [(2048, 768, 768), (2112, 2304, 768), (2048, 3072, 768), (2048, 768, 3072), (1000, 64, 1536), (77, 96, 52),
+@pytest.mark.parametrize("tile_rows,tile_cols", SMALL_TILES)
+@pytest.mark.parametrize("M,n_out,k_in", [(2048, 768, 768), (2112, 2304, 768), (2048, 3072, 768), (1088, 768, 3072), (1000, 64, 1536), (77, 96, 52),
                                           (1, 64, 4), (20000, 128, 768)])
-def test_input_grad_small_tiles_vs_fp64(pkg, M, n_out, k_in, tile_cols):
+def test_input_grad_small_tiles_vs_fp64(pkg, M, n_out, k_in, tile_rows, tile_cols):
     """csrc/gemm16.hip, WKN build: dx = dy·W (+ residual) with the weight read as it lies ([k][n] image gathered in the kernel), every tile
     width, ragged and exact shapes, against an fp64 product and against the large-tile NN kernel."""
     dy = _rand(M, n_out, seed=M + n_out, scale=1.5)
@@ -573,11 +579,11 @@ def test_input_grad_small_tiles_vs_fp64(pkg, M, n_out, k_in, tile_cols):
     dyd, wd, rd = dy.to(DEV), w.to(DEV), r.to(DEV)
     ref = dy.double() @ w.double()
     tol = 3e-6 * math.sqrt(n_out) * max(1.0, ref.abs().max().item())
-    got = pkg.ops.input_grad_small(dyd, wd, tile_cols)
-    again = pkg.ops.input_grad_small(dyd, wd, tile_cols)
+    got = pkg.ops.input_grad_small(dyd, wd, tile_cols, tile_rows=tile_rows)
+    again = pkg.ops.input_grad_small(dyd, wd, tile_cols, tile_rows=tile_rows)
     assert torch.isfinite(got).all() and torch.equal(got, again)
     assert (got.cpu().double() - ref).abs().max().item() <= tol
-    got_r = pkg.ops.input_grad_small(dyd, wd, tile_cols, residual=rd)
+    got_r = pkg.ops.input_grad_small(dyd, wd, tile_cols, residual=rd, tile_rows=tile_rows)
     assert (got_r.cpu().double() - (ref + r.double())).abs().max().item() <= tol
     if k_in % 4 == 0 and n_out % 32 == 0 and M > 1:
         lib = pkg._lib.load()
@@ -639,6 +645,12 @@ def test_ffn_block_backward_gelu_epilogue_on_small_tiles(pkg, M, p):
         scale = max(b.abs().max().item(), 1e-6)
         assert (a - b).abs().max().item() / scale <= 2e-5, name
     assert all(torch.equal(a, b) for a, b in zip(small, run(-1)))  # bitwise reproducible
+    for rows in (128, 64, 32):  # the routing restricted to one tile height (round 5: 64- and 32-row tiles): the same gradients from each
+        if os.environ.get("STLT_GEMM16") == "0":
+            break
+        for a, b, name in zip(run(rows), large, names):
+            scale = max(b.abs().max().item(), 1e-6)
+            assert (a - b).abs().max().item() / scale <= 2e-5, (rows, name)
     if p == 0.0:
         r = [t.double().requires_grad_(True) for t in host]
         hid = torch.nn.functional.gelu(r[0] @ r[1].t() + r[2])

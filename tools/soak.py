@@ -55,18 +55,18 @@ def gemm16_cases(reps):
             ref = ops.linear(x, w, b)       # the large-tile kernel
             ops.set_gemm_small_tiles(-2)
         tol = 3e-5 * math.sqrt(K) * max(1.0, ref.abs().max().item()) / 10
-        for tc in (48, 64, 96, 128, 144, 192):
-            bad += loop(f"gemm16 fwd {M}x{N}x{K} t{tc} bias", lambda: ops.linear_small(x, w, b, tc), reps, ref, tol)
-            bad += loop(f"gemm16 fwd {M}x{N}x{K} t{tc} bias+gelu", lambda: ops.linear_small(x, w, b, tc, act=1), max(reps // 3, 3))
-            bad += loop(f"gemm16 fwd {M}x{N}x{K} t{tc} bias+residual", lambda: ops.linear_small(x, w, b, tc, residual=r), max(reps // 3, 3), ref + r, tol)
+        for tr, tc in ops.SMALL_TILES:
+            bad += loop(f"gemm16 fwd {M}x{N}x{K} t{tr}x{tc} bias", lambda: ops.linear_small(x, w, b, tc, tile_rows=tr), reps, ref, tol)
+            bad += loop(f"gemm16 fwd {M}x{N}x{K} t{tr}x{tc} bias+gelu", lambda: ops.linear_small(x, w, b, tc, act=1, tile_rows=tr), max(reps // 3, 3))
+            bad += loop(f"gemm16 fwd {M}x{N}x{K} t{tr}x{tc} bias+residual", lambda: ops.linear_small(x, w, b, tc, residual=r, tile_rows=tr), max(reps // 3, 3), ref + r, tol)
     for M, n_out, k_in in ((33000, 128, 768), (20000, 768, 768), (4096, 768, 3072), (2048, 2304, 768)):
         dy, w, r = rnd(M, n_out, seed=4), rnd(n_out, k_in, seed=5, scale=1 / math.sqrt(n_out)), rnd(M, k_in, seed=6)
         with ops.gemm_scratch(DEV):
             ref = ops.gemm(dy, w, trans_b=True)
         tol = 3e-5 * math.sqrt(n_out) * max(1.0, ref.abs().max().item()) / 10
-        for tc in (48, 96, 192):
-            bad += loop(f"gemm16 dX {M}x{n_out}->{k_in} t{tc}", lambda: ops.input_grad_small(dy, w, tc), reps, ref, tol)
-            bad += loop(f"gemm16 dX {M}x{n_out}->{k_in} t{tc} +residual", lambda: ops.input_grad_small(dy, w, tc, residual=r), max(reps // 3, 3), ref + r, tol)
+        for tr, tc in ((128, 48), (128, 96), (128, 192), (64, 64), (64, 160), (64, 256), (32, 128), (32, 256)):
+            bad += loop(f"gemm16 dX {M}x{n_out}->{k_in} t{tr}x{tc}", lambda: ops.input_grad_small(dy, w, tc, tile_rows=tr), reps, ref, tol)
+            bad += loop(f"gemm16 dX {M}x{n_out}->{k_in} t{tr}x{tc} +residual", lambda: ops.input_grad_small(dy, w, tc, residual=r, tile_rows=tr), max(reps // 3, 3), ref + r, tol)
     return bad
 
 
