@@ -64,38 +64,38 @@ int launch16_any(int code, const Gemm16Args& a, int act, bool add, bool wkn, hip
 // forward, 3 - 6 % input gradient; the k-steps run at 0.80 - 0.94 of the matrix pipe's rate forward, 0.73 - 0.88 with the [k][n] gather).
 struct TileCost { int rb, nt; float a, s, e; };
 constexpr TileCost COST_FWD[] = {
-  {8, 3, 4.03f, 0.7282f, 1.39f},
-  {8, 4, 4.47f, 0.9703f, 1.49f},
-  {8, 6, 4.59f, 1.4059f, 1.97f},
-  {8, 8, 4.47f, 1.8449f, 2.32f},
-  {8, 9, 4.61f, 2.0521f, 2.99f},
-  {8, 12, 4.17f, 2.7464f, 3.41f},
-  {4, 4, 4.71f, 0.5344f, 0.36f},
-  {4, 6, 5.16f, 0.7435f, 0.69f},
-  {4, 8, 5.26f, 0.9797f, 1.21f},
-  {4, 10, 5.04f, 1.1754f, 1.57f},
-  {4, 12, 4.20f, 1.4090f, 1.88f},
-  {4, 16, 3.96f, 1.8564f, 2.52f},
-  {2, 8, 4.81f, 0.5285f, 0.33f},
-  {2, 12, 4.78f, 0.7419f, 0.83f},
-  {2, 16, 4.76f, 0.9776f, 1.35f},
+  {8, 3, 3.49f, 0.7074f, 1.76f},
+  {8, 4, 4.60f, 0.9567f, 1.57f},
+  {8, 6, 4.59f, 1.3932f, 2.06f},
+  {8, 8, 4.66f, 1.8414f, 2.27f},
+  {8, 9, 4.96f, 2.0490f, 2.68f},
+  {8, 12, 4.36f, 2.7202f, 3.48f},
+  {4, 4, 4.25f, 0.5411f, 0.43f},
+  {4, 6, 4.79f, 0.7264f, 0.89f},
+  {4, 8, 5.39f, 0.9631f, 1.25f},
+  {4, 10, 5.20f, 1.1681f, 1.57f},
+  {4, 12, 4.38f, 1.4250f, 1.50f},
+  {4, 16, 4.03f, 1.8458f, 2.54f},
+  {2, 8, 4.41f, 0.5371f, 0.34f},
+  {2, 12, 4.48f, 0.7329f, 0.89f},
+  {2, 16, 4.72f, 0.9653f, 1.33f},
 };
 constexpr TileCost COST_WKN[] = {
-  {8, 3, 4.16f, 0.8004f, 2.46f},
-  {8, 4, 4.65f, 1.0663f, 2.95f},
-  {8, 6, 4.73f, 1.5396f, 4.21f},
-  {8, 8, 5.22f, 1.9897f, 4.71f},
-  {8, 9, 5.58f, 2.1714f, 4.50f},
-  {8, 12, 5.01f, 2.9795f, 7.92f},
-  {4, 4, 6.41f, 0.5856f, 1.03f},
-  {4, 6, 6.18f, 0.8258f, 2.60f},
-  {4, 8, 5.35f, 1.0566f, 2.61f},
-  {4, 10, 4.61f, 1.2920f, 3.79f},
-  {4, 12, 4.69f, 1.5602f, 4.84f},
-  {4, 16, 5.17f, 2.0049f, 5.23f},
-  {2, 8, 6.33f, 0.5784f, 1.12f},
-  {2, 12, 5.60f, 0.8330f, 2.52f},
-  {2, 16, 4.56f, 1.0663f, 2.83f},
+  {8, 3, 4.30f, 0.7784f, 2.48f},
+  {8, 4, 4.86f, 1.0441f, 2.75f},
+  {8, 6, 4.76f, 1.5201f, 3.86f},
+  {8, 8, 5.09f, 1.9871f, 4.80f},
+  {8, 9, 5.92f, 2.1656f, 4.35f},
+  {8, 12, 5.38f, 2.9609f, 7.64f},
+  {4, 4, 6.33f, 0.5995f, 1.31f},
+  {4, 6, 6.79f, 0.7909f, 1.84f},
+  {4, 8, 5.82f, 1.0507f, 2.71f},
+  {4, 10, 5.22f, 1.2805f, 3.73f},
+  {4, 12, 4.90f, 1.5506f, 3.84f},
+  {4, 16, 5.13f, 2.0014f, 5.04f},
+  {2, 8, 6.36f, 0.5920f, 1.35f},
+  {2, 12, 6.24f, 0.7955f, 1.90f},
+  {2, 16, 5.12f, 1.0516f, 2.95f},
 };
 double est16_us(int64_t M, int64_t N, int64_t K, int rb, int nt, int64_t cus, bool wkn = false) {
   const int64_t tiles = ((M + 16 * rb - 1) / (16 * rb)) * ((N + 16 * nt - 1) / (16 * nt));

@@ -15,6 +15,9 @@
 #ifndef STLT_G16_SCHED
 #define STLT_G16_SCHED 0  // 1: the k-step's read / MFMA phases pinned with sched_barrier; 0: the compiler's own order (measured equal on narrow tiles, 3 - 8 % faster on 192-column ones: profiles/round5_gemm16_ablation.txt)
 #endif
+#ifndef STLT_G16_DEEP
+#define STLT_G16_DEEP 1  // 1: narrow wave tiles prefetch a whole k-step of fragments (0: the two-phase pipeline for every tile, A/B builds)
+#endif
 #ifndef STLT_G16_PRIO
 #define STLT_G16_PRIO 0  // s_setprio of the MFMA waves (the loader waves stay at 0); A/B builds
 #endif
@@ -63,6 +66,11 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
   constexpr int Q_NSTAGE = q_nstage<RB, NT>();
   static_assert(Q_NSTAGE >= 3, "at least three operand stages");
   constexpr int LA = Q_NSTAGE - 1;  // k-steps the loaders run ahead of the MFMA waves
+  // Narrow wave tiles (<= 3 column tiles per wave: 12 MFMAs per k-chunk) cannot cover an LDS round trip with the MFMAs of one phase.  Their
+  // MFMA waves keep a whole k-step of fragments in registers and request step s + 1's while multiplying step s, so the barrier that ends
+  // step s must already have published step s + 2: the loaders' counted wait leaves one step fewer in flight (DEEP; needs >= 4 stages).
+  constexpr bool DEEP = STLT_G16_DEEP && NTW <= 3 && Q_NSTAGE >= 4;
+  constexpr int PUB = DEEP ? 2 : 1;  // the barrier at the end of step s publishes step s + PUB
   constexpr int NI = 2 * RB + 2 * NT;   // 8-row (1 KB) LDS-DMA instructions per k-step: the X image's 2 RB, then the W image's 2 NT
   constexpr int NL_MAX = (NI + 3) / 4;  // ... dealt round-robin to the four loaders
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -160,10 +168,10 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
       if (++l_kt == nk) { ++l_it; l_kt = 0; }
       if (++l_stage == Q_NSTAGE) l_stage = 0;
     };
-    // in-order counter: once at most the instructions of the newest LA - 1 steps are in flight, everything up to the step the MFMA
+    // in-order counter: once at most the instructions of the newest LA - PUB steps are in flight, everything up to the step the MFMA
     // waves read next has landed, and the bias strip in front of it (a strip among the newer instructions only makes the wait stricter).
     // The count per step is a per-loader constant, so the wait is one of two immediates.
-    constexpr int WAIT_FULL = (LA - 1) * NL_MAX, WAIT_LESS = (LA - 1) * (NL_MAX - 1);
+    constexpr int WAIT_FULL = (LA - PUB) * NL_MAX, WAIT_LESS = (LA - PUB) * (NL_MAX - 1);
     static_assert(WAIT_FULL < 64, "vmcnt is a 6-bit counter");
     auto wait_ahead = [&]() {
       if (n_mine == NL_MAX) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT_FULL) : "memory");
@@ -198,10 +206,9 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
   const int x_row = (rb * 16 + li) * QK;
   const int w_row = (QM + cg * NTW * 16 + li) * QK;
   // A k-step is NP phases: one k-chunk of 16 per phase with all the wave's column tiles (NTW <= 6), or half the column tiles per
-  // phase (registers).  The fragments of phase p + 1 are requested before the MFMAs of phase p are issued, and those of the next stage's
-  // phase 0 right behind the barrier that publishes it, in front of the last phase's MFMAs — an order the compiler does not keep by
-  // itself (round 4's build sank every read group to its first use: three exposed LDS round trips per k-step and, with one column
-  // tile in a half, four dependent MFMAs back to back; 0.72 of the MFMA rate at 48 columns) and that sched_barrier pins here.
+  // phase (registers).  The fragments of phase p + 1 are requested behind the first MFMA group of phase p, and those of the next stage's
+  // phase 0 right behind the barrier that publishes it, in front of the last phase's MFMAs.  (STLT_G16_SCHED=1 pins that order with
+  // sched_barrier; the compiler's own placement measured equal on narrow tiles and 3 - 8 % faster on 192-column ones.)
   constexpr bool SPLIT = NTW > 6;
   constexpr int NP = SPLIT ? 4 : 2;
   constexpr int PT = SPLIT ? (NTW + 1) / 2 : NTW;  // column tiles per phase (the second half of a split chunk has NTW - PT)
@@ -259,35 +266,9 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
 #define G16_PIN() ((void)0)
 #endif
 
-  __builtin_amdgcn_s_barrier();  // the loaders' counted wait + this barrier publish step 0 and the first bias strip
-  init_acc(0);
   int c_it = 0, c_kt = 0, stage = 0;
-  read_phase(0, 0, F[0]);
-  if (STLT_G16_ABLATE & 2) read_phase(0, 1, F[1]);
-  for (int step = 0; step < total_steps; ++step) {
-    const int next_stage = stage + 1 == Q_NSTAGE ? 0 : stage + 1;
-    const bool ablate_reads = (STLT_G16_ABLATE & 2) && step > 0;
-#pragma unroll
-    for (int p = 0; p + 1 < NP; ++p) {
-      // the phase's first MFMA group goes in front of the next phase's read requests: the compiler's wait for this phase's fragments
-      // is an lgkmcnt(0) (the counter is shared with scalar loads), which behind the new requests would wait for those as well
-      mfma_phase(p, F[p & 1], 0, 1);
-      G16_PIN();
-      if (!ablate_reads) read_phase(stage, p + 1, F[(p + 1) & 1]);
-      G16_PIN();
-      mfma_phase(p, F[p & 1], 1, 4);
-      G16_PIN();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own fragment reads of this stage are done
-    if (!(STLT_G16_ABLATE & 4)) __builtin_amdgcn_s_barrier();  // retire the stage; step+1 landed
-    // the next stage's first fragments (after the last k-step of a tile: the next tile's; after the very last step: a dead read), under the last phase's MFMAs
-    if (!ablate_reads) read_phase(next_stage, 0, F[0]);
-    G16_PIN();
-    mfma_phase(NP - 1, F[1], 0, 4);
-    G16_PIN();
-    stage = next_stage;
-    if (++c_kt < nk) continue;
-
+  // epilogue of tile c_it (its last k-step's MFMAs are issued), then the next tile's accumulators
+  auto tile_done = [&](int step) {
     // ---- epilogue of tile c_it: lane (li, lg) holds columns 16 (cg NTW + t) + 4 lg .. + 3 of row 16 rb + li
     int tm, tn;
     item_of(c_it, tm, tn);
@@ -357,7 +338,98 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
     }
     ++c_it;
     c_kt = 0;
-    if (step + 1 < total_steps) init_acc(c_it);  // next tile: accumulators from its bias strip (published by the last k-step's barrier)
+    if (step + 1 < total_steps) init_acc(c_it);  // next tile: accumulators from its bias strip (published by an earlier barrier)
+  };
+
+  __builtin_amdgcn_s_barrier();  // the loaders' counted wait + this barrier publish step 0 (DEEP: and step 1) and the first bias strip
+  init_acc(0);
+  if constexpr (DEEP) {
+    struct Set { f32x4 x[2]; f32x4 w[2][NTW]; };  // a whole k-step of fragments: both k-chunks
+    // read item q of a k-step's 2 (1 + NTW) fragments: chunk c = q / (1 + NTW), then x (i = 0) or column tile i - 1
+    auto read_item = [&](const float* sp, int q, Set& r) {
+      const int c = q / (1 + NTW), i = q - c * (1 + NTW);
+      if (WKN) {  // k order 16 c + lg + 4 e for MFMA e: element lg of X chunk 4 c + e; row 16 c + lg + 4 e of the [k][n] W image
+        if (i == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r.x[c][e] = sp[x_row + (((4 * c + e) ^ sw) * 4) + lg];
+        } else {
+          const float* wk = sp + QM * QK + (16 * c + lg) * BN + cg * NTW * 16 + li;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r.w[c][i - 1][e] = wk[4 * e * BN + (i - 1) * 16];
+        }
+      } else {
+        const int off = ((4 * c + lg) ^ sw) * 4;
+        if (i == 0) r.x[c] = *reinterpret_cast<const f32x4*>(sp + x_row + off);
+        else r.w[c][i - 1] = *reinterpret_cast<const f32x4*>(sp + w_row + (i - 1) * 16 * QK + off);
+      }
+    };
+    auto read_set = [&](int st, Set& r) {
+#pragma unroll
+      for (int q = 0; q < 2 * (1 + NTW); ++q) read_item(smem + st * STAGE, q, r);
+    };
+    auto mfma_group = [&](const Set& r, int g) {  // group g = (k-chunk g / 4, MFMA g % 4 of the chunk) on every column tile
+      const int c = g >> 2, e = g & 3;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.w[c][t][e], r.x[c][e], acc[t], 0, 0, 0);
+    };
+    Set A, B;
+    read_set(0, A);
+    // One k-step: the 8 MFMA groups of `cur` with the read requests of step + 1 spread behind the first four of them (a burst of all
+    // 2 (1 + NTW) requests from eight lock-stepped waves fills the LDS queue and holds the waves' MFMAs back behind their own requests),
+    // then the wait and the barrier.  The order is pinned (sched_barrier): left alone, hipcc moves the wait and the barrier up in front of the
+    // MFMAs (register-only instructions to it) and the requests down to their first use.
+    constexpr int NRD = 2 * (1 + NTW), RPG = (NRD + 3) / 4;  // requests per k-step, per MFMA group
+    auto kstep = [&](const Set& cur, Set& nxt, int step) {
+      const int next_stage = stage + 1 == Q_NSTAGE ? 0 : stage + 1;
+      const float* sp = smem + next_stage * STAGE;  // step + 1, published by the previous barrier (after the very last step: a dead read)
+      const bool reads = !((STLT_G16_ABLATE & 2) && step > 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        mfma_group(cur, g);  // group 0 in front of the first requests: the compiler's wait for `cur` is an lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < 4 && reads) {
+#pragma unroll
+          for (int q = g * RPG; q < (g + 1) * RPG && q < NRD; ++q) read_item(sp, q, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // step + 1's fragments are in registers
+      if (!(STLT_G16_ABLATE & 4)) __builtin_amdgcn_s_barrier();  // publishes step + 2
+      stage = next_stage;
+      if (++c_kt == nk) tile_done(step);
+    };
+    if (STLT_G16_ABLATE & 2) read_set(1 % Q_NSTAGE, B);
+    for (int step = 0; step < total_steps; step += 2) {
+      kstep(A, B, step);
+      if (step + 1 < total_steps) kstep(B, A, step + 1);
+    }
+    return;
+  }
+  read_phase(0, 0, F[0]);
+  if (STLT_G16_ABLATE & 2) read_phase(0, 1, F[1]);
+  for (int step = 0; step < total_steps; ++step) {
+    const int next_stage = stage + 1 == Q_NSTAGE ? 0 : stage + 1;
+    const bool ablate_reads = (STLT_G16_ABLATE & 2) && step > 0;
+#pragma unroll
+    for (int p = 0; p + 1 < NP; ++p) {
+      // the phase's first MFMA group goes in front of the next phase's read requests: the compiler's wait for this phase's fragments
+      // is an lgkmcnt(0) (the counter is shared with scalar loads), which behind the new requests would wait for those as well
+      mfma_phase(p, F[p & 1], 0, 1);
+      G16_PIN();
+      if (!ablate_reads) read_phase(stage, p + 1, F[(p + 1) & 1]);
+      G16_PIN();
+      mfma_phase(p, F[p & 1], 1, 4);
+      G16_PIN();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own fragment reads of this stage are done
+    if (!(STLT_G16_ABLATE & 4)) __builtin_amdgcn_s_barrier();  // retire the stage; step+1 landed
+    // the next stage's first fragments (after the last k-step of a tile: the next tile's; after the very last step: a dead read), under the last phase's MFMAs
+    if (!ablate_reads) read_phase(next_stage, 0, F[0]);
+    G16_PIN();
+    mfma_phase(NP - 1, F[1], 0, 4);
+    G16_PIN();
+    stage = next_stage;
+    if (++c_kt == nk) tile_done(step);
   }
 #undef G16_PIN
 }

@@ -33,6 +33,7 @@ CASES = [  # (M, N, K, act, tile rows, tile cols)
     (14336, 768, 768, 0, 128, 48), (14336, 768, 768, 0, 64, 96), (14336, 3072, 768, 1, 128, 192), (14336, 3072, 768, 1, 64, 256),
     (2048, 768, 768, 0, 128, 48), (2048, 3072, 768, 1, 128, 192), (2048, 768, 3072, 0, 128, 48),
     (1088, 768, 768, 0, 64, 64), (1088, 2304, 768, 0, 64, 160), (5440, 2304, 768, 0, 64, 256), (5440, 768, 3072, 0, 64, 256),
+    (1088, 768, 3072, 0, 64, 64), (1088, 768, 768, 0, 32, 128), (2048, 2304, 768, 0, 128, 144), (14336, 768, 3072, 0, 128, 48), (2112, 768, 768, 0, 128, 64),
 ]
 
 
