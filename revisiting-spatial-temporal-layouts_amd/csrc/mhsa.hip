@@ -221,15 +221,18 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
   const int sw = (li_ >> 1) & 7;  // rows 16 rb + li_ and 16 t + li_ share (row >> 1) & 7
   const int x_row = (rb * 16 + li_) * FK;
   const int w_row = (FM + li_) * FK;  // + 16 * FK per 16-channel tile
-  struct Frags { f32x4 x; f32x4 w[6]; };
-  auto read_frags = [&](int stage, int hc) {  // hc = half-chunk 0..3: k-chunk c = hc >> 1 (16 k each), tiles 6 (hc & 1) .. +5
+  // A k-step is four phases (k-chunk c = p >> 1 of 16, column tiles 6 (p & 1) .. + 5); the chunk's X fragment is read once and shared by
+  // its two halves; the fragments of phase p + 1 are requested behind the first MFMA group of phase p (gemm16_kernel.h has the why)
+  struct Frags { f32x4 w[6]; };
+  f32x4 xf[2];
+  Frags F[2];
+  auto read_phase = [&](int stage, int p, Frags& f) {
     const float* s = smem + stage * F_STAGE;
-    const int off = ((4 * (hc >> 1) + lg_) ^ sw) * 4;
-    Frags f;
-    f.x = *reinterpret_cast<const f32x4*>(s + x_row + off);
+    const int c = p >> 1;
+    const int off = ((4 * c + lg_) ^ sw) * 4;
+    if ((p & 1) == 0) xf[c] = *reinterpret_cast<const f32x4*>(s + x_row + off);
 #pragma unroll
-    for (int t = 0; t < 6; ++t) f.w[t] = *reinterpret_cast<const f32x4*>(s + w_row + (6 * (hc & 1) + t) * 16 * FK + off);
-    return f;
+    for (int t = 0; t < 6; ++t) f.w[t] = *reinterpret_cast<const f32x4*>(s + w_row + (6 * (p & 1) + t) * 16 * FK + off);
   };
   f32x4 acc[12];  // tile t = 16 output columns: q channels 16 t .. (t < 4), k (4 <= t < 8), v (t >= 8); lane (li_, lg_): token li_, channels 4 lg_ .. + 3
   auto init_acc = [&](int it) {
@@ -237,19 +240,20 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
 #pragma unroll
     for (int t = 0; t < 12; ++t) acc[t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
   };
-  auto mfma_half = [&](const Frags& f, int half) {
+  auto mfma_phase = [&](int p, const Frags& f, int e_lo, int e_hi) {
+    const int c = p >> 1, t0 = 6 * (p & 1);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = e_lo; e < e_hi; ++e)
 #pragma unroll
       for (int t = 0; t < 6; ++t)
-        acc[6 * half + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[t][e], f.x[e], acc[6 * half + t], 0, 0, 0);
+        acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[t][e], xf[c][e], acc[t0 + t], 0, 0, 0);
   };
 
   __builtin_amdgcn_s_barrier();  // the loaders' counted wait + this barrier publish step 0 and the first bias strip
   init_acc(0);
   int c_it = 0, c_kt = 0, stage = 0;
   unsigned pad_byte = 1u;
-  Frags fa = read_frags(0, 0), fb;
+  read_phase(0, 0, F[0]);
   for (int step = 0; step < total_steps; ++step) {
     const int next_stage = stage + 1 == F_NSTAGE ? 0 : stage + 1;
     if (c_kt == 0) {  // this item's key-padding byte of the wave's row li_: in flight under the whole product
@@ -258,17 +262,17 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
       const int g_row = grp * a.rows_per_item + rb * 16 + li_;
       pad_byte = (rb * 16 + li_ < a.rows_per_item && g_row < M) ? (unsigned)a.kpm[g_row] : 1u;
     }
-    fb = read_frags(stage, 1);
-    mfma_half(fa, 0);
-    fa = read_frags(stage, 2);
-    mfma_half(fb, 1);
-    fb = read_frags(stage, 3);
-    mfma_half(fa, 0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      mfma_phase(p, F[p & 1], 0, 1);  // in front of the next phase's requests: the compiler's wait for this phase's fragments is an lgkmcnt(0)
+      read_phase(stage, p + 1, F[(p + 1) & 1]);
+      mfma_phase(p, F[p & 1], 1, 4);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own fragment reads of this stage are done
     __builtin_amdgcn_s_barrier();                        // retire the stage; step+1 landed
     const bool item_done = c_kt + 1 == nk;
-    if (!item_done) fa = read_frags(next_stage, 0);  // (at the end of an item the attention phase comes first: fewer live registers there)
-    mfma_half(fb, 1);
+    if (!item_done) read_phase(next_stage, 0, F[0]);  // (at the end of an item the attention phase comes first: fewer live registers there)
+    mfma_phase(3, F[1], 0, 4);
     const int dead_stage = stage;
     stage = next_stage;
     ++c_kt;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     c_kt = 0;
     if (step + 1 < total_steps) {  // next item: accumulators from its bias strip (published by the last k-step's barrier), first fragments
       init_acc(c_it);
-      fa = read_frags(stage, 0);
+      read_phase(stage, 0, F[0]);
     }
   }
 }

@@ -205,3 +205,21 @@ def test_trainer_fit_refuses_a_global_batch_that_does_not_divide_over_the_ranks(
     batch = {"categories": torch.zeros(6, 3, 2, dtype=torch.int64), "labels": torch.zeros(6, dtype=torch.int64)}
     with pytest.raises(ValueError, match="does not divide"):
         tr.fit([batch], "cpu")
+
+
+def test_every_environment_knob_is_documented():
+    """INTEGRATION.md section 2 lists every STLT_* environment variable the package and bench.py read (one table, with defaults)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set()
+    srcs = [os.path.join(root, "bench.py")]
+    for dp, _, fs in os.walk(os.path.join(root, "revisiting-spatial-temporal-layouts_amd")):
+        srcs += [os.path.join(dp, f) for f in fs if f.endswith((".hip", ".h", ".py"))]
+    for path in srcs:
+        text = open(path, errors="ignore").read()
+        names |= set(re.findall(r'getenv\("(STLT_[A-Z0-9_]+)"\)', text))
+        names |= set(re.findall(r'environ(?:\.get\(|\[)"(STLT_[A-Z0-9_]+)"', text))
+    assert len(names) >= 25
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, f"undocumented environment knobs: {missing}"
