@@ -17,6 +17,12 @@
 // next item's K / Q fragments as soon as the last Q·K^T has consumed the registers, its V tile as soon as the last P·V
 // has read the (single) V buffer.  The output leaves without an LDS transpose: lane (query, g) holds 4 consecutive
 // channels per channel block = one 16-byte store.
+// TAIL  (causal, L = 16 NB + 1 — the reference's real layouts: T = layout_num_frames + 1 = 17 / 33, datasets.py:97-113): the last token
+//         is seen as a key by itself only and as a query sees every key, so the item is NB full blocks plus one row handled beside them:
+//         its scores against the NB key blocks come from one more Q·K^T pass (the query block holds 16 copies of that row), its own
+//         key's score and value row are a 64-channel dot product and an axpy on the vector ALU.  No (NB + 1)-th key block is held, no
+//         V rows beyond 16 NB sit in LDS: the register / LDS footprint of the NB-block kernel instead of the NB + 1 one (33 tokens as three
+//         blocks: 208 VGPRs, two waves per SIMD, 0.57 of the HBM peak).
 // SPLIT (small grids): the unit of work is (item, query block) instead of item, so that a launch with fewer items than
 // wave slots spreads over NB times as many waves and each wave's dependent chain is one query block long; a unit loads
 // only the key / value blocks it uses.
@@ -42,9 +48,11 @@ struct Geo16 {
   float scale;
 };
 
-template <int NB, bool FULL, bool CAUSAL, bool SPLIT>
-__global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
+// (TAIL with two full blocks — 33 tokens — is held to three waves per SIMD: the compiler's own allocation is 184 registers, 16 over the step)
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false>
+__global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2) ? 3 : 1) void attn16_kernel(const Geo16 geo) {
   static_assert(FULL || !SPLIT, "DIAG items are independent blocks already");
+  static_assert(!TAIL || (FULL && CAUSAL && !SPLIT), "TAIL: one causal sequence of 16 NB + 1 tokens per item");
   constexpr int VROWS = NB * 16;
   __shared__ __attribute__((aligned(16))) float smem_all[WAVES16 * (VROWS * DH16 + VROWS)];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -113,10 +121,22 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
   auto load_q = [&](int u, int b) __attribute__((always_inline)) {
     int t0, head, qb0;
     unit_geo(u, t0, head, qb0);
-    const int tok = row_token(t0, b, li);
+    const int tok = row_token(t0, b, li);  // (TAIL, b == NB: the tail row for li == 0, and spare_token = the same row for the other lanes)
     const float* row = geo.qkv + head * DH16 + 4 * lg + (int64_t)(tok >= 0 ? tok : spare_token(t0, b)) * ld;
 #pragma unroll
     for (int c = 0; c < 4; ++c) qc[c] = *reinterpret_cast<const f32x4*>(row + 16 * c);
+  };
+  // TAIL: the last token's query, key and value rows, ONE channel per lane (3 registers; in the MFMA layout they would be 16 each and cost
+  // the kernel a wave per SIMD): the self score is a wave reduction, the value row reaches the output layout through 16 lane shuffles
+  float q1 = 0.f, k1 = 0.f, v1 = 0.f;
+  int tail_pad = 1;
+  auto load_tail = [&](int u) __attribute__((always_inline)) {
+    int t0, head, qb0;
+    unit_geo(u, t0, head, qb0);
+    const int tk = t0 + L - 1;  // items are whole sequences of the batch: always a valid token
+    const float* row = geo.qkv + (int64_t)tk * ld + head * DH16 + lane;
+    q1 = row[0]; k1 = row[d]; v1 = row[2 * d];
+    tail_pad = geo.kpm[tk];
   };
   auto load_v = [&](int u) __attribute__((always_inline)) {
     int t0, head, qb0;
@@ -132,13 +152,13 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
       __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)(Vs + i * 256), 16, 0, 0);
     }
   };
-
   {
     int t0, head, qb0;
     unit_geo(unit, t0, head, qb0);
     load_k(unit);
     load_q(unit, qb0);
     load_v(unit);
+    if (TAIL) load_tail(unit);
   }
   for (;;) {
     int t0, head, qb0;
@@ -164,6 +184,10 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
             for (int e = 0; e < 4; ++e) st[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kb][c][e], qc[c][e], st[kb], 0, 0, 0);
         }
       }
+      // TAIL pass (qb == NB): the tail query against its own key (one channel per lane, summed over the wave)
+      const bool tail_pass = TAIL && qb == NB;
+      float s_tail = 0.f;
+      if (tail_pass) s_tail = tail_pad == 0 ? wave_sum(q1 * k1) * geo.scale : -1e30f;
       // the Q registers are dead (after the last block the K registers too): next loads go under the softmax / P·V
       if (!last) {
         load_q(unit, qb + 1);
@@ -192,6 +216,7 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
       }
       m = fmaxf(m, __shfl_xor(m, 16, 64));
       m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (tail_pass) m = fmaxf(m, s_tail);
       float sum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
@@ -205,6 +230,11 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
       }
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
+      float p_tail = 0.f;
+      if (tail_pass) {
+        p_tail = s_tail > -1e29f ? __expf(s_tail - m) : 0.f;
+        sum += p_tail;
+      }
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
       // ---- O^T[channel][query] += V^T·P^T: MFMA step (kb, r) sums keys kb*16 + 4g + r over g
       f32x4 o[4];
@@ -223,9 +253,16 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
           }
         }
       }
+      if (tail_pass) {  // the tail's own value row: channel 16 cb + 4 lg + r sits in lane 16 cb + 4 lg + r
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[cb][r] = fmaf(p_tail, __shfl(v1, cb * 16 + 4 * lg + r, 64), o[cb][r]);
+      }
       if (last && have_next) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the unit's last V reads have returned: the tile can be refilled
         load_v(n_unit);
+        if (TAIL) load_tail(n_unit);
       }
       // ---- store: lane (query li, lg) holds channels cb*16 + 4*lg .. +3 of its query
       if (tok >= 0) {
@@ -238,7 +275,7 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
       pass(qb0, true);
     } else {
 #pragma unroll
-      for (int qb = 0; qb < NB; ++qb) pass(qb, qb == NB - 1);
+      for (int qb = 0; qb < (TAIL ? NB + 1 : NB); ++qb) pass(qb, qb == (TAIL ? NB : NB - 1));
     }
     if (!have_next) break;
     unit = n_unit;
@@ -246,24 +283,24 @@ __global__ __launch_bounds__(64 * WAVES16) void attn16_kernel(const Geo16 geo) {
 }
 
 // wave slots of the device for one instantiation (workgroups per CU x CUs x waves per workgroup)
-template <int NB, bool FULL, bool CAUSAL, bool SPLIT>
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false>
 int64_t wg_capacity16() {
   static StltPerDeviceInt occ;
   int& wg_per_cu = occ.ref();
   if (wg_per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn16_kernel<NB, FULL, CAUSAL, SPLIT>, 64 * WAVES16, 0) != hipSuccess || wg_per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn16_kernel<NB, FULL, CAUSAL, SPLIT, TAIL>, 64 * WAVES16, 0) != hipSuccess || wg_per_cu <= 0)
       wg_per_cu = 1;
   }
   return (int64_t)wg_per_cu * stlt_device_cus();
 }
 
-template <int NB, bool FULL, bool CAUSAL, bool SPLIT>
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false>
 int launch16_as(const Geo16& g, hipStream_t s) {
   const int64_t n_units = SPLIT ? (int64_t)g.n_items * NB : g.n_items;
   int64_t n_wg = (n_units + WAVES16 - 1) / WAVES16;
-  const int64_t cap = wg_capacity16<NB, FULL, CAUSAL, SPLIT>();
+  const int64_t cap = wg_capacity16<NB, FULL, CAUSAL, SPLIT, TAIL>();
   if (n_wg > cap) n_wg = cap;
-  hipLaunchKernelGGL((attn16_kernel<NB, FULL, CAUSAL, SPLIT>), dim3((unsigned)n_wg), dim3(64 * WAVES16), 0, s, g);
+  hipLaunchKernelGGL((attn16_kernel<NB, FULL, CAUSAL, SPLIT, TAIL>), dim3((unsigned)n_wg), dim3(64 * WAVES16), 0, s, g);
   return stlt_check_launch("attn16_kernel");
 }
 
@@ -308,6 +345,13 @@ int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, i
     const int64_t items = S * H;
     if (items > 0x7fffffffLL) return 0;
     g.n_items = (int)items;
+    // causal sequences of 16 NB + 1 tokens (the reference's T = 17 / 33; 49): NB full blocks + the tail row (STLT_ATTN16_TAIL=0: as NB + 1 blocks)
+    static const int tail_on = [] { const char* e = getenv("STLT_ATTN16_TAIL"); return e ? atoi(e) : 1; }();
+    if (causal && tail_on && L % 16 == 1) {
+      rc = L == 17 ? launch16_as<1, true, true, false, true>(g, s) : (L == 33 ? launch16_as<2, true, true, false, true>(g, s) : launch16_as<3, true, true, false, true>(g, s));
+      *taken = true;
+      return rc;
+    }
     if (L <= 32) rc = causal ? launch16_full<2, true>(g, s) : launch16_full<2, false>(g, s);
     else if (L <= 48) rc = causal ? launch16_full<3, true>(g, s) : launch16_full<3, false>(g, s);
     else rc = causal ? launch16_full<4, true>(g, s) : launch16_full<4, false>(g, s);

@@ -39,6 +39,8 @@ def main():
     args = ap.parse_args()
     for B in args.batches:
         run(B, 32, 12, True, args.iters)        # cfg2 temporal
+        run(B, 33, 12, True, args.iters)        # the released checkpoints' layout: 32 + 1 frames (datasets.py:97-113)
+        run(B, 17, 12, True, args.iters)        # the parser's default: 16 + 1 frames
         run(B * 32, 7, 12, False, args.iters)   # cfg2 spatial
     for B in (16, 64, 256):
         run(B, 64, 12, True, args.iters)        # cfg4 temporal
