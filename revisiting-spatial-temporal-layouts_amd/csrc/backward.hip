@@ -3,6 +3,7 @@
 // backward of the embedding / frames-embedding / last-state gather.  All parameter-gradient reductions are
 // two-stage (per-wave or per-block partials, then a fixed-order sum): bitwise reproducible, no float atomics.
 // The large products (dX = dY·W, dW = dYᵀ·X) run on the MFMA kernel of gemm.hip.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -715,7 +716,11 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   if (!dy || !a || !w || !ds || !scratch) return stlt_set_error(STLT_EINVAL, "ln_bwd: null pointer");
   if (d <= 0 || d % 4 || d > 2048) return stlt_set_error(STLT_EINVAL, "ln_bwd: bad d=%lld", (long long)d);
   if (M == 0) return 0;
-  int64_t blocks = (M + 4 * RW_WAVES - 1) / (4 * RW_WAVES);  // ~4 rows per persistent wave until the cap binds
+  // ~4 rows per persistent wave until the cap binds; few rows (the temporal tower at 64 clips: 2048) get a wave per row — at 4 rows per wave
+  // the launch is 128 workgroups for 256 CUs and a wave's four dependent row passes (22 us for 31 MB; STLT_LN_BWD_ROWS_PER_WAVE=4 restores it)
+  static const int rpw_env = [] { const char* e = getenv("STLT_LN_BWD_ROWS_PER_WAVE"); return e ? atoi(e) : 0; }();
+  const int64_t rpw = rpw_env > 0 ? rpw_env : (M <= 512 * RW_WAVES ? 1 : 4);
+  int64_t blocks = (M + rpw * RW_WAVES - 1) / (rpw * RW_WAVES);
   if (blocks > 512) blocks = 512;  // one partial row set per block (scratch is sized for that)
   StltProfScope ps(STLT_K_LN_BWD, s);
   if (nv_for(d) > 4) {  // d > 1024: accumulators in LDS (no shape of the path has such rows; kept working without scratch memory)
