@@ -432,6 +432,15 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
  * gemm_scratch (forward calls): NULL, or stlt_gemm_scratch_bytes() of device memory lent for the call's stream-K launches.
  * The backward calls ACCUMULATE (+=) into the gradient struct's buffers (NULL members are skipped), write dx (and dc, the
  * gradient wrt the context tokens of a cross-attention block), and recompute the dropout masks from (drop_p, seed, site0). */
+/* Deferred weight gradients of the block calls (per calling thread).  After stlt_block_dw_defer(1) the *_block_bwd_train calls queue their
+ * weight-gradient products (g_w += dyᵀ·x) instead of launching them; stlt_block_dw_flush runs the queue as grouped stream-K launches of up to
+ * 32 products on `stream` (the stream the blocks ran on) with stlt_gemm_scratch_bytes() of scratch, in queue order (two products into the same
+ * gradient never share a launch).  The CALLER keeps every operand of the queued products alive and unchanged until the flush: the blocks'
+ * scratch buffers (one per call: they hold the output gradients) and the forward activations they were handed.  mode 0 stops collecting
+ * (queued products stay), -1 stops and discards.  A training step of the fusion models (models.py:403-431) makes 34 block calls. */
+int stlt_block_dw_defer(int mode);
+int stlt_block_dw_pending(void);
+int stlt_block_dw_flush(void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream);
 size_t stlt_block_scratch_bytes(int64_t rows, int64_t d);
 int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_t H, float eps, const float* x, int64_t Lq, const float* c,
                               int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed, uint32_t site0, float* q,

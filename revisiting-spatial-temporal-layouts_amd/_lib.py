@@ -93,6 +93,9 @@ SIGNATURES = {
     "stlt_set_gemm_small_tiles": (C.c_int, [C.c_int]),
     "stlt_set_train_side_stream": (C.c_int, [C.c_int]),
     "stlt_get_train_side_stream": (C.c_int, []),
+    "stlt_block_dw_defer": (C.c_int, [C.c_int]),
+    "stlt_block_dw_pending": (C.c_int, []),
+    "stlt_block_dw_flush": (C.c_int, [_vp, C.c_size_t, _vp]),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
     "stlt_weight_grad_group": (C.c_int, [_vp, C.c_int, _vp]),

@@ -541,6 +541,52 @@ def _sk_scratch(device) -> torch.Tensor:
 
 
 
+_DW_DEFER = {"on": False, "keep": []}
+
+
+class deferred_block_weight_grads:
+    """Context manager around ONE backward pass of a model built from the block Functions (AttnBlockFn / FfnBlockFn), on the current
+    stream: the blocks queue their weight-gradient products instead of launching 2 - 4 of them per block, and the exit runs the queue as
+    grouped launches of up to 32 products (include/stlt_hip.h: stlt_block_dw_defer / _flush).  Only blocks whose parameter gradients are
+    accumulated in place (train.Trainer's bound flat buffer: grad_targets) take part; their scratch buffers and forward activations are
+    kept alive until the flush.  The gradients are complete when the `with` block is left."""
+
+    def __enter__(self):
+        lib = L.load()
+        L.check(lib.stlt_block_dw_defer(-1), "stlt_block_dw_defer")
+        L.check(lib.stlt_block_dw_defer(1), "stlt_block_dw_defer")
+        _DW_DEFER["on"] = True
+        _DW_DEFER["keep"] = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        lib = L.load()
+        _DW_DEFER["on"] = False
+        try:
+            if exc_type is None and lib.stlt_block_dw_pending() > 0:
+                dev = torch.device("cuda", torch.cuda.current_device())
+                sk = _sk_scratch(dev)
+                L.check(lib.stlt_block_dw_flush(sk.data_ptr(), sk.numel(), _stream()), "stlt_block_dw_flush")
+        finally:
+            lib.stlt_block_dw_defer(-1)
+            _DW_DEFER["keep"] = []  # torch's allocator recycles by the current stream: the flush's launches are enqueued on it
+        return False
+
+
+def _block_scratch(nbytes: int, device, in_place: bool, keep) -> torch.Tensor:
+    """Scratch of a block backward: the shared per-device buffer, or — while weight gradients are deferred and this block's go in place —
+    a buffer of its own that lives (with the activations in `keep`) until the flush."""
+    lib = L.load()
+    if _DW_DEFER["on"] and in_place:
+        L.check(lib.stlt_block_dw_defer(1), "stlt_block_dw_defer")
+        sc = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _DW_DEFER["keep"].append((sc,) + tuple(keep))
+        return sc
+    if _DW_DEFER["on"]:
+        L.check(lib.stlt_block_dw_defer(0), "stlt_block_dw_defer")  # this block launches its own products (temporaries handed back to autograd)
+    return _scratch(nbytes, device)
+
+
 def _block_dropout(p: float):
     """(p, seed, site0) of a block call: one seed per call from torch's CPU generator, site ids site0 and site0 + 1."""
     p = float(p)
@@ -626,7 +672,8 @@ class AttnBlockFn(torch.autograd.Function):
         dc = torch.empty_like(c) if (c is not None and ctx.needs_input_grad[1]) else None
         params = L.AttnBlockParams(*[_p(t) for t in ws])
         gstruct = L.AttnBlockParams(*[_p(t) for t in targets])
-        sc = _scratch(int(lib.stlt_block_scratch_bytes(S * max(Lq, Lk), d)), x.device)
+        in_place = all(r is None for r, need in zip(grads, ctx.needs_input_grad[7:13]) if need)
+        sc = _block_scratch(int(lib.stlt_block_scratch_bytes(S * max(Lq, Lk), d)), x.device, in_place, (x, c, att, a, q, kv))
         L.check(lib.stlt_attn_block_bwd_train(C.byref(params), C.byref(gstruct), d, heads, eps, _p(x), Lq, _p(c), Lk, _p(kpm8), int(causal), S, p, seed,
                                               site, _p(q), _p(kv), _p(att), _p(a), _p(dy), _p(dx), _p(dc), sc.data_ptr(), sc.numel(), _stream()),
                 "stlt_attn_block_bwd_train")
@@ -670,7 +717,8 @@ class FfnBlockFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         params = L.FfnBlockParams(*[_p(t) for t in ws])
         gstruct = L.FfnBlockParams(*[_p(t) for t in targets])
-        sc = _scratch(int(lib.stlt_block_scratch_bytes(M, d)), x.device)
+        in_place = all(r is None for r, need in zip(grads, ctx.needs_input_grad[5:11]) if need)
+        sc = _block_scratch(int(lib.stlt_block_scratch_bytes(M, d)), x.device, in_place, (x, u, h, f))
         L.check(lib.stlt_ffn_block_bwd_train(C.byref(params), C.byref(gstruct), d, eps, act, int(inner), _p(x), M, p, seed, site, _p(u), _p(h), _p(f),
                                              _p(dy), _p(dx), sc.data_ptr(), sc.numel(), _stream()), "stlt_ffn_block_bwd_train")
         return (dx, None, None, None, None, *grads)

@@ -21,7 +21,12 @@ from typing import Dict, Iterable, List, Optional
 import torch
 import torch.nn.functional as F
 
+import os
+
 from . import dist as D
+from . import ops
+
+_BLOCK_DW_DEFER = os.environ.get("STLT_BLOCK_DW_DEFER", "1") != "0"  # A/B knob: the fusion models' weight gradients per block instead of deferred
 
 
 def add_weight_decay(model: torch.nn.Module, weight_decay: float) -> List[dict]:
@@ -324,7 +329,13 @@ class Trainer:
             grads.append(g)
         self.bound.accumulating = True
         try:
-            torch.autograd.backward(heads, grads)
+            # the blocks' weight-gradient products (2 - 4 per block, 34 blocks in CACNF) are queued and run as a few grouped launches when
+            # the backward pass is through (ops.deferred_block_weight_grads; STLT_BLOCK_DW_DEFER=0: per block, as before)
+            if _BLOCK_DW_DEFER:
+                with ops.deferred_block_weight_grads():
+                    torch.autograd.backward(heads, grads)
+            else:
+                torch.autograd.backward(heads, grads)
         finally:
             self.bound.accumulating = False
         flat = self.bound.flat

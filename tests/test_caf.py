@@ -281,3 +281,47 @@ def test_trainer_on_a_fusion_model_matches_the_stock_loop(pkg):
     assert worst <= 5e-4, worst  # lr / 2: Adam's m / sqrt(v) amplifies rounding differences of near-zero gradients up to the step size
     untouched = [n for (n, a), b in zip(ours.named_parameters(), ref.parameters()) if b.grad is None]
     assert untouched and all("encoder_layer" in n or "score_embeddings" in n or "classifier" in n for n in untouched), untouched
+
+
+def test_deferred_block_weight_gradients_match_the_per_block_launches(pkg):
+    """Round 5: inside a Trainer step the fusion models' blocks queue their weight-gradient products and the end of the backward pass runs
+    them as grouped launches of up to 32 products (ops.deferred_block_weight_grads; stlt_block_dw_defer / _flush).  Same gradients as the
+    per-block launches to rounding (the grouping changes the stream-K split, i.e. the summation order), products are really queued, a
+    weight shared by two blocks (the fusion models' cross-attention, models.py:411-419) accumulates both contributions, and the queue is
+    empty afterwards."""
+    kw = dict(pkg.synth.model_kwargs(NAME), **EXTRA)
+    kw["hidden_dropout_prob"] = 0.0
+    c = pkg.synth.CONFIGS[NAME]
+    B = 8  # 8 clips x 16 frames = 128 layout rows (a multiple of 32: grouped launches); the 8 x 33 appearance rows keep their own launches
+    batch = pkg.synth.make_batch(B, c["T"], c["N"], seed=31)
+    batch["appearance_features"] = pkg.synth.make_appearance_features(B, seed=32)
+    batch = {k: v.to("cuda") for k, v in batch.items()}
+    batch["labels"] = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(6)).cuda()
+    lib = pkg._lib.load()
+    flats, queued = [], []
+    for defer in (True, False):
+        m = pkg.CrossAttentionCentralNetFusion(pkg.MultimodalModelConfig(**kw))
+        m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=7))
+        m.train(False).to("cuda")
+        tr = pkg.train.Trainer(m, "something", learning_rate=1e-3, weight_decay=1e-3, clip_val=5.0, warmup_steps=0, total_steps=1000)
+        tr.bound.zero()
+        heads = list(m(batch).values())
+        grads = [pkg.train.fused_criterion(v, batch["labels"], "something", 1.0 / len(heads))[1] for v in heads]
+        tr.bound.accumulating = True
+        try:
+            if defer:
+                with pkg.ops.deferred_block_weight_grads():
+                    torch.autograd.backward(heads, grads)
+                    queued.append(lib.stlt_block_dw_pending())
+            else:
+                torch.autograd.backward(heads, grads)
+        finally:
+            tr.bound.accumulating = False
+        assert lib.stlt_block_dw_pending() == 0
+        torch.cuda.synchronize()
+        flats.append(tr.bound.flat.clone())
+    assert queued[0] >= 8, queued
+    a, b = flats
+    assert torch.isfinite(a).all() and a.abs().max().item() > 0
+    assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    assert lib.stlt_block_dw_defer(7) != 0 and lib.stlt_block_dw_defer(-1) == 0
