@@ -12,6 +12,9 @@
 
 namespace {
 
+#ifndef STLT_MHSA_ABLATE
+#define STLT_MHSA_ABLATE 0  // timing-only builds (wrong results): bit 0 no ctx stores (what keeping the attention output on chip for a fused out-projection could save at most)
+#endif
 #ifndef STLT_MHSA_LOADER
 #define STLT_MHSA_LOADER 2
 #endif
@@ -398,7 +401,11 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
       if (row_ok) {
         float* dst = a.ctx + (int64_t)(row0 + my_row) * d + head * 64 + 4 * lg;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(dst + 16 * cb) = o[cb] * inv;
+        for (int cb = 0; cb < 4; ++cb) {
+          const f32x4 val = o[cb] * inv;
+          if (STLT_MHSA_ABLATE & 1) asm volatile("" :: "v"(val), "v"(dst));  // timing build: the attention output is computed, not stored
+          else *reinterpret_cast<f32x4*>(dst + 16 * cb) = val;
+        }
       }
     }
     ++c_it;
