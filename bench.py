@@ -706,7 +706,7 @@ def main():
         # collected from inside the process); the summary is committed under profiles/ and only quoted when it was
         # taken on this workload.
         traffic_gemm = traffic_attn = traffic_attn_sp = traffic_mhsa = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"round{r}_traffic_pmc.json") for r in (4, 3, 2)) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"round{r}_traffic_pmc.json") for r in (9, 8, 7, 6, 5, 4, 3, 2)) if os.path.exists(q)), "")  # the newest committed PMC pass
         if args.config == "cfg2" and B == 1024 and not args.no_cls_only and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
