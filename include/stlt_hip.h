@@ -432,7 +432,8 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
  * gemm_scratch (forward calls): NULL, or stlt_gemm_scratch_bytes() of device memory lent for the call's stream-K launches.
  * The backward calls ACCUMULATE (+=) into the gradient struct's buffers (NULL members are skipped), write dx (and dc, the
  * gradient wrt the context tokens of a cross-attention block), and recompute the dropout masks from (drop_p, seed, site0). */
-/* Deferred weight gradients of the block calls (per calling thread).  After stlt_block_dw_defer(1) the *_block_bwd_train calls queue their
+/* Deferred weight gradients of the block calls (ONE queue per process: torch's autograd engine runs the block backwards on its own thread
+ * while the training loop switches and flushes the queue from the thread that called backward()).  After stlt_block_dw_defer(1) the *_block_bwd_train calls queue their
  * weight-gradient products (g_w += dyᵀ·x) instead of launching them; stlt_block_dw_flush runs the queue as grouped stream-K launches of up to
  * 32 products on `stream` (the stream the blocks ran on) with stlt_gemm_scratch_bytes() of scratch, in queue order (two products into the same
  * gradient never share a launch).  The CALLER keeps every operand of the queued products alive and unchanged until the flush: the blocks'

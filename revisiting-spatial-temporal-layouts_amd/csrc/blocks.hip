@@ -6,6 +6,7 @@
 //   attention block:  out = LN_eps( x + drop( MHA(x, c, c; kpm, causal, prob-dropout) · Woᵀ + bo ) )      c = x for self-attention
 //   feed-forward block: out = LN_eps( x + drop( W2 · drop_inner( act(W1 x + b1) ) + b2 ) )                 act = GELU | ReLU
 // Dropout sites: site0 = attention probabilities / inner dropout, site0 + 1 = the dropout in front of the residual.
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -70,21 +71,28 @@ struct DwList {
     if (g_w && rows > 0) it[n++] = StltWeightGradItem{dy, n_out, x, k_in, rows, g_w};
   }
 };
-// Collector of the calling thread (stlt_block_dw_defer): while it is on, a block's grouped weight-gradient launch is not made at the end of
-// the block's backward — its products are queued and stlt_block_dw_flush runs the queue as grouped launches of up to 32 products.  A block's
-// own group is 2 - 4 products over 2048 / 2112 rows (18 k-steps per workgroup: 0.39 of the MFMA peak, 34 launches + 34 fix-ups per CACNF
-// step); 32 products per launch run at the rate of the STLT sweep's 8-layer groups (0.84).  The caller keeps every operand alive until the flush.
+// Collector (stlt_block_dw_defer): while it is on, a block's grouped weight-gradient launch is not made at the end of the block's backward —
+// its products are queued and stlt_block_dw_flush runs the queue as grouped launches of up to 32 products.  A block's own group is 2 - 4
+// products over 2048 / 2112 rows (18 k-steps per workgroup: 0.39 of the MFMA peak, 34 launches + 34 fix-ups per CACNF step); 32 products per
+// launch run at the rate of the STLT sweep's 8-layer groups (0.84).  The caller keeps every operand alive until the flush.
+// ONE collector per process, not per thread: torch's autograd engine runs the block backwards on its own device thread while the trainer
+// switches the collector and flushes it from the thread that called backward() (a thread-local collector queued the products on the
+// engine's thread, where nobody ever flushed them: caught by the GPU suite as all-zero weight gradients in a later test).  One training
+// loop per process uses it at a time (the mutex only keeps the queue consistent).
 constexpr int DW_DEFER_CAP = 512;
-struct DwCollector { StltWeightGradItem it[DW_DEFER_CAP]; int n = 0; bool on = false; };
-thread_local DwCollector t_dw;
+struct DwCollector { StltWeightGradItem it[DW_DEFER_CAP]; int n = 0; bool on = false; std::mutex mu; };
+DwCollector t_dw;
 
 int flush_dw(const DwList& l, const BlockScratch& sc, hipStream_t s) {
   if (l.n == 0) return 0;
   bool group_ok = true;
   for (int i = 0; i < l.n; ++i) group_ok = group_ok && l.it[i].rows % 32 == 0 && l.it[i].rows <= 4096;  // long contractions: separate launches are as fast (train.hip: weight_grad_all)
-  if (group_ok && t_dw.on && t_dw.n + l.n <= DW_DEFER_CAP) {
-    for (int i = 0; i < l.n; ++i) t_dw.it[t_dw.n++] = l.it[i];
-    return 0;
+  if (group_ok) {
+    std::lock_guard<std::mutex> lk(t_dw.mu);
+    if (t_dw.on && t_dw.n + l.n <= DW_DEFER_CAP) {
+      for (int i = 0; i < l.n; ++i) t_dw.it[t_dw.n++] = l.it[i];
+      return 0;
+    }
   }
   StltGemmScratch lend(sc.lin, STLT_GEMM_SCRATCH_BYTES);
   if (group_ok) return launch_weight_grad_group(l.it, l.n, s);
@@ -115,13 +123,15 @@ int linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64
 extern "C" {
 
 int stlt_block_dw_defer(int mode) {
+  std::lock_guard<std::mutex> lk(t_dw.mu);
   if (mode == 1) { t_dw.on = true; return 0; }
   if (mode == 0) { t_dw.on = false; return 0; }
   if (mode == -1) { t_dw.on = false; t_dw.n = 0; return 0; }
   return stlt_set_error(STLT_EINVAL, "stlt_block_dw_defer: mode 1 (collect), 0 (stop collecting; queued products stay) or -1 (stop and discard)");
 }
-int stlt_block_dw_pending(void) { return t_dw.n; }
+int stlt_block_dw_pending(void) { std::lock_guard<std::mutex> lk(t_dw.mu); return t_dw.n; }
 int stlt_block_dw_flush(void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream) {
+  std::lock_guard<std::mutex> lk(t_dw.mu);
   if (t_dw.n == 0) return 0;
   if (!gemm_scratch || gemm_scratch_bytes < STLT_GEMM_SCRATCH_BYTES) return stlt_set_error(STLT_EWORKSPACE, "stlt_block_dw_flush: needs stlt_gemm_scratch_bytes() of scratch");
   StltGemmScratch lend(gemm_scratch, STLT_GEMM_SCRATCH_BYTES);
