@@ -237,8 +237,7 @@ int stlt_ffn_block_fwd_train(const stlt_ffn_block_params* p, int64_t d, float ep
   const StltDrop dr = stlt_drop_make(drop_p, seed);
   const StltDrop inner = inner_dropout ? dr : StltDrop{0u, 1.0f, 0ull};
   if (act == STLT_ACT_GELU) {
-    TRY(launch_linear(x, d, p->lin1_w, p->lin1_b, u, 4 * d, M, 4 * d, d, STLT_ACT_NONE, s));
-    TRY(launch_gelu_fwd(u, h, M * 4 * d, s, inner, site0));
+    TRY(launch_linear_gelu_keep(x, d, p->lin1_w, p->lin1_b, u, h, M, 4 * d, d, inner, site0, nullptr, s));
   } else {
     TRY(launch_linear(x, d, p->lin1_w, p->lin1_b, h, 4 * d, M, 4 * d, d, STLT_ACT_RELU, s));
     if (inner.thr) TRY(stlt_dropout(h, h, M * 4 * d, drop_p, seed, site0, stream));

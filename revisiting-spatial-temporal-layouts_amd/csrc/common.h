@@ -152,11 +152,19 @@ int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias
                   int64_t N, int64_t K, int act, hipStream_t s);
 int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* bias, const float* r, int64_t ldr, float* y,
                       int64_t ldy, int64_t M, int64_t N, int64_t K, hipStream_t s);
+// u (M, N) = x·Wᵀ + b and h (M, N) = drop(gelu(u)) (dropout of site `site`, indices of rows drop_rows[] when given: launch_gelu_fwd's
+// arguments): one small-tile launch with the STLT_ACT_GELU_KEEP epilogue when the routing takes the product, else product + launch_gelu_fwd
+int launch_linear_gelu_keep(const float* x, int64_t ldx, const float* w, const float* bias, float* u, float* h, int64_t M, int64_t N, int64_t K,
+                            StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s);
 // Epilogue of the fused GELU backward (act == STLT_ACT_GELU_BWD, internal): C = drop(A·B) ∘ gelu'(U) with U passed as the
 // add-source (r / ldr), the dropout of the FFN hidden (site, drop_rows as launch_gelu_bwd_colsum), and the column sums of C
 // (the producing Linear's bias gradient) left as partial rows: cs_part[(tile row * 16 + slot) * N + n], 16 slots per 256-row
 // tile row, every slot written — launch_reduce_slabs(cs_part, N, ceil(M/256)*16, g, N, 1) finishes them.
 constexpr int STLT_ACT_GELU_BWD = 3;
+// Epilogue of the training forward's FFN1 (internal, small-tile kernel only): the pre-activation u = x·W1ᵀ + b1 is stored to the
+// add-source pointer (r / ldr, written here, not read) and h = drop(gelu(u)) to the output — the tape keeps both (gelu' needs u, the
+// second product and its weight gradient need h); one launch instead of the product + launch_gelu_fwd's read of u.
+constexpr int STLT_ACT_GELU_KEEP = 4;
 struct StltGemmEpi { StltDrop dr; uint32_t site; const int* drop_rows; float* cs_part; };
 // d/dx gelu(x) = Phi(x) + x phi(x), fixed cost like gelu_epilogue (same erf fit, two v_exp_f32)
 __device__ __forceinline__ float gelu_grad_epilogue(float x) {

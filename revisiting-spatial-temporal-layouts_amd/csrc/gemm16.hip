@@ -221,6 +221,29 @@ int launch_linear_gemm16(const float* x, int64_t ldx, const float* w, int64_t ld
   return launch16_any(code, a, act, r != nullptr, false, s);
 }
 
+int launch_linear_gelu_keep(const float* x, int64_t ldx, const float* w, const float* bias, float* u, float* h, int64_t M, int64_t N, int64_t K,
+                            StltDrop dr, uint32_t site, const int* drop_rows, hipStream_t s) {
+  if (!x || !w || !u || !h) return stlt_set_error(STLT_EINVAL, "linear + GELU (kept pre-activation): null pointer");
+  static const bool fused_on = [] { const char* e = getenv("STLT_FFN1_KEEP_FUSED"); return !(e && e[0] == '0'); }();
+  const int code = fused_on && !stlt_split_bf16_takes(M, N, K, ldx, K) ? stlt_gemm16_choice(M, N, K, ldx, K, false) : 0;
+  if (code == 0) {  // large tiles (or the small-tile kernel switched off): the product, then the element-wise pass over u
+    if (int e = launch_linear(x, ldx, w, bias, u, N, M, N, K, STLT_ACT_NONE, s)) return e;
+    return launch_gelu_fwd(u, h, M * N, s, dr, site, drop_rows, N);
+  }
+  const int rb = tile_rb(code), nt = tile_nt(code);
+  Gemm16Args a{};
+  a.epi.dr = dr; a.epi.site = site; a.epi.drop_rows = drop_rows; a.epi.cs_part = nullptr;
+  a.X = x; a.W = w; a.bias = bias; a.R = u; a.Y = h;
+  a.ldx = ldx; a.ldw = K; a.ldr = N; a.ldy = N;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = (int)((M + 16 * rb - 1) / (16 * rb));
+  a.tiles_n = (int)((N + 16 * nt - 1) / (16 * nt));
+  if ((int64_t)a.tiles_m * a.tiles_n > 0x3fffffffLL) return stlt_set_error(STLT_EINVAL, "gemm16: too many tiles");
+  StltProfScope ps(STLT_K_GEMM, s);
+  stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
+  return launch16_any(code, a, STLT_ACT_GELU_KEEP, false, false, s);
+}
+
 // C (rows, k_in; ldc) = dY (rows, n_out; ld_dy) · W (n_out, k_in) (+ R): the input gradient of a Linear on the small-tile kernel, W read
 // as it lies (WKN build).  *taken = false: the product stays on gemm.hip's NN kernel (shape not taken, or estimated slower).
 int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* c,

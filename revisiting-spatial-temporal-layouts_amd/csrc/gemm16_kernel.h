@@ -40,7 +40,7 @@ struct Gemm16Args {
   float* Y;
   int64_t ldx, ldw, ldr, ldy;
   int M, N, K, tiles_m, tiles_n;
-  StltGemmEpi epi;  // ACT == STLT_ACT_GELU_BWD only (R = the pre-activation u, not added)
+  StltGemmEpi epi;  // ACT == STLT_ACT_GELU_BWD (R = the pre-activation u, read, not added) / STLT_ACT_GELU_KEEP (R = where u is stored; dr, site, drop_rows)
 };
 
 template <int RB, int NT> constexpr int q_stage_floats() { return (16 * RB + 16 * NT) * QK; }
@@ -316,6 +316,28 @@ __global__ __launch_bounds__(Q_THREADS, 3) void gemm16_kernel(const Gemm16Args a
                 *reinterpret_cast<f32x4*>(a.epi.cs_part + (size_t)b * (size_t)a.N + col0 + 16 * t) = f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
+      } else if constexpr (ACT == STLT_ACT_GELU_KEEP) {
+        // the training forward's FFN1: u to the add-source pointer, h = drop(gelu(u)) to the output (launch_gelu_fwd's mask indices)
+        if (row < a.M) {
+          float* urow = const_cast<float*>(a.R) + (int64_t)row * a.ldr + col0;
+          float* yrow = a.Y + (int64_t)row * a.ldy + col0;
+          const uint64_t key = stlt_drop_key(a.epi.dr, a.epi.site);
+          const uint64_t drow = a.epi.drop_rows ? (uint64_t)a.epi.drop_rows[row] : (uint64_t)row;
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            if (col0 + 16 * t < a.N) {
+              const f32x4 u = acc[t];
+              *reinterpret_cast<f32x4*>(urow + 16 * t) = u;
+              f32x4 o = {gelu_epilogue(u[0]), gelu_epilogue(u[1]), gelu_epilogue(u[2]), gelu_epilogue(u[3])};
+              if (a.epi.dr.thr) {
+                const uint64_t idx0 = drow * (uint64_t)a.N + (uint64_t)(col0 + 16 * t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = stlt_keep_k(a.epi.dr.thr, key, idx0 + j) ? o[j] * a.epi.dr.scale : 0.f;
+              }
+              *reinterpret_cast<f32x4*>(yrow + 16 * t) = o;
+            }
+          }
+        }
       } else if (row < a.M) {
         float* yrow = a.Y + (int64_t)row * a.ldy + col0;
         if (ADD) {
@@ -456,6 +478,7 @@ int launch16_nt(const Gemm16Args& a, int act, bool add, bool wkn, hipStream_t s)
   if (wkn && act == STLT_ACT_GELU_BWD) return launch16_as<RB, NT, STLT_ACT_GELU_BWD, false, true>(a, s);
   if (wkn) return add ? launch16_as<RB, NT, STLT_ACT_NONE, true, true>(a, s) : launch16_as<RB, NT, STLT_ACT_NONE, false, true>(a, s);
   if (add) return launch16_as<RB, NT, STLT_ACT_NONE, true, false>(a, s);
+  if (act == STLT_ACT_GELU_KEEP) return launch16_as<RB, NT, STLT_ACT_GELU_KEEP, false, false>(a, s);
   if (act == STLT_ACT_GELU) return launch16_as<RB, NT, STLT_ACT_GELU, false, false>(a, s);
   if (act == STLT_ACT_RELU) return launch16_as<RB, NT, STLT_ACT_RELU, false, false>(a, s);
   return launch16_as<RB, NT, STLT_ACT_NONE, false, false>(a, s);

@@ -429,8 +429,7 @@ static int layer_forward(const stlt_layer_params& lp, int64_t d, int64_t H, cons
   TRY(qkv_attention_train(lp, d, H, t, M, S, L, kpm, causal, kid, dr, site0, s, seg_start, seg_end));
   TRY(launch_linear(t.ctx, d, lp.out_proj_w, lp.out_proj_b, t.a, d, M, d, d, STLT_ACT_NONE, s));
   TRY(launch_add_layernorm(t.a, d, t.x, d, lp.norm1_w, lp.norm1_b, 1e-5f, M, d, t.x1, d, s, dr, site0 + 1));
-  TRY(launch_linear(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, 4 * d, M, 4 * d, d, STLT_ACT_NONE, s));
-  TRY(launch_gelu_fwd(t.u, t.h, M * 4 * d, s, dr, site0 + 2));
+  TRY(launch_linear_gelu_keep(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, t.h, M, 4 * d, d, dr, site0 + 2, nullptr, s));
   TRY(launch_linear(t.h, 4 * d, lp.lin2_w, lp.lin2_b, t.f, d, M, d, 4 * d, STLT_ACT_NONE, s));
   TRY(launch_add_layernorm(t.f, d, t.x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, M, d, y, d, s, dr, site0 + 3));
   return 0;
@@ -452,8 +451,7 @@ static int layer_forward_tail(const stlt_layer_params& lp, int64_t d, int64_t H,
   TRY(launch_gather_rows(t.x, d, rows, n, d, g_x, s));
   TRY(launch_linear(g_ctx, d, lp.out_proj_w, lp.out_proj_b, t.a, d, n, d, d, STLT_ACT_NONE, s));
   TRY(launch_add_layernorm(t.a, d, g_x, d, lp.norm1_w, lp.norm1_b, 1e-5f, n, d, t.x1, d, s, dr, site0 + 1, rows));
-  TRY(launch_linear(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, 4 * d, n, 4 * d, d, STLT_ACT_NONE, s));
-  TRY(launch_gelu_fwd(t.u, t.h, n * 4 * d, s, dr, site0 + 2, rows, 4 * d));
+  TRY(launch_linear_gelu_keep(t.x1, d, lp.lin1_w, lp.lin1_b, t.u, t.h, n, 4 * d, d, dr, site0 + 2, rows, s));
   TRY(launch_linear(t.h, 4 * d, lp.lin2_w, lp.lin2_b, t.f, d, n, d, 4 * d, STLT_ACT_NONE, s));
   TRY(launch_add_layernorm(t.f, d, t.x1, d, lp.norm2_w, lp.norm2_b, 1e-5f, n, d, y, d, s, dr, site0 + 3, rows));
   return 0;

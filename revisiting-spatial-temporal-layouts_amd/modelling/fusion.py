@@ -157,10 +157,11 @@ class CrossAttentionFusionBackbone(nn.Module):
                 Lh = self.layout_branch.forward_batch_major(batch)
             self.layout_branch.train(was_training)
         Ah = self._appearance_train(feats)
-        B = Lh.shape[0]
-        idx = torch.arange(B, device=Lh.device)
-        last = batch["lengths"].to(Lh.device) - 1
-        lay_state, app_state = Lh[idx, last], Ah[:, 0]
+        B, d = Lh.shape[0], Lh.shape[2]
+        # row lengths - 1 of every clip (models.py:455-459) as a gather: its backward is one scatter-add, where advanced indexing
+        # (Lh[arange(B), last]) sorts the indices and runs six launches; the remainder keeps indexing's wrap-around of a negative row
+        last = torch.remainder(batch["lengths"].to(Lh.device) - 1, Lh.shape[1]).view(B, 1, 1).expand(B, 1, d)
+        lay_state, app_state = Lh.gather(1, last).squeeze(1), Ah[:, 0]
         kpm = batch["src_key_padding_mask_frames"]
         p = self.config.hidden_dropout_prob
         eps = self.config.layer_norm_eps
@@ -173,7 +174,7 @@ class CrossAttentionFusionBackbone(nn.Module):
             Lh = ops.FfnBlockFn.apply(la, eps, L.ACT_GELU, False, p if self.training else 0.0, ff.linear1.weight, ff.linear1.bias, ff.linear2.weight,
                                       ff.linear2.bias, ff.ln.weight, ff.ln.bias)
             Ah = self._attn_block(m.appearance_ffn, aa, aa, None, False, p)
-        fused = torch.cat((Lh[idx, last], Ah[:, 0]), dim=-1)
+        fused = torch.cat((Lh.gather(1, last).squeeze(1), Ah[:, 0]), dim=-1)
         caf = self._head_train(fusion_head, fused)
         if layout_head is None:
             return (caf,)

@@ -370,7 +370,7 @@ class LinearFn(torch.autograd.Function):
         x = x.contiguous()
         y = linear(x, w, b, act=act)
         ctx.save_for_backward(x, w, y if act == L.ACT_RELU else None)
-        ctx.has_bias = b is not None
+        ctx.bias = b  # the parameter itself (grad_targets looks at its Trainer binding), not saved for its value
         ctx.act = act
         return y
 
@@ -386,13 +386,14 @@ class LinearFn(torch.autograd.Function):
             L.check(lib.stlt_relu_bwd(_p(dy), _p(y), _p(dz), dy.numel(), _stream()), "stlt_relu_bwd")
             dy = dz
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
-        db = torch.zeros(N, device=w.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        # inside a Trainer step the parameter gradients accumulate in place into the bound flat buffer (grad_targets): no zero fill,
+        # no AccumulateGrad add (4 launches per Linear; the fusion models' heads and projector are 7 Linears a step)
+        (dw, db), grads = grad_targets((w, ctx.bias), (ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]))
         nbytes = int(lib.stlt_linear_bwd_scratch_bytes(N))
         sc = _scratch(nbytes, x.device)
         L.check(lib.stlt_linear_bwd(_p(x), _p(w), _p(dy), M, N, K, _p(dx), _p(dw), _p(db), sc.data_ptr(), sc.numel(), _stream()),
                 "stlt_linear_bwd")
-        return dx, dw, db, None
+        return dx, grads[0], grads[1], None
 
 
 class DropoutFn(torch.autograd.Function):
@@ -483,6 +484,7 @@ class AddLayerNormFn(torch.autograd.Function):
         res = None if res is None else res.contiguous()
         ctx.save_for_backward(x, res, w)
         ctx.eps = eps
+        ctx.bias = b
         return add_layernorm(x, res, w, b, eps)
 
     @staticmethod
@@ -493,12 +495,11 @@ class AddLayerNormFn(torch.autograd.Function):
         M = x.numel() // d
         dy = dy.contiguous()
         ds = torch.empty_like(x)
-        gw = torch.zeros_like(w)
-        gb = torch.zeros_like(w)
+        (gw, gb), grads = grad_targets((w, ctx.bias), ctx.needs_input_grad[2:4])
         sc = _scratch(int(lib.stlt_add_layernorm_bwd_scratch_bytes(d)), x.device)
         L.check(lib.stlt_add_layernorm_bwd(_p(dy), _p(x), _p(res), _p(w), float(ctx.eps), M, d, _p(ds), _p(gw), _p(gb), sc.data_ptr(),
                                            sc.numel(), _stream()), "stlt_add_layernorm_bwd")
-        return ds, (ds if res is not None else None), gw, gb, None
+        return ds, (ds if res is not None else None), grads[0], grads[1], None
 
 
 class GeluFn(torch.autograd.Function):

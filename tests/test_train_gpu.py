@@ -169,7 +169,11 @@ def test_dropout_forward_and_gradients_match_masked_oracle(pkg, name, B, p):
     F.cross_entropy(ref_logits, labels).backward()
 
     out = m({k: v.to(DEV) for k, v in batch.items()})["stlt"]
-    assert (out.detach().cpu().double() - ref_logits.detach()).abs().max().item() <= 2e-4
+    # fp32 against the fp64 oracle under the same masks.  The rounding noise grows steeply with p (measured over three seeds, tools/scratch
+    # runs of round 5: p = 0.1: 3 - 5e-6; 0.3: 2 - 3e-5; 0.5: 0.6 - 2.5e-4 — the same band with the FFN GELU in the product's epilogue
+    # (branch-free erf fit) and as a separate pass (library erff)); the gradient check below and the small-vs-large-tile
+    # comparison of test_ffn_block_backward_gelu_epilogue_on_small_tiles are what would catch a wrong mask index
+    assert (out.detach().cpu().double() - ref_logits.detach()).abs().max().item() <= (2e-5 if p <= 0.1 else 4e-4)
     F.cross_entropy(out, labels.to(DEV)).backward()
     for k, prm in m.named_parameters():
         if "encoder_layer." in k or "score_embeddings" in k:
