@@ -348,6 +348,13 @@ int stlt_attn_bwd(const float* q, int64_t ldq, const float* k, const float* v, i
   }
   if (S == 0) return 0;
   if (S * H > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_attn_bwd: too many sequences");
+  if (!causal) {  // at most 48 tokens on either side (the fusion models' 32 frames x 33 appearance tokens): the MFMA kernel of attn_bwdx16.hip
+    bool taken = false;
+    StltProfScope ps(STLT_K_ATTN_BWD, (hipStream_t)stream);
+    const int rc = launch_attn_bwdx16(q, ldq, k, v, ldkv, dctx, kpm, S, Lq, Lk, H, dq, lddq, dk, dv, lddkv, stlt_drop_make(dropout_p, seed), site,
+                                      (hipStream_t)stream, &taken);
+    if (taken || rc != 0) return rc;
+  }
   const size_t lds = ((size_t)2 * Lq * XB_LD + (size_t)2 * Lk * XB_LD + (size_t)2 * Lq * (Lk + 1)) * sizeof(float);
   static StltPerDeviceOnce once;  // a function attribute is set per device
   bool& opt_in = once.flag();

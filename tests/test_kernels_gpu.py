@@ -805,6 +805,47 @@ def test_attn_core_bwd_mfma_blocks_vs_fp64(pkg, L, causal, p):
     assert dqkv[4].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("Lq,Lk", [(32, 33), (33, 32), (16, 33), (33, 16), (7, 20), (48, 48), (1, 5), (40, 9)])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_attn_cross_bwd_mfma_vs_fp64(pkg, Lq, Lk, p):
+    """stlt_attn_bwd with queries and keys from different buffers (the fusion models' cross-attention: 32 frames x 33 appearance tokens,
+    models.py:411-419) on attn_bwdx16.hip's 16-row blocks — every (query blocks, key blocks) pair of 1 - 3 — against torch autograd in
+    fp64: k | v as the two halves of one packed projection (the block path's layout), padded keys, a fully padded sequence, and the
+    dropout mask the forward drew."""
+    S, H = 13, 3
+    d = 64 * H
+    q = _rand(S, Lq, d, seed=Lq, scale=1.5)
+    kv = _rand(S, Lk, 2 * d, seed=Lk + 100, scale=1.5)
+    g = _rand(S, Lq, d, seed=Lq + Lk)
+    kpm = torch.rand(S, Lk, generator=torch.Generator().manual_seed(Lk)) < 0.3
+    kpm[:, 0] = False
+    kpm[4, :] = True  # a fully padded sequence: zero output, zero gradient
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # what AttnFn.forward will draw
+    torch.manual_seed(77)
+    qd = q.to(DEV).requires_grad_(True)
+    kvd = kv.to(DEV).requires_grad_(True)
+    ctx = pkg.ops.AttnFn.apply(qd, kvd[..., :d], kvd[..., d:], kpm.to(DEV), False, H, p)
+    ctx.backward(g.to(DEV))
+    qr, kvr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    sp = lambda t, L_: t.reshape(S, L_, H, 64).transpose(1, 2)
+    sc = sp(qr, Lq) @ sp(kvr[..., :d], Lk).transpose(-1, -2) / 8.0
+    pr = torch.nan_to_num(torch.softmax(sc.masked_fill(kpm[:, None, None, :].expand(S, H, Lq, Lk), float("-inf")), -1), nan=0.0)
+    if p > 0:
+        s_, h_, i_, j_ = np.meshgrid(np.arange(S, dtype=np.uint64), np.arange(H, dtype=np.uint64), np.arange(Lq, dtype=np.uint64),
+                                     np.arange(Lk, dtype=np.uint64), indexing="ij")
+        idx = ((((s_ * np.uint64(Lq) + i_) * np.uint64(H)) + h_) << np.uint64(8)) | j_
+        keep = O.dropout_keep(p, seed, pkg.ops.AttnFn._site, idx)
+        pr = pr * (torch.from_numpy(keep).double() * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p))))
+    ref = (pr @ sp(kvr[..., d:], Lk)).transpose(1, 2).reshape(S, Lq, d)
+    assert (ctx.detach().cpu().double() - ref.detach()).abs().max().item() <= 5e-5
+    ref.backward(g.double())
+    for got, want, name in ((qd.grad, qr.grad, "dq"), (kvd.grad, kvr.grad, "dkv")):
+        assert torch.isfinite(got).all(), name
+        assert (got.cpu().double() - want).abs().max().item() / max(want.abs().max().item(), 1e-6) <= 2e-5, name
+    assert qd.grad[4].abs().max().item() == 0.0 and kvd.grad[4].abs().max().item() == 0.0
+
+
 def _drop_mask(O, p, seed, site, S, H, L):
     """(S,H,L,L) multiplicative mask of the attention probabilities: element (s,h,i,j) has idx = (((s*L+i)*H + h) << 8) | j."""
     s_, h_, i_, j_ = np.meshgrid(np.arange(S, dtype=np.uint64), np.arange(H, dtype=np.uint64), np.arange(L, dtype=np.uint64),
