@@ -367,10 +367,10 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
   if (groups * g.ntq * H > 0x7fffffffLL || g.nq_tokens > 0x7fffffffLL || g.nk_tokens > 0x7fffffffLL)
     return stlt_set_error(STLT_EINVAL, "stlt_attn_core_fwd: too many tiles / tokens (32-bit index arithmetic)");
   StltProfScope ps(kid, s);
-  // short self-attention on a packed buffer without dropout: the 16-row-tile kernel (attn16.hip)
-  if (Lq == Lk && Lq <= 64 && !dr.thr && k == q + H * dh && v == q + 2 * H * dh && ldq == 3 * H * dh && ldkv == ldq && !g_stlt_debug_buf) {
+  // short self-attention on a packed buffer (with or without the dropout of the probabilities): the 16-row-tile kernel (attn16.hip)
+  if (Lq == Lk && Lq <= 64 && k == q + H * dh && v == q + 2 * H * dh && ldq == 3 * H * dh && ldkv == ldq && !g_stlt_debug_buf) {
     bool taken = false;
-    const int rc = launch_attn16(q, kpm, causal, S, Lq, H, ctx, attn_reverse_order(), s, &taken);
+    const int rc = launch_attn16(q, kpm, causal, S, Lq, H, ctx, attn_reverse_order(), s, &taken, dr, site);
     if (taken || rc != 0) return rc;
   }
   const int64_t n_items = groups * g.ntq * H;

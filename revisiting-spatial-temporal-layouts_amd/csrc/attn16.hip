@@ -1,5 +1,5 @@
-// K3, 16-row tiles: the attention core for self-attention over short sequences (L <= 64 tokens on a packed QKV buffer,
-// no dropout) on v_mfma_f32_16x16x4_f32.  attn.hip's 32x32 tiles are exact for L = 32 / 64 and for 4 x 7-token frames, but
+// K3, 16-row tiles: the attention core for self-attention over short sequences (L <= 64 tokens on a packed QKV buffer; DROP builds:
+// with the train-mode dropout of the probabilities) on v_mfma_f32_16x16x4_f32.  attn.hip's 32x32 tiles are exact for L = 32 / 64 and for 4 x 7-token frames, but
 // a 36-token sequence (cfg4: N = 36) costs them four (query tile, key tile) steps of which 68 % is padding, and a wave
 // needs 64 dependent 64-cycle MFMAs per (sequence, head).  Here an item is up to four 16-row blocks:
 //   FULL  (16 < L <= 64): one sequence = NB = ceil(L/16) blocks; every (query block, key block) pair, or the lower
@@ -46,11 +46,13 @@ struct Geo16 {
   int rows_per_item;     // FULL: L; DIAG: NB * P * L
   int n_items, reverse;
   float scale;
+  StltDrop dr;           // DROP builds: train-mode dropout of the probabilities (attn.hip's mask: ((query token * H + head) << 8) | key position)
+  uint32_t site;
 };
 
 // (TAIL with two full blocks — 33 tokens — is held to three waves per SIMD: the compiler's own allocation is 184 registers, 16 over the step)
-template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false>
-__global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2) ? 3 : 1) void attn16_kernel(const Geo16 geo) {
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false, bool DROP = false>
+__global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2 && !DROP) ? 3 : 1) void attn16_kernel(const Geo16 geo) {
   static_assert(FULL || !SPLIT, "DIAG items are independent blocks already");
   static_assert(!TAIL || (FULL && CAUSAL && !SPLIT), "TAIL: one causal sequence of 16 NB + 1 tokens per item");
   constexpr int VROWS = NB * 16;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2) ? 3 : 1) void attn1
       const int mq = tok >= 0 ? row_meta(qb) : -1;
       const int q_seq = mq >> 8, q_pos = mq & 0xff;
       float m = -1e30f;
+      int kpos[DROP ? NB : 1][4];  // DROP: the keys' positions inside their sequences (the mask index)
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
         if (!used(kb, qb)) continue;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2) ? 3 : 1) void attn1
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool ok = (kmv[r] >= 0) & ((kmv[r] >> 8) == q_seq) & (!CAUSAL || (kmv[r] & 0xff) <= q_pos);
+          if (DROP) kpos[kb][r] = kmv[r] & 0xff;
           st[kb][r] = ok ? st[kb][r] * geo.scale : -1e30f;
           m = fmaxf(m, st[kb][r]);
         }
@@ -236,6 +240,17 @@ __global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2) ? 3 : 1) void attn1
         sum += p_tail;
       }
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
+      if (DROP) {  // train-mode dropout of the probabilities: the denominator keeps the undropped sum (as attn.hip)
+        const uint64_t key = stlt_drop_key(geo.dr, geo.site);
+        const uint64_t qidx = (((uint64_t)(tok >= 0 ? tok : 0)) * (uint64_t)H + (uint64_t)head) << 8;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+          if (!used(kb, qb)) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kb][r] = stlt_keep_k(geo.dr.thr, key, qidx | (uint64_t)kpos[kb][r]) ? st[kb][r] * geo.dr.scale : 0.f;
+        }
+        if (tail_pass) p_tail = stlt_keep_k(geo.dr.thr, key, qidx | (uint64_t)(L - 1)) ? p_tail * geo.dr.scale : 0.f;
+      }
       // ---- O^T[channel][query] += V^T·P^T: MFMA step (kb, r) sums keys kb*16 + 4g + r over g
       f32x4 o[4];
 #pragma unroll
@@ -283,32 +298,36 @@ __global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2) ? 3 : 1) void attn1
 }
 
 // wave slots of the device for one instantiation (workgroups per CU x CUs x waves per workgroup)
-template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false>
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false, bool DROP = false>
 int64_t wg_capacity16() {
   static StltPerDeviceInt occ;
   int& wg_per_cu = occ.ref();
   if (wg_per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn16_kernel<NB, FULL, CAUSAL, SPLIT, TAIL>, 64 * WAVES16, 0) != hipSuccess || wg_per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, attn16_kernel<NB, FULL, CAUSAL, SPLIT, TAIL, DROP>, 64 * WAVES16, 0) != hipSuccess || wg_per_cu <= 0)
       wg_per_cu = 1;
   }
   return (int64_t)wg_per_cu * stlt_device_cus();
 }
 
-template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false>
-int launch16_as(const Geo16& g, hipStream_t s) {
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL, bool DROP>
+int launch16_drop(const Geo16& g, hipStream_t s) {
   const int64_t n_units = SPLIT ? (int64_t)g.n_items * NB : g.n_items;
   int64_t n_wg = (n_units + WAVES16 - 1) / WAVES16;
-  const int64_t cap = wg_capacity16<NB, FULL, CAUSAL, SPLIT, TAIL>();
+  const int64_t cap = wg_capacity16<NB, FULL, CAUSAL, SPLIT, TAIL, DROP>();
   if (n_wg > cap) n_wg = cap;
-  hipLaunchKernelGGL((attn16_kernel<NB, FULL, CAUSAL, SPLIT, TAIL>), dim3((unsigned)n_wg), dim3(64 * WAVES16), 0, s, g);
+  hipLaunchKernelGGL((attn16_kernel<NB, FULL, CAUSAL, SPLIT, TAIL, DROP>), dim3((unsigned)n_wg), dim3(64 * WAVES16), 0, s, g);
   return stlt_check_launch("attn16_kernel");
+}
+template <int NB, bool FULL, bool CAUSAL, bool SPLIT, bool TAIL = false>
+int launch16_as(const Geo16& g, hipStream_t s) {
+  return g.dr.thr ? launch16_drop<NB, FULL, CAUSAL, SPLIT, TAIL, true>(g, s) : launch16_drop<NB, FULL, CAUSAL, SPLIT, TAIL, false>(g, s);
 }
 
 // FULL launches with fewer items than `split_below` x the device's wave slots are cut into (item, query block) units
 template <int NB, bool CAUSAL>
 int launch16_full(const Geo16& g, hipStream_t s) {
   static const double split_below = [] { const char* e = getenv("STLT_ATTN16_SPLIT_BELOW"); return e ? atof(e) : 0.5; }();
-  const int64_t slots = wg_capacity16<NB, true, CAUSAL, false>() * WAVES16;
+  const int64_t slots = (g.dr.thr ? wg_capacity16<NB, true, CAUSAL, false, false, true>() : wg_capacity16<NB, true, CAUSAL, false>()) * WAVES16;
   if ((double)g.n_items < split_below * (double)slots && (int64_t)g.n_items * NB <= 0x7fffffffLL) return launch16_as<NB, true, CAUSAL, true>(g, s);
   return launch16_as<NB, true, CAUSAL, false>(g, s);
 }
@@ -318,10 +337,11 @@ int launch16_full(const Geo16& g, hipStream_t s) {
 // *taken = true when the launch was made (return value: 0 or the error), false when the shape is not this kernel's (the
 // caller then uses attn.hip).
 int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s,
-                  bool* taken) {
+                  bool* taken, StltDrop dr, uint32_t site) {
   *taken = false;
   static const int enabled = [] { const char* e = getenv("STLT_ATTN16"); return e ? atoi(e) : 1; }();
-  if (!enabled || L < 1 || L > 64) return 0;
+  static const int drop_on = [] { const char* e = getenv("STLT_ATTN16_DROPOUT"); return e ? atoi(e) : 1; }();
+  if (!enabled || L < 1 || L > 64 || (dr.thr && !drop_on)) return 0;
   const int64_t n_tokens = S * L;
   if (n_tokens > 0x7fffffffLL || H > 65535) return 0;
   Geo16 g;
@@ -329,6 +349,7 @@ int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, i
   g.n_tokens = (int)n_tokens; g.L = (int)L; g.H = (int)H;
   g.reverse = reverse;
   g.scale = 0.125f;  // 1 / sqrt(64)
+  g.dr = dr; g.site = site;
   int rc;
   if (L <= 16) {
     if (causal) return 0;  // short causal sequences: not a shape of the path (the temporal pass has T frames), keep attn.hip

@@ -283,7 +283,7 @@ int launch_reduce_slabs3(const float* slabs, int64_t stride, int n_slabs, float*
 int launch_attn(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, int64_t dh,
                 float* ctx, int kid, hipStream_t s, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);
 int launch_attn16(const float* qkv, const uint8_t* kpm, int causal, int64_t S, int64_t L, int64_t H, float* ctx, int reverse, hipStream_t s,
-                  bool* taken);  // attn16.hip; *taken = false: not this kernel's shape
+                  bool* taken, StltDrop dr = StltDrop{0u, 1.0f, 0ull}, uint32_t site = 0);  // attn16.hip; *taken = false: not this kernel's shape
 // attn_bwdx16.hip: the same for queries and keys from different buffers (cross-attention), no causal mask, at most 48 tokens on either side
 int launch_attn_bwdx16(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dctx, const uint8_t* kpm,
                        int64_t S, int64_t Lq, int64_t Lk, int64_t H, float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv, StltDrop dr,
