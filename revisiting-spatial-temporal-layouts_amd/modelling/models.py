@@ -195,6 +195,7 @@ class StltBackbone(nn.Module):
         state["_ws"] = _Workspace()
         state.pop("_train_bufs", None)
         state.pop("_flat_grad_buf", None)
+        state.pop("_grad_table", None)
         return state
 
     @classmethod
@@ -206,6 +207,7 @@ class StltBackbone(nn.Module):
     # ---- parameter table for the C-ABI -------------------------------------------------------------
     def _apply(self, fn, *a, **kw):
         self._cache = None  # .to()/.cuda()/.float() move parameter storage
+        self.__dict__.pop("_grad_table", None)
         return super()._apply(fn, *a, **kw)
 
     def _sentinel(self):
@@ -517,6 +519,7 @@ class _BackboneTrainFn(torch.autograd.Function):
             L.check(lib.stlt_train_forward(C.byref(p), C.byref(inp), tape.data_ptr(), tape.numel(), out.data_ptr(), drop_p, seed,
                                            L.FLAG_TRAIN_BACKBONE, torch.cuda.current_stream().cuda_stream), "stlt_train_forward")
         ctx.bb, ctx.batch, ctx.shape, ctx.params, ctx.drop = bb, batch, (B, T, N, d), params, (drop_p, seed)
+        ctx.inp = (inp, keep)  # the input table and the tensors it points into, for the backward
         return out
 
     @staticmethod
@@ -528,31 +531,43 @@ class _BackboneTrainFn(torch.autograd.Function):
         if getattr(bb, "_tape_gen", 0) != ctx.tape_gen:
             raise L.StltHipError("StltBackbone backward: the activation tape was overwritten by a later grad-enabled forward of the same "
                                  "backbone (one tape per backbone): run each forward's backward before the next forward")
-        inp, keep, _ = _prep_inputs(batch, need_lengths=True)
+        inp, keep = ctx.inp
         p, _, _ = bb.c_params(None)
-        le = bb.frames_embeddings.layout_embedding
-        skip = {id(q) for q in le.encoder_layer.parameters()}
-        if "scores" not in batch:
-            skip |= {id(q) for q in le.category_box_embeddings.score_embeddings.parameters()}
-        want = [prm for prm in ctx.params if prm.requires_grad and id(prm) not in skip]
         # inside a Trainer step, parameters whose .grad is bound to the trainer's flat buffer are accumulated into in place (no
         # temporary, autograd gets None for them); the others — and every parameter outside a Trainer step, e.g. under
-        # torch.autograd.grad() — get views of a fresh zero buffer that autograd accumulates / returns
-        direct = {}
-        for q in want:
-            bound = getattr(q, "_stlt_bound", None)
-            if bound is not None and bound.accumulating and q.grad is not None and bound.owns(q):
-                bound.touch(q)
-                direct[id(q)] = q.grad
-        layout, off = [], 0
-        for q in want:
-            if id(q) not in direct:
-                layout.append((q, off, q.numel()))
-                off += (q.numel() + 3) // 4 * 4
-        flat = torch.zeros(off, device=device, dtype=torch.float32) if off else None
-        views = {id(q): flat[o: o + n].view_as(q) for q, o, n in layout}
-        target = lambda t: direct[id(t)].data_ptr() if id(t) in direct else (views[id(t)].data_ptr() if id(t) in views else None)  # noqa: E731
-        g, gsp, gtp = bb._build_struct(None, target)
+        # torch.autograd.grad() — get views of a fresh zero buffer that autograd accumulates / returns.  The gradient table of a
+        # fully bound backbone is the same every step (fixed views of one flat buffer): it is kept with the backbone.
+        b0 = next((getattr(q, "_stlt_bound", None) for q in ctx.params if q.requires_grad), None)
+        key = (id(b0), "scores" in batch, tuple(q.requires_grad for q in ctx.params)) if (b0 is not None and b0.accumulating) else None
+        cached = bb.__dict__.get("_grad_table")
+        views = {}
+        if key is not None and cached is not None and cached[0] == key and cached[1] is b0:
+            g, gsp, gtp, touched = cached[2]
+            b0._touched.update(touched)
+        else:
+            le = bb.frames_embeddings.layout_embedding
+            skip = {id(q) for q in le.encoder_layer.parameters()}
+            if "scores" not in batch:
+                skip |= {id(q) for q in le.category_box_embeddings.score_embeddings.parameters()}
+            want = [prm for prm in ctx.params if prm.requires_grad and id(prm) not in skip]
+            direct = {}
+            for q in want:
+                bound = getattr(q, "_stlt_bound", None)
+                view = bound.view_of(q) if bound is not None else None
+                if view is not None:
+                    bound.touch(q)
+                    direct[id(q)] = view
+            layout, off = [], 0
+            for q in want:
+                if id(q) not in direct:
+                    layout.append((q, off, q.numel()))
+                    off += (q.numel() + 3) // 4 * 4
+            flat = torch.zeros(off, device=device, dtype=torch.float32) if off else None
+            views = {id(q): flat[o: o + n].view_as(q) for q, o, n in layout}
+            target = lambda t: direct[id(t)].data_ptr() if id(t) in direct else (views[id(t)].data_ptr() if id(t) in views else None)  # noqa: E731
+            g, gsp, gtp = bb._build_struct(None, target)
+            if key is not None and not layout and all(getattr(q, "_stlt_bound", None) is b0 for q in want):
+                bb.__dict__["_grad_table"] = (key, b0, (g, gsp, gtp, frozenset(direct)))
         tape = bb._train_buf("tape", int(lib.stlt_train_tape_bytes(B, T, N, d, p.n_spatial, p.n_temporal)), device)
         scratch = bb._train_buf("scratch", int(lib.stlt_train_scratch_bytes(B, T, N, d, p.n_categories)), device)
         dl = dout.contiguous().float()

@@ -606,11 +606,12 @@ def grad_targets(ws, needs):
     targets, returned = [], []
     for w, need in zip(ws, needs):
         bound = getattr(w, "_stlt_bound", None)
+        view = bound.view_of(w) if (need and bound is not None) else None
         if not need:
             targets.append(None); returned.append(None)
-        elif bound is not None and bound.accumulating and w.grad is not None and bound.owns(w):
+        elif view is not None:
             bound.touch(w)
-            targets.append(w.grad); returned.append(None)
+            targets.append(view); returned.append(None)
         else:
             g = torch.zeros_like(w)
             targets.append(g); returned.append(g)
