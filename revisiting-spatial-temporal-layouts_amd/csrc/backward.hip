@@ -678,8 +678,20 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const float* __restrict
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)M * N) return;
   const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+  // eight loads of each operand in flight per step (a thread's k-loop is a chain of L2 round trips: 174 dependent steps were 43 us for the
+  // 64 x 768 input gradient of a 174-class head); the partial sums are added in a fixed order
+  const float* ap = a + m * sam;
+  const float* bp = b + n * sbn;
   float acc = 0.f;
-  for (int k = 0; k < K; ++k) acc += a[m * sam + k * sak] * b[k * sbk + n * sbn];
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { av[j] = ap[(k + j) * sak]; bv[j] = bp[(k + j) * sbk]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf(av[j], bv[j], acc);
+  }
+  for (; k < K; ++k) acc = fmaf(ap[k * sak], bp[k * sbk], acc);
   float* o = c + (int64_t)m * ldc + n;
   *o = accumulate ? *o + acc : acc;
 }
