@@ -82,9 +82,16 @@ python tools/bench_caf.py --train --batch 32 >> $O/round5_bench_caf.jsonl 2>&1
 python tools/bench_caf.py --train --batch 64 >> $O/round5_bench_caf.jsonl 2>&1
 rm -rf /tmp/pc
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o o -- python3 $R/tools/bench_caf.py --train --batch 64 --steps 4 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc -o o -- python3 $R/tools/bench_caf.py --train --batch 64 --steps 12 --warmup 3 > /dev/null 2>&1
 python3 $R/tools/step_trace.py $(find /tmp/pc -name '*kernel_trace.csv' | head -1) --marker sumsq_kernel --summary > $O/round5_caf_train_step_timeline_b64.txt
 cd $R
+# the switches of the fusion-model step, one box: block weight-gradient deferral, FFN1 keep epilogue, cross-attention backward, attn16 dropout
+: > $O/round5_caf_switches_ab.jsonl
+for sw in "" "STLT_BLOCK_DW_DEFER=0" "STLT_FFN1_KEEP_FUSED=0" "STLT_ATTN_BWDX16=0" "STLT_ATTN16_DROPOUT=0" ""; do
+  echo "{\"switch\": \"${sw:-default}\"}" >> $O/round5_caf_switches_ab.jsonl
+  env $sw python tools/bench_caf.py --train --batch 64 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $O/round5_caf_switches_ab.jsonl
+done
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/round5_smoke.log 2>&1
 tail -1 $O/round5_bench_b1024.json | cut -c1-300
 tail -1 $O/round5_bench_train_b64.json | cut -c1-300
 head -8 $O/round5_kernel_stats_b1024.csv | cut -c1-200
