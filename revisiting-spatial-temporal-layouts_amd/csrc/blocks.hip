@@ -81,16 +81,16 @@ struct DwList {
 // loop per process uses it at a time (the mutex only keeps the queue consistent).
 constexpr int DW_DEFER_CAP = 512;
 struct DwCollector { StltWeightGradItem it[DW_DEFER_CAP]; int n = 0; bool on = false; std::mutex mu; };
-DwCollector t_dw;
+DwCollector g_dw;
 
 int flush_dw(const DwList& l, const BlockScratch& sc, hipStream_t s) {
   if (l.n == 0) return 0;
   bool group_ok = true;
   for (int i = 0; i < l.n; ++i) group_ok = group_ok && l.it[i].rows % 32 == 0 && l.it[i].rows <= 4096;  // long contractions: separate launches are as fast (train.hip: weight_grad_all)
   if (group_ok) {
-    std::lock_guard<std::mutex> lk(t_dw.mu);
-    if (t_dw.on && t_dw.n + l.n <= DW_DEFER_CAP) {
-      for (int i = 0; i < l.n; ++i) t_dw.it[t_dw.n++] = l.it[i];
+    std::lock_guard<std::mutex> lk(g_dw.mu);
+    if (g_dw.on && g_dw.n + l.n <= DW_DEFER_CAP) {
+      for (int i = 0; i < l.n; ++i) g_dw.it[g_dw.n++] = l.it[i];
       return 0;
     }
   }
@@ -123,39 +123,39 @@ int linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64
 extern "C" {
 
 int stlt_block_dw_defer(int mode) {
-  std::lock_guard<std::mutex> lk(t_dw.mu);
-  if (mode == 1) { t_dw.on = true; return 0; }
-  if (mode == 0) { t_dw.on = false; return 0; }
-  if (mode == -1) { t_dw.on = false; t_dw.n = 0; return 0; }
+  std::lock_guard<std::mutex> lk(g_dw.mu);
+  if (mode == 1) { g_dw.on = true; return 0; }
+  if (mode == 0) { g_dw.on = false; return 0; }
+  if (mode == -1) { g_dw.on = false; g_dw.n = 0; return 0; }
   return stlt_set_error(STLT_EINVAL, "stlt_block_dw_defer: mode 1 (collect), 0 (stop collecting; queued products stay) or -1 (stop and discard)");
 }
-int stlt_block_dw_pending(void) { std::lock_guard<std::mutex> lk(t_dw.mu); return t_dw.n; }
+int stlt_block_dw_pending(void) { std::lock_guard<std::mutex> lk(g_dw.mu); return g_dw.n; }
 int stlt_block_dw_flush(void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream) {
-  std::lock_guard<std::mutex> lk(t_dw.mu);
-  if (t_dw.n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_dw.mu);
+  if (g_dw.n == 0) return 0;
   if (!gemm_scratch || gemm_scratch_bytes < STLT_GEMM_SCRATCH_BYTES) return stlt_set_error(STLT_EWORKSPACE, "stlt_block_dw_flush: needs stlt_gemm_scratch_bytes() of scratch");
   StltGemmScratch lend(gemm_scratch, STLT_GEMM_SCRATCH_BYTES);
   hipStream_t s = (hipStream_t)stream;
   // groups in queue order, closed at 32 products or when a product's gradient overlaps one already in the group (a weight used by two
   // blocks — the fusion models' shared cross-attention, models.py:411-419 — accumulates in launch order, as the per-block launches did)
   int i0 = 0, rc = 0;
-  while (i0 < t_dw.n && rc == 0) {
+  while (i0 < g_dw.n && rc == 0) {
     int i1 = i0;
-    for (; i1 < t_dw.n && i1 - i0 < STLT_GEMM_GROUP_MAX; ++i1) {
-      const float* lo = t_dw.it[i1].g_w;
-      const float* hi = lo + t_dw.it[i1].n_out * t_dw.it[i1].k_in;
+    for (; i1 < g_dw.n && i1 - i0 < STLT_GEMM_GROUP_MAX; ++i1) {
+      const float* lo = g_dw.it[i1].g_w;
+      const float* hi = lo + g_dw.it[i1].n_out * g_dw.it[i1].k_in;
       bool clash = false;
       for (int j = i0; j < i1 && !clash; ++j) {
-        const float* lo2 = t_dw.it[j].g_w;
-        const float* hi2 = lo2 + t_dw.it[j].n_out * t_dw.it[j].k_in;
+        const float* lo2 = g_dw.it[j].g_w;
+        const float* hi2 = lo2 + g_dw.it[j].n_out * g_dw.it[j].k_in;
         clash = lo < hi2 && lo2 < hi;
       }
       if (clash) break;
     }
-    rc = launch_weight_grad_group(t_dw.it + i0, i1 - i0, s);
+    rc = launch_weight_grad_group(g_dw.it + i0, i1 - i0, s);
     i0 = i1;
   }
-  t_dw.n = 0;
+  g_dw.n = 0;
   return rc;
 }
 
