@@ -372,3 +372,35 @@ def test_fused_residual_knob_gives_identical_logits(pkg, tmp_path):
     fused = torch.load(out)
     assert torch.equal(fused, here)
     assert np.abs(fused.numpy() - z["logits"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2"])
+def test_forward_replays_from_a_hip_graph(pkg, name):
+    """include/stlt_hip.h: the forward is a fixed launch sequence on the caller's stream — no allocation, synchronisation or host
+    read-back — so it can be captured once per batch shape (torch.cuda.CUDAGraph = hipGraph on ROCm) and replayed on new inputs
+    written into the captured tensors: same logits, bit for bit, as the eager call on those inputs, and the golden's within 1e-4."""
+    sd, batch, z, meta = golden_case(name)
+    m = _model(pkg, name, sd)
+    static = _to(batch)
+    other = {k: v.clone() for k, v in static.items()}
+    other["boxes"] = (other["boxes"] * 0.5).contiguous()  # a second, different, batch of the same shape (box coordinates halved)
+    with torch.no_grad():
+        eager_a = m(static)["stlt"].clone()  # also the warm-up: workspaces, per-device function attributes, occupancy queries
+        eager_b = m(other)["stlt"].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(static)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = m(static)["stlt"]
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, eager_a)
+        assert np.abs(captured.cpu().numpy() - z["logits"]).max() <= TOL
+        for k in static:
+            static[k].copy_(other[k])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, eager_b) and not torch.equal(eager_a, eager_b)
