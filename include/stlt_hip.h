@@ -442,6 +442,22 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
 int stlt_block_dw_defer(int mode);
 int stlt_block_dw_pending(void);
 int stlt_block_dw_flush(void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream);
+/* Transposed weight copies for the input-gradient products of a training step (csrc/wt_cache.hip; ONE set per process).  dX = dY·W with W
+ * (n_out, k_in) read as it lies runs 13 - 17 % below a forward product of the same shape on the small-tile kernel; with a copy wt (k_in,
+ * n_out) it IS a forward product.  stlt_wt_refresh writes every entry's copy (wt[k][n] = w[n][k]; caller-owned buffers; dimensions
+ * multiples of 4, 16-byte aligned) on `stream` and makes the set current: until stlt_wt_clear, every input-gradient product of the library
+ * (stlt_train_backward, the block backwards, stlt_linear_bwd, stlt_input_grad_small with tile 0) whose weight pointer lies inside a
+ * registered weight — row ranges of a packed in-projection included — and that routes to the small tiles reads the copy.  The caller
+ * refreshes after the weights changed and before the products run on the same stream (train.Trainer: at the start of every step) and
+ * clears before anything else may change the weights (at the end of the step).  stlt_wt_hits: products served from a copy so far. */
+typedef struct {
+  const float* w;      /* (n_out, k_in) row-major: nn.Linear's weight */
+  float* wt;           /* (k_in, n_out) row-major: the copy */
+  int64_t n_out, k_in;
+} stlt_wt_entry;
+int stlt_wt_refresh(const stlt_wt_entry* entries, int64_t n, stlt_stream_t stream);
+int stlt_wt_clear(void);
+long long stlt_wt_hits(void);
 size_t stlt_block_scratch_bytes(int64_t rows, int64_t d);
 int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_t H, float eps, const float* x, int64_t Lq, const float* c,
                               int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed, uint32_t site0, float* q,

@@ -28,6 +28,10 @@ class OptChunk(C.Structure):
     _fields_ = [("param", C.c_void_p), ("flat_offset", C.c_int64), ("n", C.c_int32), ("weight_decay", C.c_float)]
 
 
+class WtEntry(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("n_out", C.c_int64), ("k_in", C.c_int64)]
+
+
 class WgradItem(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("n_out", C.c_int64), ("x", C.c_void_p), ("k_in", C.c_int64), ("rows", C.c_int64), ("g_w", C.c_void_p)]
 
@@ -96,6 +100,9 @@ SIGNATURES = {
     "stlt_block_dw_defer": (C.c_int, [C.c_int]),
     "stlt_block_dw_pending": (C.c_int, []),
     "stlt_block_dw_flush": (C.c_int, [_vp, C.c_size_t, _vp]),
+    "stlt_wt_refresh": (C.c_int, [_vp, C.c_int64, _vp]),
+    "stlt_wt_clear": (C.c_int, []),
+    "stlt_wt_hits": (C.c_longlong, []),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
     "stlt_weight_grad_group": (C.c_int, [_vp, C.c_int, _vp]),

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstlt_hip.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 SOURCES = ["api.hip", "rowwise.hip", "gemm.hip", "attn.hip", "backward.hip", "train.hip", "collate.hip", "caf.hip", "ragged.hip",
-           "optim.hip", "bwd_api.hip", "evalk.hip", "attn16.hip", "attn_bwd16.hip", "attn_bwdx16.hip", "mhsa.hip", "blocks.hip", "gemm_bf16x3.hip", "gemm16.hip", "gemm16_rb4.hip", "gemm16_rb2.hip", "attn_any.hip", "gemm_any.hip"]
+           "optim.hip", "bwd_api.hip", "evalk.hip", "attn16.hip", "attn_bwd16.hip", "attn_bwdx16.hip", "wt_cache.hip", "mhsa.hip", "blocks.hip", "gemm_bf16x3.hip", "gemm16.hip", "gemm16_rb4.hip", "gemm16_rb2.hip", "attn_any.hip", "gemm_any.hip"]
 BASE_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 # per-source flags of the default build.  gemm_bf16x3.hip: the SLP vectoriser would pair the operand cut's f32 subtractions into
 # v_pk_add_f32, which issues slower than two v_sub_f32 beside MFMAs (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever")

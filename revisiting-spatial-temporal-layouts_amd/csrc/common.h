@@ -210,6 +210,7 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
 // gemm16.hip: the same product on 128 x (16 NT) whole tiles for under-filled launches (no stream-K, no fix-up); *taken = launched
 double stlt_linear_est_us(int64_t M, int64_t N, int64_t K);  // launch-time estimate of launch_linear's duration (us)
 int stlt_gemm16_set_mode(int mode);  // -1 by estimate (default), 0 off, 1 always
+bool stlt_wt_lookup(const float* w, int64_t n_out, int64_t k_in, const float** wt, int64_t* ldwt);  // wt_cache.hip: the current transposed copy of (a row range of) a weight
 int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, bool wkn = false);  // 0 = gemm.hip keeps the product, else the tile code (row blocks << 5 | column tiles; wkn: the input-gradient build)
 int stlt_gemm16_tile_from_public(int tile);  // C-ABI tile parameter (columns | rows << 16, rows 0 = 128) -> tile code, 0 = not a tile of the kernel
 int stlt_gemm16_tile_to_public(int code);

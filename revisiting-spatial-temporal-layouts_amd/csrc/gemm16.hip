@@ -252,6 +252,29 @@ int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int
   // column sums of c left in gelu_bwd->cs_part (16 partial rows per 256 rows; train.hip: stlt_ffn_hidden_backward_fused)
   *taken = false;
   if (gelu_bwd && (!r || !gelu_bwd->cs_part)) return stlt_set_error(STLT_EINVAL, "gemm16 (GELU backward): the pre-activation and a column-sum buffer are required");
+  // a current transposed copy of the weight (a trainer step refreshed it: wt_cache.hip): the product is a forward product dX = dY·(Wt)ᵀ on
+  // the forward build — same add-source / GELU-backward epilogues, the forward build's cost table for the tile
+  const float* wt = nullptr;
+  int64_t ldwt = 0;
+  if (force_tile == 0 && dy && w && c && stlt_wt_lookup(w, n_out, k_in, &wt, &ldwt)) {
+    const int fcode = stlt_gemm16_choice(rows, k_in, n_out, ld_dy, ldwt, false);
+    if (fcode != 0) {
+      if (ld_dy < n_out || ldc < k_in || (r && ldr < k_in) || ldc % 4 != 0 || (r && ldr % 4 != 0)) return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): bad leading dimension");
+      const int frb = tile_rb(fcode), fnt = tile_nt(fcode);
+      Gemm16Args a{};
+      if (gelu_bwd) a.epi = *gelu_bwd;
+      a.X = dy; a.W = wt; a.bias = nullptr; a.R = r; a.Y = c;
+      a.ldx = ld_dy; a.ldw = ldwt; a.ldr = ldr; a.ldy = ldc;
+      a.M = (int)rows; a.N = (int)k_in; a.K = (int)n_out;
+      a.tiles_m = (int)((rows + 16 * frb - 1) / (16 * frb));
+      a.tiles_n = (int)((k_in + 16 * fnt - 1) / (16 * fnt));
+      if ((int64_t)a.tiles_m * a.tiles_n > 0x3fffffffLL) return stlt_set_error(STLT_EINVAL, "gemm16 (input gradient): too many tiles");
+      StltProfScope ps(STLT_K_GEMM, s);
+      stlt_prof_add_flops(2.0 * (double)rows * (double)k_in * (double)n_out);
+      *taken = true;
+      return launch16_any(fcode, a, gelu_bwd ? STLT_ACT_GELU_BWD : STLT_ACT_NONE, r != nullptr && !gelu_bwd, false, s);
+    }
+  }
   int code = force_tile;
   if (code == 0) code = stlt_gemm16_choice(rows, k_in, n_out, ld_dy, k_in, true);
   else if (!shape_ok(rows, k_in, n_out, ld_dy, k_in) || !tile_ok(tile_rb(code), tile_nt(code)))

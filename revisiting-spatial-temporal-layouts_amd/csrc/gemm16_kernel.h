@@ -476,6 +476,7 @@ int launch16_as(const Gemm16Args& a, hipStream_t s) {
 template <int RB, int NT>
 int launch16_nt(const Gemm16Args& a, int act, bool add, bool wkn, hipStream_t s) {
   if (wkn && act == STLT_ACT_GELU_BWD) return launch16_as<RB, NT, STLT_ACT_GELU_BWD, false, true>(a, s);
+  if (act == STLT_ACT_GELU_BWD) return launch16_as<RB, NT, STLT_ACT_GELU_BWD, false, false>(a, s);  // the same epilogue on the forward build: dX through a transposed weight copy (wt_cache.hip)
   if (wkn) return add ? launch16_as<RB, NT, STLT_ACT_NONE, true, true>(a, s) : launch16_as<RB, NT, STLT_ACT_NONE, false, true>(a, s);
   if (add) return launch16_as<RB, NT, STLT_ACT_NONE, true, false>(a, s);
   if (act == STLT_ACT_GELU_KEEP) return launch16_as<RB, NT, STLT_ACT_GELU_KEEP, false, false>(a, s);

@@ -1,5 +1,6 @@
 """Training step parity: the native forward/backward against torch autograd on the CPU oracle."""
 import importlib
+import math
 
 import numpy as np
 import pytest
@@ -541,3 +542,86 @@ def test_fused_criterion_ignores_label_minus_100_like_torch(pkg):
     assert (dl.cpu()[[3, 11, 36]] == 0).all()
     loss2, dl2 = pkg.train.fused_criterion(x.cuda(), torch.full((37,), -100).cuda(), "something")
     assert loss2.item() != loss2.item() and (dl2 == 0).all()
+
+
+def test_transposed_weight_copies_serve_the_input_gradient_products(pkg):
+    """csrc/wt_cache.hip: stlt_wt_refresh writes wt[k][n] = w[n][k] for every registered weight (ragged 64 x 64 tiles included) and, until
+    stlt_wt_clear, the input-gradient products that route to the small tiles read the copy — a row range of a packed weight included
+    (the cross-attention blocks' k | v rows of in_proj_weight).  Same dx as with the weight read as it lies (summation order aside),
+    and as torch in fp64."""
+    import ctypes as C
+    lib = pkg._lib.load()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(768, 768), (2304, 768), (96, 100), (3072, 768), (160, 36)]
+    ws = [(torch.randn(n, k, generator=g) / math.sqrt(k)).to(DEV) for n, k in shapes]
+    wts = [torch.full((k, n), float("nan"), device=DEV) for n, k in shapes]
+    ent = (pkg._lib.WtEntry * len(ws))()
+    for e, w, t in zip(ent, ws, wts):
+        e.w, e.wt, e.n_out, e.k_in = w.data_ptr(), t.data_ptr(), w.shape[0], w.shape[1]
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        pkg._lib.check(lib.stlt_wt_refresh(ent, len(ws), stream), "stlt_wt_refresh")
+        for w, t in zip(ws, wts):
+            assert torch.equal(t, w.t().contiguous())
+        M = 2048
+        x = torch.randn(M, 768, generator=g).to(DEV)
+        cases = [(ws[0], 768), (ws[1][768:], 1536), (ws[3], 3072)]  # whole weights and the k | v rows of the packed in-projection
+        hits0 = lib.stlt_wt_hits()
+        with_copy = []
+        for w, n_out in cases:
+            xr = x.clone().requires_grad_(True)
+            dy = torch.randn(M, n_out, generator=torch.Generator().manual_seed(n_out)).to(DEV)
+            pkg.ops.LinearFn.apply(xr, w, None).backward(dy)
+            with_copy.append((xr.grad.clone(), dy))
+        assert lib.stlt_wt_hits() - hits0 >= len(cases)
+        lib.stlt_wt_clear()
+        hits1 = lib.stlt_wt_hits()
+        for (dx_copy, dy), (w, n_out) in zip(with_copy, cases):
+            xr = x.clone().requires_grad_(True)
+            pkg.ops.LinearFn.apply(xr, w, None).backward(dy)
+            ref = dy.double() @ w.double()
+            scale = ref.abs().max().item()
+            assert (xr.grad.double() - ref).abs().max().item() / scale <= 1e-5  # fp32 accumulation over up to 3072 terms
+            assert (dx_copy.double() - ref).abs().max().item() / scale <= 1e-5
+        assert lib.stlt_wt_hits() == hits1  # withdrawn: the weights are read as they lie
+        bad = (pkg._lib.WtEntry * 1)()
+        bad[0].w, bad[0].wt, bad[0].n_out, bad[0].k_in = ws[0].data_ptr(), wts[0].data_ptr(), 767, 768
+        assert lib.stlt_wt_refresh(bad, 1, stream) != 0
+    finally:
+        lib.stlt_wt_clear()
+
+
+def test_trainer_steps_agree_with_and_without_transposed_weight_copies(pkg, monkeypatch):
+    """train.Trainer refreshes the copies at the start of every step and withdraws them at its end: three steps with dropout off give the
+    same losses, gradient norms and parameters as with STLT_TRAIN_WT=0 (to the rounding of a different summation order in dX), the copies
+    really served products, and none is current after a step."""
+    name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
+    lib = pkg._lib.load()
+    runs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("STLT_TRAIN_WT", on)
+        kw = dict(pkg.synth.model_kwargs(name), hidden_dropout_prob=0.0)
+        m = pkg.Stlt(pkg.StltModelConfig(**kw))
+        m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234))
+        m.to(DEV)
+        tr = pkg.train.Trainer(m, "something", learning_rate=1e-3, weight_decay=1e-3, clip_val=5.0, warmup_steps=0, total_steps=100)
+        assert (tr.transposed is not None) == (on == "1")
+        hits0 = lib.stlt_wt_hits()
+        log = []
+        for s in range(3):
+            batch = pkg.synth.make_batch(48, c["T"], c["N"], seed=700 + s)
+            batch["labels"] = torch.randint(0, c["num_classes"], (48,), generator=torch.Generator().manual_seed(800 + s))
+            out = tr.step({k: v.to(DEV) for k, v in batch.items()})
+            log.append((float(out["loss"]), float(out["grad_norm"])))
+        used = lib.stlt_wt_hits() - hits0
+        assert (used > 0) == (on == "1"), used
+        probe = torch.zeros(8, 256, device=DEV, requires_grad=True)  # after the step: nothing is current
+        h = lib.stlt_wt_hits()
+        pkg.ops.LinearFn.apply(probe, m.backbone.transformer.layers[0].linear1.weight, None).sum().backward()
+        assert lib.stlt_wt_hits() == h
+        runs.append((log, [p.detach().clone() for p in m.parameters()]))
+    (log_a, pa), (log_b, pb) = runs
+    for (la, ga), (lb, gb) in zip(log_a, log_b):
+        assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb)) and abs(ga - gb) <= 2e-5 * max(1.0, gb)
+    assert max((a - b).abs().max().item() for a, b in zip(pa, pb)) <= 5e-4  # lr / 2 (Adam amplifies last-bit gradient noise up to the step size)
