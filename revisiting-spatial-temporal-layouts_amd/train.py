@@ -275,6 +275,8 @@ class TransposedWeights:
         self.flat = torch.empty(off, device=self.params[0].device, dtype=torch.float32) if self.params else None
         self.entries = (L.WtEntry * max(1, len(self.params)))()
         self._sentinel = None
+        self._side = None       # the copies are written beside the step's forward (only its backward reads them): a stream of their own
+        self._pending = False
 
     def refresh(self) -> None:
         if not self.params:
@@ -285,11 +287,25 @@ class TransposedWeights:
             for e, p, o, ptr in zip(self.entries, self.params, self.offsets, ptrs):
                 e.w, e.wt, e.n_out, e.k_in = ptr, base + 4 * o, p.shape[0], p.shape[1]
             self._sentinel = ptrs
-        with torch.cuda.device(self.flat.device):
-            L.check(L.load().stlt_wt_refresh(self.entries, len(self.params), torch.cuda.current_stream().cuda_stream), "stlt_wt_refresh")
+        dev = self.flat.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        # behind everything the caller's stream holds (the update that produced these weights, the last step's products that read the old
+        # copies); the step's backward joins before its first input-gradient product
+        self._side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.device(dev):
+            L.check(L.load().stlt_wt_refresh(self.entries, len(self.params), self._side.cuda_stream), "stlt_wt_refresh")
+        self._pending = True
+
+    def join(self) -> None:
+        """The caller's stream waits for the copies (call before the step's backward)."""
+        if self._pending:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+            self._pending = False
 
     def clear(self) -> None:
         if self.params:
+            self.join()
             L.load().stlt_wt_clear()
 
 
@@ -340,6 +356,10 @@ class Trainer:
         finally:
             self.transposed.clear()
 
+    def _join_transposed(self) -> None:
+        if self.transposed is not None:
+            self.transposed.join()
+
     def _step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
         self.model.train(True)
         if self.bound is not None:
@@ -355,9 +375,11 @@ class Trainer:
                 l, g = fused_criterion(v, batch["labels"], self.dataset_name, 1.0 / len(heads))
                 loss = loss + l
                 grads.append(g)
+            self._join_transposed()
             torch.autograd.backward(heads, grads)
         else:
             loss = criterion(logits, batch["labels"], self.dataset_name)
+            self._join_transposed()
             loss.backward()
         if self.fused:
             # the reverse sweep left every gradient in one flat buffer: all-reduce it in place, then norm + clip +
@@ -388,6 +410,7 @@ class Trainer:
             l, g = fused_criterion(v, batch["labels"], self.dataset_name, 1.0 / len(heads))
             loss = loss + l
             grads.append(g)
+        self._join_transposed()
         self.bound.accumulating = True
         try:
             # the blocks' weight-gradient products (2 - 4 per block, 34 blocks in CACNF) are queued and run as a few grouped launches when

@@ -12,7 +12,7 @@ if [ "$1" == "suites" ]; then
   python tools/soak.py --reps 200 > $O/round5_soak.jsonl 2>/dev/null
   python -m pytest tests -q -m gpu > $O/round5_pytest_gpu.log 2>&1
   STLT_GEMM_SPLIT_BF16=6 python -m pytest tests -q -m gpu > $O/round5_pytest_gpu_split_bf16_on.log 2>&1
-  STLT_FUSED_MHSA=0 STLT_GEMM16=0 STLT_TRAIN_DW_STREAM=0 STLT_TRAIN_DEFER_REDUCE=0 STLT_ATTN16_TAIL=0 STLT_BLOCK_DW_DEFER=0 STLT_FFN1_KEEP_FUSED=0 python -m pytest tests -q -m gpu > $O/round5_pytest_gpu_dispatches_off.log 2>&1
+  STLT_FUSED_MHSA=0 STLT_GEMM16=0 STLT_TRAIN_DW_STREAM=0 STLT_TRAIN_DEFER_REDUCE=0 STLT_ATTN16_TAIL=0 STLT_BLOCK_DW_DEFER=0 STLT_FFN1_KEEP_FUSED=0 STLT_TRAIN_WT=0 STLT_ATTN_BWDX16=0 STLT_ATTN16_DROPOUT=0 python -m pytest tests -q -m gpu > $O/round5_pytest_gpu_dispatches_off.log 2>&1
   for f in $O/round5_pytest_gpu.log $O/round5_pytest_gpu_split_bf16_on.log $O/round5_pytest_gpu_dispatches_off.log; do tail -n 1 $f; done
   python - <<PY
 import json
@@ -87,7 +87,7 @@ python3 $R/tools/step_trace.py $(find /tmp/pc -name '*kernel_trace.csv' | head -
 cd $R
 # the switches of the fusion-model step, one box: block weight-gradient deferral, FFN1 keep epilogue, cross-attention backward, attn16 dropout
 : > $O/round5_caf_switches_ab.jsonl
-for sw in "" "STLT_BLOCK_DW_DEFER=0" "STLT_FFN1_KEEP_FUSED=0" "STLT_ATTN_BWDX16=0" "STLT_ATTN16_DROPOUT=0" ""; do
+for sw in "" "STLT_BLOCK_DW_DEFER=0" "STLT_FFN1_KEEP_FUSED=0" "STLT_ATTN_BWDX16=0" "STLT_ATTN16_DROPOUT=0" "STLT_TRAIN_WT=0" ""; do
   echo "{\"switch\": \"${sw:-default}\"}" >> $O/round5_caf_switches_ab.jsonl
   env $sw python tools/bench_caf.py --train --batch 64 --steps 10 --warmup 3 2>/dev/null | tail -1 >> $O/round5_caf_switches_ab.jsonl
 done
