@@ -22,7 +22,9 @@
  *     products, owned by a call from its first fork to its join: concurrent sweeps of several host threads on the same
  *     device are serialised on a per-device mutex for that span (host-side enqueue only; different devices do not
  *     contend), and every exit path of the call — error returns included — joins the side stream back into `stream`.
- *     One model per process is the intended use.
+ *     The queue of deferred block weight gradients (stlt_block_dw_defer) and the set of transposed weight copies
+ *     (stlt_wt_refresh .. stlt_wt_clear) are ONE each per process, mutex-guarded, owned by the training loop that
+ *     switched them on.  One model and one training loop per process is the intended use.
  *   - plain C: this header compiles as C99 and as C++ (tests/test_host_cpu.py builds a C client against the library).
  */
 #ifndef STLT_HIP_H
