@@ -184,6 +184,9 @@ def make_video_samples(dataset: str, n_videos: int, N: int, seed: int):
 CONFIGS = {
     "micro": dict(T=5, N=3, hidden_size=32, num_attention_heads=4, num_spatial_layers=1, num_temporal_layers=1,
                   num_classes=7, dataset="something"),
+    # the smallest model the checkpoint round-trip fixture trains on the GPU box (tools/make_ckpt_fixture.py: 58 KB of weights; head dim 8)
+    "nano": dict(T=9, N=3, hidden_size=16, num_attention_heads=2, num_spatial_layers=1, num_temporal_layers=1,
+                 num_classes=7, dataset="something"),
     "cfg1": dict(T=16, N=4, hidden_size=256, num_attention_heads=4, num_spatial_layers=4, num_temporal_layers=8,
                  num_classes=174, dataset="something"),
     "cfg2": dict(T=32, N=7, hidden_size=768, num_attention_heads=12, num_spatial_layers=4, num_temporal_layers=8,
@@ -215,6 +218,22 @@ def model_kwargs(name: str) -> dict:
         num_temporal_layers=c["num_temporal_layers"],
         hidden_dropout_prob=0.0,
     )
+
+
+# The small learnable task of the epoch-shell fixture (tools/gen_golden_fit.py -> tests/golden/fit_micro.npz): the label of a clip is a
+# function of its number of real frames, which the temporal tower sees through the frame types and positions.
+FIT_TASK = dict(config="micro", T=9, N=3, clips_per_batch=16, train_batches=2, val_batches=2, epochs=6, warmup_epochs=1, lr=6e-3,
+                weight_decay=1e-3, clip_val=5.0, weight_seed=77)
+
+
+def fit_batch(split: str, epoch: int, index: int) -> Dict[str, torch.Tensor]:
+    """Batch `index` of `epoch` of the fit task's train split (a fresh shuffle per epoch, as a DataLoader(shuffle=True) gives) or of
+    its fixed validation split, with labels."""
+    t = FIT_TASK
+    seed = 40000 + 100 * epoch + index if split == "train" else 90000 + index
+    b = make_batch(t["clips_per_batch"], t["T"], t["N"], seed=seed)
+    b["labels"] = (b["lengths"] - 2) % CONFIGS[t["config"]]["num_classes"]
+    return b
 
 
 def make_appearance_features(B: int, seed: int = 0, channels: int = 2048) -> torch.Tensor:

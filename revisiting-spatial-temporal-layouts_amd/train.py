@@ -16,7 +16,7 @@ shards reproduce the single-process global batch exactly.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional
+from typing import Callable, Dict, Iterable, List, Optional
 
 import torch
 import torch.nn.functional as F
@@ -449,3 +449,44 @@ class Trainer:
                 out["loss"] = l / self.world
             log.append({k: float(v) for k, v in out.items()})
         return log
+
+    def fit_epochs(self, train_batches, val_batches, evaluator, epochs: int, device, save_model_path: Optional[str] = None,
+                   save_backbone_path: Optional[str] = None, on_epoch: Optional[Callable[[dict], None]] = None) -> List[dict]:
+        """The epoch shell of the reference's `train()` (src/train.py:115-152): per epoch, the optimisation steps over the epoch's
+        GLOBAL batches (`fit`), then `model.train(False)`, `evaluator.reset()`, the validation batches under no_grad into the
+        evaluator (utils/evaluation.py: counters / score tables stay on the device, one read-back in `evaluate()`), and when
+        `evaluator.is_best()` rank 0 writes `model.state_dict()` to `save_model_path` and — if asked — `model.backbone.state_dict()`
+        to `save_backbone_path` (what `Stlt(config)` with `load_backbone_path` reads back, models.py:130-134,170-176).
+
+        `train_batches`: a re-iterable of collated batches holding `labels` (a list, a DataLoader), or a callable epoch -> iterable
+        (a fresh shuffle per epoch).  Every rank passes the same global batches and takes its contiguous shard; the evaluators sum
+        their counters / gather their tables over the default process group.  The scheduler's horizon is the caller's:
+        `Trainer(total_steps=epochs * len(train_loader), warmup_steps=warmup_epochs * len(train_loader))` as train.py:108-113.
+        -> one dict per epoch: {"epoch", "steps": [{"loss", "grad_norm"}...], "metrics", "is_best", "saved"}."""
+        history = []
+        for epoch in range(int(epochs)):
+            steps = self.fit(train_batches(epoch) if callable(train_batches) else train_batches, device)
+            self.model.train(False)
+            evaluator.reset()
+            with torch.no_grad():
+                for batch in (val_batches(epoch) if callable(val_batches) else val_batches):
+                    mine = D.shard_batch(batch, self.rank, self.world)
+                    if mine["categories"].shape[0] == 0:  # more ranks than clips in the last batch
+                        continue
+                    mine = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in mine.items()}
+                    evaluator.process(self.model(mine), mine["labels"])
+            metrics = evaluator.evaluate()
+            best = bool(evaluator.is_best())  # every rank evaluates (the evaluators' collectives need all of them); rank 0 writes
+            saved = []
+            if best and self.rank == 0:
+                if save_model_path:
+                    torch.save(self.model.state_dict(), save_model_path)
+                    saved.append(save_model_path)
+                if save_backbone_path:
+                    torch.save(self.model.backbone.state_dict(), save_backbone_path)
+                    saved.append(save_backbone_path)
+            rec = {"epoch": epoch, "steps": steps, "metrics": dict(metrics), "is_best": best, "saved": saved}
+            if on_epoch is not None:
+                on_epoch(rec)
+            history.append(rec)
+        return history

@@ -15,10 +15,24 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "data", "config", "roofline"}
 
 
-def _last_json(stdout: str):
+def _last_json(stdout: str, with_legs=False):
+    """The contract line is the LAST JSON line and stays under 6 KB (the driver keeps an 8-KB tail of stdout); every line before it is
+    a side measurement's own object, {"leg": name, ...}."""
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, stdout[-2000:]
-    return json.loads(lines[0])
+    assert lines, stdout[-2000:]
+    assert len(lines[-1]) < 6144, len(lines[-1])
+    head = json.loads(lines[-1])
+    legs = {}
+    for l in lines[:-1]:
+        j = json.loads(l)
+        assert "leg" in j and "metric" not in j, l[:200]
+        legs[j.pop("leg")] = j
+    assert "leg" not in head
+    for name, summary in head.get("legs", {}).items():  # the last line's four-number summaries are the legs' own numbers
+        assert name in legs, (name, sorted(legs))
+        if isinstance(summary, list):
+            assert summary[0] == legs[name]["value"] and summary[1] == legs[name]["ms_per_step"], (name, summary)
+    return (head, legs) if with_legs else head
 
 
 def test_single_process_line():
@@ -30,7 +44,8 @@ def test_single_process_line():
     assert j["config"]["per_gpu_batch"] == 64 and "workload" in j["config"]
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "port"
-    assert j["skip_padding"]["value"] > j["value"] and j["logit_max_abs_diff"] <= 1e-4
+    assert j["legs"]["skip_padding"][0] > j["value"] and j["logit_max_abs_diff"] <= 1e-4
+    assert j["roofline_attn_temporal"]["bound"] == "hbm" and j["roofline_attn_temporal"]["frac"] > 0
 
 
 def test_side_legs_ride_on_the_default_line():
@@ -38,7 +53,14 @@ def test_side_legs_ride_on_the_default_line():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "256", "--side-legs", "--no-cpu-baseline",
                         "--no-skip-padding"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _last_json(r.stdout)
+    head, j = _last_json(r.stdout, with_legs=True)
+    for key in ("dense_schedule", "train_step", "cfg4", "small_batch", "cfg2p", "ref_default", "cfg2p_b64", "ref_default_b64", "skip_padding_b64", "cfg5",
+                "cfg5_train", "split_bf16"):
+        assert isinstance(head["legs"][key], list) and head["legs"][key][0] > 0, (key, head["legs"].get(key))
+    for key in ("train_step", "small_batch", "cfg2p_b64", "ref_default_b64", "cfg5_train"):  # [clips/s, ms, GEMM fraction, temporal-core fraction]
+        assert 0 < head["legs"][key][2] < 1, (key, head["legs"][key])
+    assert 0 < head["legs"]["small_batch"][3] < 1 and 0 < head["legs"]["ref_default_b64"][3] < 1
+    assert j["skip_padding_b64"]["value"] > j["small_batch"]["value"]
     assert "error" not in j["cfg5_train"] and j["cfg5_train"]["value"] > 0 and j["cfg5_train"]["grad_norm"] > 0 and 0 < j["cfg5_train"]["roofline"]["frac"] < 1, j["cfg5_train"]
     assert "error" not in j["cfg5"] and j["cfg5"]["value"] > 0 and j["cfg5"]["finite"] and 0 < j["cfg5"]["roofline"]["frac"] < 1, j["cfg5"]
     for key in ("train_step", "cfg4", "small_batch"):
@@ -52,12 +74,12 @@ def test_side_legs_ride_on_the_default_line():
     sb_t = j["small_batch"]["roofline_attn_temporal"]
     assert sb_t["launches_per_step"] > 0 and sb_t["frac"] > 0, sb_t
     # 256 clips (this run's main line): the fused kernel, with the core alone still reported against HBM
-    assert j["roofline_attn_temporal"]["frac"] > 0
+    assert head["roofline_attn_temporal"]["frac"] > 0
     if os.environ.get("STLT_FUSED_MHSA") != "0":  # (a suite run with the fused kernel switched off keeps the two launches)
-        assert j["roofline_mhsa_fused"]["frac"] > 0
+        assert head["roofline_mhsa_fused"]["frac"] > 0
     # the dense schedule beside `value` (how much of the headline is the exact elision of unread rows)
     ds = j["dense_schedule"]
-    assert "error" not in ds and 0 < ds["value"] < j["value"] * 1.02 and ds["logit_max_abs_diff_vs_value_schedule"] <= 1e-5 and 0 < ds["roofline"]["frac"] < 1, ds
+    assert "error" not in ds and 0 < ds["value"] < head["value"] * 1.02 and ds["logit_max_abs_diff_vs_value_schedule"] <= 1e-5 and 0 < ds["roofline"]["frac"] < 1, ds
     # the reference's real layouts (T = layout_num_frames + 1): 33 x 8 and 17 x 5
     for key, tn in (("cfg2p", "T=33, N=8"), ("ref_default", "T=17, N=5")):
         assert "error" not in j[key] and tn in j[key]["workload"] and j[key]["value"] > 0 and 0 < j[key]["roofline"]["frac"] < 1, j[key]
