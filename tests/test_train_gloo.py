@@ -55,8 +55,29 @@ def _worker(rank, world, port, q):
     log = tr.fit(batches, "cpu")
     if rank == 0:
         q.put((log, {k: p.detach().numpy().copy() for k, p in model.named_parameters()}))
+    # the epoch shell over two ranks: sharded optimisation steps, sharded validation into the evaluator (counters summed over the group in
+    # evaluate()), is_best on every rank, files written by rank 0 only
+    import tempfile
+    hist, files = _fit_epochs(pkg, r, w, tempfile.mkdtemp() if rank == 0 else "/nonexistent-dir-rank1")
+    if rank == 0:
+        q.put((hist, files))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def _fit_epochs(pkg, rank, world, out_dir):
+    task = pkg.synth.FIT_TASK
+    c = pkg.synth.CONFIGS[task["config"]]
+    shapes = {k: tuple(v.shape) for k, v in pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(task["config"]))).state_dict().items()}
+    model = _OracleStlt(pkg.synth.make_state_dict(shapes, seed=task["weight_seed"]), c["num_attention_heads"])
+    nb = task["train_batches"]
+    tr = pkg.train.Trainer(model, "something", learning_rate=task["lr"], weight_decay=task["weight_decay"], clip_val=task["clip_val"],
+                           warmup_steps=task["warmup_epochs"] * nb, total_steps=task["epochs"] * nb, rank=rank, world=world)
+    val = [pkg.synth.fit_batch("val", 0, i) for i in range(task["val_batches"])]
+    ev = pkg.evaluators_factory["something"](sum(b["labels"].shape[0] for b in val), c["num_classes"], ("stlt",))
+    path = os.path.join(out_dir, "model.pt")
+    hist = tr.fit_epochs(lambda e: [pkg.synth.fit_batch("train", e, i) for i in range(nb)], val, ev, task["epochs"], "cpu", save_model_path=path)
+    return hist, (os.path.exists(path), [rec["saved"] for rec in hist])
 
 
 def test_two_rank_training_matches_single_process():
@@ -69,6 +90,7 @@ def test_two_rank_training_matches_single_process():
     for p in procs:
         p.start()
     log2, params2 = q.get(timeout=300)
+    hist2, (wrote2, saved2) = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -82,6 +104,15 @@ def test_two_rank_training_matches_single_process():
         assert abs(a["grad_norm"] - b["grad_norm"]) <= 1e-4 * a["grad_norm"]
     for k, p in model.named_parameters():
         assert np.abs(p.detach().numpy() - params2[k]).max() <= 2.5e-5, k  # < lr/2: Adam turns last-bit gradient noise into O(lr) steps
+
+
+    # the epoch shell: two ranks give the reference loop's metrics and best-epoch pattern (tests/golden/fit_micro.npz), rank 0 wrote the file
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fit_micro.npz"))
+    assert wrote2 and [bool(x) for x in saved2] == [bool(x) for x in z["saved"]]
+    for e, rec in enumerate(hist2):
+        assert rec["is_best"] == bool(z["saved"][e])
+        assert (rec["metrics"]["stlt_top1_accuracy"], rec["metrics"]["stlt_top5_accuracy"]) == tuple(z[f"metrics{e}"])
+        assert abs(float(np.mean([s["loss"] for s in rec["steps"]])) - float(z[f"mean_loss{e}"][0])) <= 2e-4
 
 
 def test_weight_decay_groups_follow_reference_rule():
