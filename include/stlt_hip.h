@@ -10,21 +10,22 @@
  *   - extern "C"; every function returns 0 on success, a negative STLT_E* code on argument errors,
  *     or a positive hipError_t; stlt_last_error() returns a thread-local message.
  *   - all tensor arguments are raw DEVICE pointers owned by the caller (PyTorch allocations); the
- *     library never allocates, frees or retains them.  fp32, row-major, contiguous unless a leading
- *     dimension (ld*) is given in ELEMENTS.  ids/lengths int64, masks uint8 (1 = padded / masked).
+ *     library never allocates or frees device memory.  It retains caller pointers in ONE place only: a training-loop context
+ *     (stlt_ctx, below), which the caller creates, names in the calls that may use it, and destroys.  fp32, row-major,
+ *     contiguous unless a leading dimension (ld*) is given in ELEMENTS.  ids/lengths int64, masks uint8 (1 = padded / masked).
  *   - asynchronous on `stream` (a hipStream_t passed as void*); no implicit synchronisation — the one exception
  *     is STLT_FLAG_SKIP_PADDING, which reads two row counts back (one stream synchronisation per call); everything
  *     else is a fixed launch sequence that can be captured in a hipGraph.
  *   - per-thread state: the error string and the scratch lent with stlt_gemm_set_scratch (both thread-local).
- *     Process-wide: write-once caches of device properties; the routing switches (stlt_set_gemm_small_tiles,
+ *     Process-wide: write-once caches of device properties and the routing switches (stlt_set_gemm_small_tiles,
  *     stlt_set_gemm_split_bf16, stlt_set_train_side_stream: plain integers, set them before the calls they steer, not
- *     concurrently with them); and ONE side stream + event set per device for stlt_train_backward's weight-gradient
- *     products, owned by a call from its first fork to its join: concurrent sweeps of several host threads on the same
- *     device are serialised on a per-device mutex for that span (host-side enqueue only; different devices do not
- *     contend), and every exit path of the call — error returns included — joins the side stream back into `stream`.
- *     The queue of deferred block weight gradients (stlt_block_dw_defer) and the set of transposed weight copies
- *     (stlt_wt_refresh .. stlt_wt_clear) are ONE each per process, mutex-guarded, owned by the training loop that
- *     switched them on.  One model and one training loop per process is the intended use.
+ *     concurrently with them).  Nothing else is process-wide: what a training loop leaves in the library between calls —
+ *     the transposed weight copies of its step, its queue of deferred block weight gradients, the side stream + events of
+ *     its reverse sweeps — lives in the stlt_ctx it passes to the `*_bwd` / `*_backward` calls (NULL: none of the three).
+ *     A context is internally locked: calls naming the same context from several host threads are safe (reverse sweeps on
+ *     the same device are serialised from their first fork to their join); different contexts never interact, so two
+ *     training loops in one process — or a plain autograd backward of another model in the middle of a trainer's step —
+ *     cannot read each other's copies or queue into each other's flush.
  *   - plain C: this header compiles as C99 and as C++ (tests/test_host_cpu.py builds a C client against the library).
  */
 #ifndef STLT_HIP_H
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define STLT_VERSION 100
+#define STLT_VERSION 110  /* 110: training-loop contexts (stlt_ctx) in the backward calls; block backward buffers split into keep / work */
 
 #define STLT_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
 #define STLT_EWORKSPACE (-2) /* workspace too small */
@@ -50,6 +51,21 @@ typedef void* stlt_stream_t; /* hipStream_t */
 
 int stlt_version(void);
 const char* stlt_last_error(void);
+
+/* ---- training-loop context -------------------------------------------------------------------------------------------
+ * The reference's train() (src/train.py:102-135) is one loop over one model; its state between statements lives in torch objects.
+ * Here the three things a loop leaves INSIDE the library between calls hang off an explicit handle:
+ *   transposed weight copies   stlt_ctx_wt_refresh .. stlt_ctx_wt_clear: current for the calls that name the context, on the device of
+ *                              the refresh; every such call's stream is ordered behind the transposes by the library (an event
+ *                              recorded at the end of the refresh), whatever stream the refresh ran on
+ *   deferred weight gradients  stlt_ctx_dw_defer / _pending / _flush: queued by the block backwards that name the context
+ *   side stream + events       of stlt_train_backward's weight-gradient products: one set per context and device, created by the first
+ *                              sweep that wants it (stlt_set_train_side_stream), destroyed with the context
+ * stlt_ctx_destroy: the caller has synchronised with what it enqueued through the context; queued products are dropped, copies
+ * withdrawn.  Functions taking a context return STLT_EINVAL for a handle that is not live. */
+typedef struct stlt_ctx stlt_ctx;
+int stlt_ctx_create(stlt_ctx** out);
+int stlt_ctx_destroy(stlt_ctx* ctx);
 
 /* K1 — CategoryBoxEmbeddings.forward, src/modelling/models.py:29-39.
  * out[t,:] = LN_eps( cat_table[categories[t]] + boxes[t,0:4]·box_w^T + box_b (+ scores[t]*score_w[:,0] + score_b) )
@@ -94,11 +110,14 @@ int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const flo
 int stlt_linear_small_choice(int64_t M, int64_t N, int64_t K);
 /* The input gradient of that Linear on the same kernel: dx (M, k_in; ld_dx) = dy (M, n_out; ld_dy) · w (n_out, k_in) (+ r), the weight
  * read as it lies (no transposed copy: the [k][n] image is gathered inside the kernel).  The training sweeps (stlt_train_backward,
- * the block backwards, stlt_linear_bwd) route their under-filled dX products here by the same launch-time estimate; this entry point
- * runs it with the tile width given (n_out % 32 == 0, n_out >= 64, k_in % 4 == 0).  Same result as stlt_gemm(0, 1, ...) to rounding. */
+ * the block backwards, stlt_linear_bwd) route their under-filled dX products here by the same launch-time estimate.  tile != 0 runs it
+ * on that tile (columns | rows << 16), always reading w as it lies; tile == 0 routes by the estimate — STLT_EINVAL when the estimate
+ * leaves the product to the large tiles (stlt_input_grad_small_choice tells beforehand) — and, when `ctx` holds a current transposed
+ * copy of w (stlt_ctx_wt_refresh), runs the product as a forward product on the copy.  n_out % 32 == 0, n_out >= 64, k_in % 4 == 0.
+ * Same result as stlt_gemm(0, 1, ...) to rounding.  ctx may be NULL. */
 int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* dx,
-                          int64_t ld_dx, int64_t M, int tile, stlt_stream_t stream);
-int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in);  /* the tile width the routing picks for that input gradient (0: large tiles) */
+                          int64_t ld_dx, int64_t M, int tile, stlt_ctx* ctx, stlt_stream_t stream);
+int stlt_input_grad_small_choice(int64_t M, int64_t n_out, int64_t k_in);  /* the tile the routing picks for that input gradient, reading w as it lies: columns | rows << 16 (0: large tiles) */
 /* Process-wide routing switch: -1 = by the launch-time estimate (default; STLT_GEMM16 in the environment is the initial value),
  * 0 = every product on the large tiles, 1 = every product the small-tile kernel can take on it (A/B measurements), 128 / 64 / 32 = by
  * the estimate over tiles of that height only (tests, A/B; STLT_GEMM16_ROWS is the environment's form), -2 = back to the initial value
@@ -319,9 +338,10 @@ int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, cons
  * categories (the embedding-gradient kernel keeps per-category sums in LDS; the reference's vocabularies have 4 and 38):
  * stlt_train_scratch_bytes returns 0 and stlt_train_forward / _backward return STLT_EINVAL above it, before anything runs. */
 #define STLT_TRAIN_MAX_CATEGORIES 128
-/* stlt_train_backward runs the weight-gradient products (off the dX chain) on a second, library-owned stream per device, forked
- * from and joined to the caller's stream with events inside the call; 0 keeps every launch on the caller's stream (A/B runs, per-kernel
- * event timing without overlap).  Process-wide; STLT_TRAIN_DW_STREAM in the environment is the initial value (default on);
+/* stlt_train_backward, when it is given a context, runs the weight-gradient products (off the dX chain) on the context's second stream for
+ * the device, forked from and joined to the caller's stream with events inside the call (every exit path, error returns included, joins);
+ * without a context, or with this switch at 0, every launch stays on the caller's stream (A/B runs, per-kernel event timing without
+ * overlap).  The switch is process-wide; STLT_TRAIN_DW_STREAM in the environment is its initial value (default on);
  * on < 0 goes back to that value.  stlt_get_train_side_stream returns the setting in force (1 / 0), so that a caller can restore it. */
 int stlt_set_train_side_stream(int on);
 int stlt_get_train_side_stream(void);
@@ -335,7 +355,7 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape, 
                        float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream);
 int stlt_train_backward(const stlt_params* p, const stlt_params* grads, const stlt_inputs* in, const void* tape,
                         size_t tape_bytes, void* scratch, size_t scratch_bytes, const float* dlogits,
-                        float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream);
+                        float dropout_p, uint64_t dropout_seed, int flags, stlt_ctx* ctx, stlt_stream_t stream);
 
 /* ---- optimiser step of the training loop (reference train.py:128-131 with utils/train_inference_utils.py:37-54) ----
  * The reverse sweep writes all parameter gradients into ONE flat fp32 buffer (what a data-parallel run all-reduces).
@@ -353,7 +373,7 @@ typedef struct {
 /* ---- per-kernel backward entry points (autograd of the K-row forwards above; the fusion models' training is composed
  * from these, the STLT training step uses the fixed reverse sweep of stlt_train_backward) ----
  * stlt_linear_bwd: y = x·Wᵀ + b (no activation).  dx (M,K) = dy·W (nullable), dw (N,K) += dyᵀ·x (nullable), db (N) +=
- *   column sums of dy (nullable).  scratch: stlt_linear_bwd_scratch_bytes(N).
+ *   column sums of dy (nullable).  scratch: stlt_linear_bwd_scratch_bytes(N).  ctx (nullable): dx may run on the context's transposed copy of w.
  * stlt_attn_bwd: backward of stlt_attn_cross_fwd (and, with q = qkv, k = qkv+d, v = qkv+2d, of stlt_attn_core_fwd):
  *   dq / dk / dv written (not accumulated) with their own leading dimensions; sequences of at most 256 tokens on either
  *   side (above 64 a streamed variant: query tiles of 32, keys / values in tiles through LDS); head dims other than 64: attn_any.hip.
@@ -362,7 +382,7 @@ typedef struct {
  * stlt_gelu_fwd / stlt_gelu_bwd: exact-erf GELU and du = dh * gelu'(u), n a multiple of 4. */
 size_t stlt_linear_bwd_scratch_bytes(int64_t N);
 int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, float* dw, float* db,
-                    void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+                    stlt_ctx* ctx, void* scratch, size_t scratch_bytes, stlt_stream_t stream);
 /* Backward of K3 on the packed projection (what the training sweep runs per layer): dqkv (S*L, 3*H*dh) from qkv and dctx, with
  * the masks of stlt_attn_core_fwd, optional dropout of the probabilities (site as in stlt_train_forward) and, when in_proj_b_grad
  * is not NULL, in_proj_b_grad (3*H*dh) += column sums of dqkv.  dh == 64, L <= 64: v_mfma_f32_16x16x4_f32 tiles (one wave per
@@ -423,7 +443,7 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
 /* ---- block-level training calls for the fusion models (CAF / CACNF / LCF; reference models.py:328-431, 239-246) ----
  * One native forward and one native reverse call per residual block, so an optimisation step of a fusion model is a few
  * dozen calls instead of a few hundred op-level ones.  The caller owns the tape tensors (q / kv / ctx / a, u / h / f) and the
- * scratch (stlt_block_scratch_bytes(rows, d), rows = the larger token count of the block).
+ * two backward buffers (stlt_block_keep_bytes / stlt_block_work_bytes, below).
  *   attention block (SelfAttentionLayer / CrossAttentionLayer :345-382, and the first half of nn.TransformerEncoderLayer):
  *     out = LN_eps(x + drop(MHA(x, c, c) Wo^T + bo)); c == NULL: self-attention on a packed q|k|v buffer q (S*Lq, 3d);
  *     else q (S*Lq, d) and kv (S*Lk, 2d).  kpm (S*Lk) bytes over the keys (never NULL: pass zeros).  Dropout sites: site0 =
@@ -434,46 +454,53 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
  * gemm_scratch (forward calls): NULL, or stlt_gemm_scratch_bytes() of device memory lent for the call's stream-K launches.
  * The backward calls ACCUMULATE (+=) into the gradient struct's buffers (NULL members are skipped), write dx (and dc, the
  * gradient wrt the context tokens of a cross-attention block), and recompute the dropout masks from (drop_p, seed, site0). */
-/* Deferred weight gradients of the block calls (ONE queue per process: torch's autograd engine runs the block backwards on its own thread
- * while the training loop switches and flushes the queue from the thread that called backward()).  After stlt_block_dw_defer(1) the *_block_bwd_train calls queue their
- * weight-gradient products (g_w += dyᵀ·x) instead of launching them; stlt_block_dw_flush runs the queue as grouped stream-K launches of up to
- * 32 products on `stream` (the stream the blocks ran on) with stlt_gemm_scratch_bytes() of scratch, in queue order (two products into the same
- * gradient never share a launch).  The CALLER keeps every operand of the queued products alive and unchanged until the flush: the blocks'
- * scratch buffers (one per call: they hold the output gradients) and the forward activations they were handed.  mode 0 stops collecting
- * (queued products stay), -1 stops and discards.  A training step of the fusion models (models.py:403-431) makes 34 block calls. */
-int stlt_block_dw_defer(int mode);
-int stlt_block_dw_pending(void);
-int stlt_block_dw_flush(void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream);
-/* Transposed weight copies for the input-gradient products of a training step (csrc/wt_cache.hip; ONE set per process).  dX = dY·W with W
- * (n_out, k_in) read as it lies runs 13 - 17 % below a forward product of the same shape on the small-tile kernel; with a copy wt (k_in,
- * n_out) it IS a forward product.  stlt_wt_refresh writes every entry's copy (wt[k][n] = w[n][k]; caller-owned buffers; dimensions
- * multiples of 4, 16-byte aligned) on `stream` and makes the set current: until stlt_wt_clear, every input-gradient product of the library
- * (stlt_train_backward, the block backwards, stlt_linear_bwd, stlt_input_grad_small with tile 0) whose weight pointer lies inside a
- * registered weight — row ranges of a packed in-projection included — and that routes to the small tiles reads the copy.  The caller
- * refreshes after the weights changed and before the products run on the same stream (train.Trainer: at the start of every step) and
- * clears before anything else may change the weights (at the end of the step).  stlt_wt_hits: products served from a copy so far. */
+/* Deferred weight gradients of the block calls.  After stlt_ctx_dw_defer(ctx, 1) the *_block_bwd_train calls that name `ctx` queue their
+ * weight-gradient products (g_w += dyᵀ·x) in the context instead of launching them; stlt_ctx_dw_flush runs the queue as grouped stream-K
+ * launches of up to 32 products on `stream` (the stream the blocks ran on) with stlt_gemm_scratch_bytes() of scratch, in queue order (two
+ * products into the same gradient never share a launch).  The CALLER keeps every operand of the queued products alive and unchanged until the
+ * flush: the blocks' `keep` buffers (they hold the output gradients) and the forward activations the blocks were handed — their `work`
+ * buffers are free again when the call returns.  mode 0 stops collecting (queued products stay), -1 stops and discards.  The queue holds at
+ * most 512 products: a block that would overflow it launches its own.  A training step of the fusion models (models.py:403-431) makes 34
+ * block calls.  torch's autograd engine runs the block backwards on its own thread: the queue follows the handle, not the thread. */
+int stlt_ctx_dw_defer(stlt_ctx* ctx, int mode);
+int stlt_ctx_dw_pending(stlt_ctx* ctx);
+int stlt_ctx_dw_flush(stlt_ctx* ctx, void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream);
+/* Transposed weight copies for the input-gradient products of a training step (csrc/wt_cache.hip).  dX = dY·W with W (n_out, k_in) read as
+ * it lies runs 13 - 17 % below a forward product of the same shape on the small-tile kernel; with a copy wt (k_in, n_out) it IS a forward
+ * product.  stlt_ctx_wt_refresh writes every entry's copy (wt[k][n] = w[n][k]; caller-owned buffers; dimensions multiples of 4, 16-byte
+ * aligned) on `stream` and makes the set current in `ctx`: until stlt_ctx_wt_clear, every input-gradient product of a call that names
+ * `ctx` on the same device (stlt_train_backward, the block backwards, stlt_linear_bwd, stlt_input_grad_small with tile 0) whose weight
+ * pointer lies inside a registered weight — row ranges of a packed in-projection starting at a multiple of four rows included — and that
+ * routes to the small tiles reads the copy.  The library orders each such call's stream behind the transposes.  The caller refreshes after
+ * the weights changed (train.Trainer: at the start of every step) and clears before anything else may change them (at the end of the
+ * step); a call that names another context, or none, never sees a copy.  stlt_ctx_wt_hits: products LAUNCHED on a copy so far. */
 typedef struct {
   const float* w;      /* (n_out, k_in) row-major: nn.Linear's weight */
   float* wt;           /* (k_in, n_out) row-major: the copy */
   int64_t n_out, k_in;
 } stlt_wt_entry;
-int stlt_wt_refresh(const stlt_wt_entry* entries, int64_t n, stlt_stream_t stream);
-int stlt_wt_clear(void);
-long long stlt_wt_hits(void);
-size_t stlt_block_scratch_bytes(int64_t rows, int64_t d);
+int stlt_ctx_wt_refresh(stlt_ctx* ctx, const stlt_wt_entry* entries, int64_t n, stlt_stream_t stream);
+int stlt_ctx_wt_clear(stlt_ctx* ctx);
+long long stlt_ctx_wt_hits(stlt_ctx* ctx);
+/* Device memory of a block backward, in two buffers: `keep` (stlt_block_keep_bytes(rows, d, kind); kind 0 = attention block, 1 =
+ * feed-forward block; rows = the larger token count of the block) holds the gradients the block's weight-gradient products read — with
+ * deferral on it must stay untouched until the flush, one buffer per block call; `work` (stlt_block_work_bytes(rows, d): stream-K partial
+ * tiles, reduction pools, a context gradient) is dead when the call has enqueued its launches — one buffer per stream serves all blocks. */
+size_t stlt_block_keep_bytes(int64_t rows, int64_t d, int kind);
+size_t stlt_block_work_bytes(int64_t rows, int64_t d);
 int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_t H, float eps, const float* x, int64_t Lq, const float* c,
                               int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed, uint32_t site0, float* q,
                               float* kv, float* ctx, float* a, float* out, void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream);
 int stlt_attn_block_bwd_train(const stlt_attn_block_params* p, const stlt_attn_block_params* g, int64_t d, int64_t H, float eps, const float* x,
                               int64_t Lq, const float* c, int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed,
                               uint32_t site0, const float* q, const float* kv, const float* ctx, const float* a, const float* dy, float* dx,
-                              float* dc, void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+                              float* dc, stlt_ctx* tctx, void* keep, size_t keep_bytes, void* work, size_t work_bytes, stlt_stream_t stream);
 int stlt_ffn_block_fwd_train(const stlt_ffn_block_params* p, int64_t d, float eps, int act, int inner_dropout, const float* x, int64_t M,
                              float drop_p, uint64_t seed, uint32_t site0, float* u, float* h, float* f, float* out, void* gemm_scratch,
                              size_t gemm_scratch_bytes, stlt_stream_t stream);
 int stlt_ffn_block_bwd_train(const stlt_ffn_block_params* p, const stlt_ffn_block_params* g, int64_t d, float eps, int act, int inner_dropout,
                              const float* x, int64_t M, float drop_p, uint64_t seed, uint32_t site0, const float* u, const float* h, const float* f,
-                             const float* dy, float* dx, void* scratch, size_t scratch_bytes, stlt_stream_t stream);
+                             const float* dy, float* dx, stlt_ctx* tctx, void* keep, size_t keep_bytes, void* work, size_t work_bytes, stlt_stream_t stream);
 
 /* ---- evaluators on the device (reference src/utils/evaluation.py) ----
  * stlt_eval_topk: EvaluatorSomething.process (evaluation.py:21-34) for one logit head.  counts[0] += clips whose label is

@@ -92,17 +92,19 @@ SIGNATURES = {
                                   C.c_int, _vp]),
     "stlt_linear_small_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp]),
     "stlt_linear_small_choice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
-    "stlt_input_grad_small": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int, _vp]),
+    "stlt_input_grad_small": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64, C.c_int, _vp, _vp]),
     "stlt_input_grad_small_choice": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "stlt_set_gemm_small_tiles": (C.c_int, [C.c_int]),
     "stlt_set_train_side_stream": (C.c_int, [C.c_int]),
     "stlt_get_train_side_stream": (C.c_int, []),
-    "stlt_block_dw_defer": (C.c_int, [C.c_int]),
-    "stlt_block_dw_pending": (C.c_int, []),
-    "stlt_block_dw_flush": (C.c_int, [_vp, C.c_size_t, _vp]),
-    "stlt_wt_refresh": (C.c_int, [_vp, C.c_int64, _vp]),
-    "stlt_wt_clear": (C.c_int, []),
-    "stlt_wt_hits": (C.c_longlong, []),
+    "stlt_ctx_create": (C.c_int, [C.POINTER(_vp)]),
+    "stlt_ctx_destroy": (C.c_int, [_vp]),
+    "stlt_ctx_dw_defer": (C.c_int, [_vp, C.c_int]),
+    "stlt_ctx_dw_pending": (C.c_int, [_vp]),
+    "stlt_ctx_dw_flush": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "stlt_ctx_wt_refresh": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "stlt_ctx_wt_clear": (C.c_int, [_vp]),
+    "stlt_ctx_wt_hits": (C.c_longlong, [_vp]),
     "stlt_gemm": (C.c_int, [C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, C.c_int, _vp]),
     "stlt_weight_grad_group": (C.c_int, [_vp, C.c_int, _vp]),
@@ -135,9 +137,9 @@ SIGNATURES = {
     "stlt_train_scratch_bytes": (C.c_size_t, [C.c_int64] * 5),
     "stlt_train_forward": (C.c_int, [C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
     "stlt_train_backward": (C.c_int, [C.POINTER(Params), C.POINTER(Params), C.POINTER(Inputs), _vp, C.c_size_t, _vp,
-                                      C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp]),
+                                      C.c_size_t, _vp, C.c_float, C.c_uint64, C.c_int, _vp, _vp]),
     "stlt_linear_bwd_scratch_bytes": (C.c_size_t, [C.c_int64]),
-    "stlt_linear_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "stlt_linear_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "stlt_attn_fwd_dropout": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_float, C.c_uint64, C.c_uint32, _vp, _vp]),
     "stlt_attn_bwd": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
@@ -158,15 +160,16 @@ SIGNATURES = {
     "stlt_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
     "stlt_dropout": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp]),
     "stlt_relu_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
-    "stlt_block_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "stlt_block_keep_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
+    "stlt_block_work_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "stlt_attn_block_fwd_train": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_float, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_float,
                                             C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "stlt_attn_block_bwd_train": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_float, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.c_int64, C.c_float,
-                                            C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+                                            C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "stlt_ffn_block_fwd_train": (C.c_int, [_vp, C.c_int64, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp, _vp, _vp,
                                            _vp, _vp, C.c_size_t, _vp]),
     "stlt_ffn_block_bwd_train": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_int, C.c_int, _vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, _vp, _vp,
-                                           _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+                                           _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "stlt_prof_take_gemm_flops": (C.c_double, []),
     "stlt_eval_topk": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "stlt_eval_max_clips": (C.c_int64, []),

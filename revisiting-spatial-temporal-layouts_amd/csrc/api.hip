@@ -162,9 +162,12 @@ int stlt_linear_small_fwd(const float* x, int64_t ldx, const float* w, const flo
 }
 
 int stlt_input_grad_small(const float* dy, int64_t ld_dy, const float* w, int64_t n_out, int64_t k_in, const float* r, int64_t ldr, float* dx, int64_t ld_dx,
-                          int64_t M, int tile, stlt_stream_t stream) {
-  const int code = stlt_gemm16_tile_from_public(tile);
-  if (code == 0) return stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: tile = columns | rows << 16: 128 rows (or 0) x {48,64,96,128,144,192}, 64 x {64,96,128,160,192,256}, 32 x {128,192,256}");
+                          int64_t M, int tile, stlt_ctx* ctx, stlt_stream_t stream) {
+  // tile 0: routed by the launch-time estimate, and — when `ctx` holds a current transposed copy of w — run as a forward product on the copy
+  const int code = tile == 0 ? 0 : stlt_gemm16_tile_from_public(tile);
+  if (tile != 0 && code == 0) return stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: tile = 0 (by estimate) or columns | rows << 16: 128 rows (or 0) x {48,64,96,128,144,192}, 64 x {64,96,128,160,192,256}, 32 x {128,192,256}");
+  StltCtxScope ctx_scope(ctx, (hipStream_t)stream);
+  if (ctx_scope.error()) return ctx_scope.error();
   bool taken = false;
   if (int e = launch_input_grad_gemm16(dy, ld_dy, w, n_out, k_in, r, ldr, dx, ld_dx, M, (hipStream_t)stream, &taken, code)) return e;
   return taken || M == 0 ? 0 : stlt_set_error(STLT_EINVAL, "stlt_input_grad_small: shape not taken by the small-tile kernel");

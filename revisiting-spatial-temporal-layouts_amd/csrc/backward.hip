@@ -900,6 +900,7 @@ int launch_embed_bwd(const float* dx, const int64_t* categories, const float* bo
                      float* g_score_b, float* scratch, hipStream_t s, const int* src_index) {
   StltProfScope ps(STLT_K_EMBED_BWD, s);
   if (!dx || !categories || !boxes || !scratch) return stlt_set_error(STLT_EINVAL, "embed_bwd: null pointer");
+  if (n_tokens < 0 || n_tokens > 0x7fffffff || C <= 0 || d <= 0 || d % 4 != 0) return stlt_set_error(STLT_EINVAL, "embed_bwd: bad shape (tokens %lld, categories %lld, d %lld)", (long long)n_tokens, (long long)C, (long long)d);
   if (n_tokens == 0) return 0;
   int64_t blocks = (n_tokens + 31) / 32;  // short token chunks x channel slices: enough blocks for every CU (round 3: 112 -> 1344 at 64 clips)
   if (blocks > 512) blocks = 512;

@@ -6,38 +6,43 @@
 //   attention block:  out = LN_eps( x + drop( MHA(x, c, c; kpm, causal, prob-dropout) · Woᵀ + bo ) )      c = x for self-attention
 //   feed-forward block: out = LN_eps( x + drop( W2 · drop_inner( act(W1 x + b1) ) + b2 ) )                 act = GELU | ReLU
 // Dropout sites: site0 = attention probabilities / inner dropout, site0 + 1 = the dropout in front of the residual.
-#include <mutex>
-#include "common.h"
+#include "ctx.h"
 
 namespace {
 
 #define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+// A block backward's device memory comes in two buffers.  `keep` holds what the block's QUEUED weight-gradient products read (their dY
+// operands): while a context defers them (stlt_ctx_dw_defer) the caller keeps this buffer — a few rows x d floats — alive until the flush.
+// `work` holds everything that is dead when the call returns its launches (stream-K partial tiles, the attention context gradient, reduction
+// pools, a transposed weight for the split-bf16 products): one buffer per stream serves every block.
 struct BlockScratch {
+  // work
   char* lin;        // stlt_linear_bwd's scratch (stream-K partial tiles + column-sum partials)
   size_t lin_bytes;
-  float *ds, *da, *dctx, *dq, *dkv, *dh, *red;
+  float *dctx, *red;
   float* red_pool;  // 4 x red: the call's partial-row reductions are deferred into one batched launch (StltReduceDefer)
   size_t red_floats;
   float* wt;        // 4 d^2 floats: a transposed weight for the opt-in split-bf16 input-gradient products
-  size_t wt_floats, total;
+  size_t wt_floats, work_total;
+  // keep
+  float *ds, *da, *dq, *dkv, *dh;
+  size_t keep_total;
 };
 
+enum { BLOCK_ATTN = 0, BLOCK_FFN = 1 };
+
 // rows = the larger of the query-side and key-side row counts
-BlockScratch block_scratch(char* base, int64_t rows, int64_t d) {
+BlockScratch block_scratch(char* keep, char* work, int64_t rows, int64_t d, int kind) {
   BlockScratch b;
+  const size_t f = sizeof(float);
   size_t off = 0;
+  char* base = work;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = align256(off + bytes); return p; };
   b.lin_bytes = stlt_linear_bwd_scratch_bytes(4 * d);
   b.lin = take(b.lin_bytes);
-  const size_t f = sizeof(float);
-  b.ds = (float*)take((size_t)rows * d * f);
-  b.da = (float*)take((size_t)rows * d * f);
-  b.dctx = (float*)take((size_t)rows * d * f);
-  b.dq = (float*)take((size_t)rows * 3 * d * f);
-  b.dkv = (float*)take((size_t)rows * 2 * d * f);
-  b.dh = (float*)take((size_t)rows * 4 * d * f);
+  b.dctx = (float*)take(kind == BLOCK_ATTN ? (size_t)rows * d * f : 0);
   int64_t red = ln_bwd_scratch_floats(d);
   if (512 * 4 * d > red) red = 512 * 4 * d;
   b.red = (float*)take((size_t)red * f);
@@ -45,7 +50,15 @@ BlockScratch block_scratch(char* base, int64_t rows, int64_t d) {
   b.red_pool = (float*)take((size_t)red * 4 * f);
   b.wt_floats = (size_t)4 * d * d;
   b.wt = (float*)take(b.wt_floats * f);
-  b.total = off;
+  b.work_total = off;
+  off = 0;
+  base = keep;
+  b.ds = (float*)take((size_t)rows * d * f);
+  b.da = (float*)take((size_t)rows * d * f);
+  b.dq = (float*)take(kind == BLOCK_ATTN ? (size_t)rows * 3 * d * f : 0);
+  b.dkv = (float*)take(kind == BLOCK_ATTN ? (size_t)rows * 2 * d * f : 0);
+  b.dh = (float*)take(kind == BLOCK_FFN ? (size_t)rows * 4 * d * f : 0);
+  b.keep_total = off;
   return b;
 }
 
@@ -71,26 +84,22 @@ struct DwList {
     if (g_w && rows > 0) it[n++] = StltWeightGradItem{dy, n_out, x, k_in, rows, g_w};
   }
 };
-// Collector (stlt_block_dw_defer): while it is on, a block's grouped weight-gradient launch is not made at the end of the block's backward —
-// its products are queued and stlt_block_dw_flush runs the queue as grouped launches of up to 32 products.  A block's own group is 2 - 4
-// products over 2048 / 2112 rows (18 k-steps per workgroup: 0.39 of the MFMA peak, 34 launches + 34 fix-ups per CACNF step); 32 products per
-// launch run at the rate of the STLT sweep's 8-layer groups (0.84).  The caller keeps every operand alive until the flush.
-// ONE collector per process, not per thread: torch's autograd engine runs the block backwards on its own device thread while the trainer
-// switches the collector and flushes it from the thread that called backward() (a thread-local collector queued the products on the
-// engine's thread, where nobody ever flushed them: caught by the GPU suite as all-zero weight gradients in a later test).  One training
-// loop per process uses it at a time (the mutex only keeps the queue consistent).
-constexpr int DW_DEFER_CAP = 512;
-struct DwCollector { StltWeightGradItem it[DW_DEFER_CAP]; int n = 0; bool on = false; std::mutex mu; };
-DwCollector g_dw;
-
+// Collector (stlt_ctx_dw_defer): while the call's context has it on, a block's grouped weight-gradient launch is not made at the end of the
+// block's backward — its products are queued in the context and stlt_ctx_dw_flush runs the queue as grouped launches of up to 32 products.  A
+// block's own group is 2 - 4 products over 2048 / 2112 rows (18 k-steps per workgroup: 0.39 of the MFMA peak, 34 launches + 34 fix-ups per
+// CACNF step); 32 products per launch run at the rate of the STLT sweep's 8-layer groups (0.84).  The caller keeps every operand alive until the
+// flush.  The queue lives in the CONTEXT the block call names, not in a thread or the process: torch's autograd engine runs the block backwards
+// on its own device thread while the trainer switches the collector and flushes it from the thread that called backward() (a thread-local
+// collector queued the products on the engine's thread, where nobody ever flushed them: caught by the GPU suite as all-zero weight gradients in
+// a later test); two training loops in one process hold two contexts and never see each other's products.
 int flush_dw(const DwList& l, const BlockScratch& sc, hipStream_t s) {
   if (l.n == 0) return 0;
   bool group_ok = true;
   for (int i = 0; i < l.n; ++i) group_ok = group_ok && l.it[i].rows % 32 == 0 && l.it[i].rows <= 4096;  // long contractions: separate launches are as fast (train.hip: weight_grad_all)
-  if (group_ok) {
-    std::lock_guard<std::mutex> lk(g_dw.mu);
-    if (g_dw.on && g_dw.n + l.n <= DW_DEFER_CAP) {
-      for (int i = 0; i < l.n; ++i) g_dw.it[g_dw.n++] = l.it[i];
+  if (stlt_ctx* c = group_ok ? stlt_ctx_current() : nullptr) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->dw_on && c->dw_n + l.n <= STLT_DW_DEFER_CAP) {
+      for (int i = 0; i < l.n; ++i) c->dw[c->dw_n++] = l.it[i];
       return 0;
     }
   }
@@ -98,7 +107,7 @@ int flush_dw(const DwList& l, const BlockScratch& sc, hipStream_t s) {
   if (group_ok) return launch_weight_grad_group(l.it, l.n, s);
   for (int i = 0; i < l.n; ++i)
     TRY(stlt_linear_bwd(l.it[i].x, l.it[i].g_w /* unused: dx is null */, l.it[i].dy, l.it[i].rows, l.it[i].n_out, l.it[i].k_in, nullptr, l.it[i].g_w, nullptr,
-                        sc.lin, sc.lin_bytes, (stlt_stream_t)s));
+                        nullptr, sc.lin, sc.lin_bytes, (stlt_stream_t)s));
   return 0;
 }
 
@@ -122,46 +131,53 @@ int linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64
 
 extern "C" {
 
-int stlt_block_dw_defer(int mode) {
-  std::lock_guard<std::mutex> lk(g_dw.mu);
-  if (mode == 1) { g_dw.on = true; return 0; }
-  if (mode == 0) { g_dw.on = false; return 0; }
-  if (mode == -1) { g_dw.on = false; g_dw.n = 0; return 0; }
-  return stlt_set_error(STLT_EINVAL, "stlt_block_dw_defer: mode 1 (collect), 0 (stop collecting; queued products stay) or -1 (stop and discard)");
+int stlt_ctx_dw_defer(stlt_ctx* c, int mode) {
+  if (!stlt_ctx_valid(c)) return stlt_set_error(STLT_EINVAL, "stlt_ctx_dw_defer: not a live context handle");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (mode == 1) { c->dw_on = true; return 0; }
+  if (mode == 0) { c->dw_on = false; return 0; }
+  if (mode == -1) { c->dw_on = false; c->dw_n = 0; return 0; }
+  return stlt_set_error(STLT_EINVAL, "stlt_ctx_dw_defer: mode 1 (collect), 0 (stop collecting; queued products stay) or -1 (stop and discard)");
 }
-int stlt_block_dw_pending(void) { std::lock_guard<std::mutex> lk(g_dw.mu); return g_dw.n; }
-int stlt_block_dw_flush(void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream) {
-  std::lock_guard<std::mutex> lk(g_dw.mu);
-  if (g_dw.n == 0) return 0;
-  if (!gemm_scratch || gemm_scratch_bytes < STLT_GEMM_SCRATCH_BYTES) return stlt_set_error(STLT_EWORKSPACE, "stlt_block_dw_flush: needs stlt_gemm_scratch_bytes() of scratch");
+int stlt_ctx_dw_pending(stlt_ctx* c) {
+  if (!stlt_ctx_valid(c)) return -1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return c->dw_n;
+}
+int stlt_ctx_dw_flush(stlt_ctx* c, void* gemm_scratch, size_t gemm_scratch_bytes, stlt_stream_t stream) {
+  if (!stlt_ctx_valid(c)) return stlt_set_error(STLT_EINVAL, "stlt_ctx_dw_flush: not a live context handle");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->dw_n == 0) return 0;
+  if (!gemm_scratch || gemm_scratch_bytes < STLT_GEMM_SCRATCH_BYTES) return stlt_set_error(STLT_EWORKSPACE, "stlt_ctx_dw_flush: stlt_gemm_scratch_bytes() of scratch are required");
   StltGemmScratch lend(gemm_scratch, STLT_GEMM_SCRATCH_BYTES);
   hipStream_t s = (hipStream_t)stream;
-  // groups in queue order, closed at 32 products or when a product's gradient overlaps one already in the group (a weight used by two
-  // blocks — the fusion models' shared cross-attention, models.py:411-419 — accumulates in launch order, as the per-block launches did)
-  int i0 = 0, rc = 0;
-  while (i0 < g_dw.n && rc == 0) {
+  int rc = 0, i0 = 0;
+  while (i0 < c->dw_n && rc == 0) {
     int i1 = i0;
-    for (; i1 < g_dw.n && i1 - i0 < STLT_GEMM_GROUP_MAX; ++i1) {
-      const float* lo = g_dw.it[i1].g_w;
-      const float* hi = lo + g_dw.it[i1].n_out * g_dw.it[i1].k_in;
-      bool clash = false;
+    for (; i1 < c->dw_n && i1 - i0 < STLT_GEMM_GROUP_MAX; ++i1) {
+      const float* lo = c->dw[i1].g_w;
+      const float* hi = lo + c->dw[i1].n_out * c->dw[i1].k_in;
+      bool clash = false;  // two products into overlapping gradient ranges (a weight shared by two blocks) never share a launch
       for (int j = i0; j < i1 && !clash; ++j) {
-        const float* lo2 = g_dw.it[j].g_w;
-        const float* hi2 = lo2 + g_dw.it[j].n_out * g_dw.it[j].k_in;
+        const float* lo2 = c->dw[j].g_w;
+        const float* hi2 = lo2 + c->dw[j].n_out * c->dw[j].k_in;
         clash = lo < hi2 && lo2 < hi;
       }
       if (clash) break;
     }
-    rc = launch_weight_grad_group(g_dw.it + i0, i1 - i0, s);
+    rc = launch_weight_grad_group(c->dw + i0, i1 - i0, s);
     i0 = i1;
   }
-  g_dw.n = 0;
+  c->dw_n = 0;
   return rc;
 }
-
-size_t stlt_block_scratch_bytes(int64_t rows, int64_t d) {
+size_t stlt_block_keep_bytes(int64_t rows, int64_t d, int kind) {
+  if (rows <= 0 || d <= 0 || (kind != BLOCK_ATTN && kind != BLOCK_FFN)) return 0;
+  return block_scratch(nullptr, nullptr, rows, d, kind).keep_total;
+}
+size_t stlt_block_work_bytes(int64_t rows, int64_t d) {
   if (rows <= 0 || d <= 0) return 0;
-  return block_scratch(nullptr, rows, d).total;
+  return block_scratch(nullptr, nullptr, rows, d, BLOCK_ATTN).work_total;  // the attention block's is the larger layout
 }
 
 int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_t H, float eps, const float* x, int64_t Lq, const float* c,
@@ -194,13 +210,18 @@ int stlt_attn_block_fwd_train(const stlt_attn_block_params* p, int64_t d, int64_
 int stlt_attn_block_bwd_train(const stlt_attn_block_params* p, const stlt_attn_block_params* g, int64_t d, int64_t H, float eps, const float* x,
                               int64_t Lq, const float* c, int64_t Lk, const uint8_t* kpm, int causal, int64_t S, float drop_p, uint64_t seed,
                               uint32_t site0, const float* q, const float* kv, const float* ctx, const float* a, const float* dy, float* dx,
-                              float* dc, void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
-  if (!p || !g || !x || !kpm || !q || !ctx || !a || !dy || !dx || !scratch || (c && !kv)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: null argument");
+                              float* dc, stlt_ctx* tctx, void* keep, size_t keep_bytes, void* work, size_t work_bytes, stlt_stream_t stream) {
+  if (!p || !g || !x || !kpm || !q || !ctx || !a || !dy || !dx || !keep || !work || (c && !kv)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: null argument");
   if (!stlt_heads_ok(d, H)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: need d %% H == 0, a head dim of at most 256 and d %% 4 == 0");
+  if (S < 0 || Lq <= 0 || Lk <= 0 || S > (int64_t)0x7fffffff / (Lq > Lk ? Lq : Lk)) return stlt_set_error(STLT_EINVAL, "stlt_attn_block_bwd_train: bad shape (S %lld, Lq %lld, Lk %lld)", (long long)S, (long long)Lq, (long long)Lk);
+  if (S == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int64_t Mq = S * Lq, Mk = S * Lk;
-  const BlockScratch sc = block_scratch((char*)scratch, Mq > Mk ? Mq : Mk, d);
-  if (scratch_bytes < sc.total) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_block_bwd_train: scratch %zu B < required %zu B", scratch_bytes, sc.total);
+  const BlockScratch sc = block_scratch((char*)keep, (char*)work, Mq > Mk ? Mq : Mk, d, BLOCK_ATTN);
+  if (keep_bytes < sc.keep_total) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_block_bwd_train: keep buffer %zu B < required %zu B", keep_bytes, sc.keep_total);
+  if (work_bytes < sc.work_total) return stlt_set_error(STLT_EWORKSPACE, "stlt_attn_block_bwd_train: work buffer %zu B < required %zu B", work_bytes, sc.work_total);
+  StltCtxScope scope(tctx, s);
+  if (scope.error()) return scope.error();
   const StltDrop dr = stlt_drop_make(drop_p, seed);
   auto G = [&](const float* q_) { return const_cast<float*>(q_); };
   BlockDefer defer(sc, s);
@@ -248,11 +269,16 @@ int stlt_ffn_block_fwd_train(const stlt_ffn_block_params* p, int64_t d, float ep
 
 int stlt_ffn_block_bwd_train(const stlt_ffn_block_params* p, const stlt_ffn_block_params* g, int64_t d, float eps, int act, int inner_dropout,
                              const float* x, int64_t M, float drop_p, uint64_t seed, uint32_t site0, const float* u, const float* h, const float* f,
-                             const float* dy, float* dx, void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
-  if (!p || !g || !x || !h || !f || !dy || !dx || !scratch || (act == STLT_ACT_GELU && !u)) return stlt_set_error(STLT_EINVAL, "stlt_ffn_block_bwd_train: null argument");
+                             const float* dy, float* dx, stlt_ctx* tctx, void* keep, size_t keep_bytes, void* work, size_t work_bytes, stlt_stream_t stream) {
+  if (!p || !g || !x || !h || !f || !dy || !dx || !keep || !work || (act == STLT_ACT_GELU && !u)) return stlt_set_error(STLT_EINVAL, "stlt_ffn_block_bwd_train: null argument");
+  if (M < 0 || M > 0x7fffffff || d <= 0 || d % 4 != 0 || d > 16384) return stlt_set_error(STLT_EINVAL, "stlt_ffn_block_bwd_train: bad shape (M %lld, d %lld)", (long long)M, (long long)d);
+  if (M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const BlockScratch sc = block_scratch((char*)scratch, M, d);
-  if (scratch_bytes < sc.total) return stlt_set_error(STLT_EWORKSPACE, "stlt_ffn_block_bwd_train: scratch %zu B < required %zu B", scratch_bytes, sc.total);
+  const BlockScratch sc = block_scratch((char*)keep, (char*)work, M, d, BLOCK_FFN);
+  if (keep_bytes < sc.keep_total) return stlt_set_error(STLT_EWORKSPACE, "stlt_ffn_block_bwd_train: keep buffer %zu B < required %zu B", keep_bytes, sc.keep_total);
+  if (work_bytes < sc.work_total) return stlt_set_error(STLT_EWORKSPACE, "stlt_ffn_block_bwd_train: work buffer %zu B < required %zu B", work_bytes, sc.work_total);
+  StltCtxScope scope(tctx, s);
+  if (scope.error()) return scope.error();
   const StltDrop dr = stlt_drop_make(drop_p, seed);
   const StltDrop inner = inner_dropout ? dr : StltDrop{0u, 1.0f, 0ull};
   auto G = [&](const float* q_) { return const_cast<float*>(q_); };

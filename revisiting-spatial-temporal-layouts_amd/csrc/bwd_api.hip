@@ -285,12 +285,14 @@ size_t stlt_linear_bwd_scratch_bytes(int64_t N) {
 }
 
 int stlt_linear_bwd(const float* x, const float* w, const float* dy, int64_t M, int64_t N, int64_t K, float* dx, float* dw, float* db,
-                    void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
+                    stlt_ctx* ctx, void* scratch, size_t scratch_bytes, stlt_stream_t stream) {
   if (!x || !w || !dy || !scratch) return stlt_set_error(STLT_EINVAL, "stlt_linear_bwd: null pointer");
   if (M < 0 || N <= 0 || K <= 0) return stlt_set_error(STLT_EINVAL, "stlt_linear_bwd: bad shape");
   if (scratch_bytes < stlt_linear_bwd_scratch_bytes(N)) return stlt_set_error(STLT_EWORKSPACE, "stlt_linear_bwd: scratch %zu B < required %zu B", scratch_bytes, stlt_linear_bwd_scratch_bytes(N));
   if (M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  StltCtxScope ctx_scope(ctx, s);  // dx may be served from the context's transposed copy of w
+  if (ctx_scope.error()) return ctx_scope.error();
   StltGemmScratch lend(scratch, STLT_GEMM_SCRATCH_BYTES);
   float* red = (float*)((char*)scratch + STLT_GEMM_SCRATCH_BYTES);
   const bool mfma_ok = N % 32 == 0 && K % 4 == 0;  // contraction lengths / leading dimensions the MFMA kernel takes

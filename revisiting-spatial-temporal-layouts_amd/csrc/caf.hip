@@ -141,6 +141,10 @@ extern "C" int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_input
   const int64_t B = in->B, T = in->T, N = in->N, d = lp.d, H = lp.H, C = p->feat_channels, S = p->app_tokens, K = lp.n_classes;
   const float eps = lp.ln_eps;
   if (K <= 0 || !in->lengths || !p->fusion_head.fc1_w) return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: heads / lengths missing");
+  if (B <= 0 || T <= 0 || N <= 0 || C <= 0 || S <= 0 || T > 256 || S > 4096 || N > 4096 || B > (int64_t)0x7fffffff / (T * N) || B > (int64_t)0x7fffffff / (S + 1) || K > 65536 ||
+      C > 65536 || p->n_app_layers < 0 || p->n_fusion < 0 || (p->n_app_layers > 0 && !p->app_layers) || (p->n_fusion > 0 && !p->fusion))
+    return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: bad shape (B %lld, T %lld, N %lld, feature channels %lld, appearance tokens %lld, classes %lld)", (long long)B,
+                          (long long)T, (long long)N, (long long)C, (long long)S, (long long)K);
   if (C % 4 != 0 || !stlt_heads_ok(d, H)) return stlt_set_error(STLT_EINVAL, "stlt_caf_forward: feat_channels and hidden_size must be multiples of 4, hidden_size %% heads == 0, head dim <= 256");
   const bool cacnf = p->layout_head.fc1_w != nullptr;
   if (cacnf && (!p->appearance_head.fc1_w || !logits_stlt || !logits_resnet3d || !logits_ensemble))

@@ -210,7 +210,23 @@ int launch_linear_bf16x3(const float* x, int64_t ldx, const float* w, int64_t ld
 // gemm16.hip: the same product on 128 x (16 NT) whole tiles for under-filled launches (no stream-K, no fix-up); *taken = launched
 double stlt_linear_est_us(int64_t M, int64_t N, int64_t K);  // launch-time estimate of launch_linear's duration (us)
 int stlt_gemm16_set_mode(int mode);  // -1 by estimate (default), 0 off, 1 always
-bool stlt_wt_lookup(const float* w, int64_t n_out, int64_t k_in, const float** wt, int64_t* ldwt);  // wt_cache.hip: the current transposed copy of (a row range of) a weight
+// ctx.h / wt_cache.hip: the training-loop context of the public call this thread is inside (nullptr: the call named none).  StltCtxScope makes
+// `c` current for a call launching on `s` and orders `s` behind a refresh of the context's transposed weight copies that is still in flight.
+struct stlt_ctx;
+stlt_ctx* stlt_ctx_current();
+class StltCtxScope {
+ public:
+  StltCtxScope(stlt_ctx* c, hipStream_t s);
+  ~StltCtxScope();
+  StltCtxScope(const StltCtxScope&) = delete;
+  StltCtxScope& operator=(const StltCtxScope&) = delete;
+  int error() const { return err_; }  // != 0: the handle is not a live context (or the wait could not be enqueued)
+ private:
+  stlt_ctx* prev_;
+  int err_ = 0;
+};
+bool stlt_wt_lookup(const float* w, int64_t n_out, int64_t k_in, const float** wt, int64_t* ldwt);  // the current context's transposed copy of (a row range of) a weight
+void stlt_wt_count_hit();  // a product was launched on a copy
 int stlt_gemm16_choice(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw, bool wkn = false);  // 0 = gemm.hip keeps the product, else the tile code (row blocks << 5 | column tiles; wkn: the input-gradient build)
 int stlt_gemm16_tile_from_public(int tile);  // C-ABI tile parameter (columns | rows << 16, rows 0 = 128) -> tile code, 0 = not a tile of the kernel
 int stlt_gemm16_tile_to_public(int code);

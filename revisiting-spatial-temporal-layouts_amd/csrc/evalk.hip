@@ -142,7 +142,8 @@ extern "C" {
 int stlt_eval_store_sigmoid(const float* logits, int64_t ld, const float* labels, int64_t B, int64_t C, double* pred, double* truth,
                             int64_t row0, stlt_stream_t stream) {
   if (!logits || !labels || !pred || !truth) return stlt_set_error(STLT_EINVAL, "stlt_eval_store_sigmoid: null pointer");
-  if (B < 0 || C <= 0 || C > 0x7fffffff || ld < C || row0 < 0) return stlt_set_error(STLT_EINVAL, "stlt_eval_store_sigmoid: bad shape");
+  if (B < 0 || C <= 0 || C > 0x7fffffff || ld < C || row0 < 0 || B > (int64_t)0x7fffffff * 256 / C || row0 > ((int64_t)1 << 40) / C)
+    return stlt_set_error(STLT_EINVAL, "stlt_eval_store_sigmoid: bad shape");
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   StltProfScope ps(STLT_K_MISC, s);

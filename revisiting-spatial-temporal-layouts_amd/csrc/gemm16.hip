@@ -272,7 +272,9 @@ int launch_input_grad_gemm16(const float* dy, int64_t ld_dy, const float* w, int
       StltProfScope ps(STLT_K_GEMM, s);
       stlt_prof_add_flops(2.0 * (double)rows * (double)k_in * (double)n_out);
       *taken = true;
-      return launch16_any(fcode, a, gelu_bwd ? STLT_ACT_GELU_BWD : STLT_ACT_NONE, r != nullptr && !gelu_bwd, false, s);
+      const int rc = launch16_any(fcode, a, gelu_bwd ? STLT_ACT_GELU_BWD : STLT_ACT_NONE, r != nullptr && !gelu_bwd, false, s);
+      if (rc == 0) stlt_wt_count_hit();  // served: the product was launched on the copy
+      return rc;
     }
   }
   int code = force_tile;

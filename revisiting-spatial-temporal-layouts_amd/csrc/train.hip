@@ -11,7 +11,7 @@
 //                f = h·W2ᵀ+b2 ; y = LN2(x1+f)   (y is the next layer's x)
 #include <cstdlib>
 #include <mutex>
-#include "common.h"
+#include "ctx.h"
 
 namespace {
 
@@ -41,7 +41,7 @@ static Tape tape_layout(char* base, int64_t B, int64_t T, int64_t N, int64_t d, 
   Tape t;
   t.tokp = up32(B * T * N); t.btp = up32(B * T); t.bp = up32(B);
   size_t off = 0;
-  auto take = [&](int64_t rows, int64_t width) { float* p = (float*)(base + off); off = align256(off + (size_t)rows * width * sizeof(float)); return p; };
+  auto take = [&](int64_t rows, int64_t width) { float* p = base ? (float*)(base + off) : nullptr; off = align256(off + (size_t)rows * width * sizeof(float)); return p; };
   t.s_embed = take(t.tokp, d);
   auto take_layer = [&](LayerTape& l, int64_t rows) {
     l.x = take(rows, d); l.qkv = take(rows, 3 * d); l.ctx = take(rows, d); l.a = take(rows, d);
@@ -102,7 +102,7 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
   Scratch s;
   const int64_t tokp = up32(B * T * N), btp = up32(B * T), bp = up32(B);
   size_t off = 0;
-  auto take = [&](int64_t floats) { float* p = (float*)(base + off); off = align256(off + (size_t)floats * sizeof(float)); return p; };
+  auto take = [&](int64_t floats) { float* p = base ? (float*)(base + off) : nullptr; off = align256(off + (size_t)floats * sizeof(float)); return p; };
   s.sA = take(tokp * d); s.sB = take(tokp * d); s.sC = take(tokp * d); s.sD = take(tokp * d); s.sE = take(tokp * d); s.sQKV = take(tokp * 3 * d); s.sH = take(tokp * 4 * d);
   s.tA = take(btp * d); s.tB = take(btp * d); s.tC = take(btp * d); s.tD = take(btp * d); s.tE = take(btp * d); s.tQKV = take(btp * 3 * d); s.tH = take(btp * 4 * d);
   s.hA = take(bp * d); s.hB = take(bp * d);
@@ -138,9 +138,8 @@ static Scratch scratch_layout(char* base, int64_t B, int64_t T, int64_t N, int64
 // end of the call.  The products fill the chip while the chain runs its row-wise kernels, fix-ups and under-filled launches.
 // STLT_TRAIN_DW_STREAM=0 keeps everything on the caller's stream (A/B runs); STLT_TRAIN_DW_WG / STLT_TRAIN_DX_WG cap the grids of
 // the side products / the chain's dX products (0 = uncapped) so that both persistent kernels can be resident at once.
-struct DwSideDevice;
 struct DwSide {
-  DwSideDevice* dev = nullptr;  // != nullptr: this sweep holds dev->busy (released by DwSideHold)
+  StltSideDevice* dev = nullptr;  // != nullptr: this sweep holds dev->busy (released by DwSideHold)
   hipStream_t s = nullptr;
   hipEvent_t chain[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
   bool pending[2] = {false, false};
@@ -148,11 +147,6 @@ struct DwSide {
   float* sk = nullptr;
   int flush_no = 0;
 };
-// `busy`: the stream and its four events are one set per device, so a sweep owns them from its first fork to its join — a second host
-// thread's sweep on the same device waits here instead of re-recording an event the first one is about to wait on (DwSideHold).
-struct DwSideDevice { hipStream_t s = nullptr; hipEvent_t ev[4] = {}; bool tried = false, ok = false; std::mutex busy; };
-static DwSideDevice g_dw_side[STLT_MAX_DEVICES];
-
 static int g_dw_side_wanted = -1;  // -1: not read yet (STLT_TRAIN_DW_STREAM, default on); stlt_set_train_side_stream overrides
 static bool dw_side_wanted() {
   if (g_dw_side_wanted < 0) { const char* e = getenv("STLT_TRAIN_DW_STREAM"); g_dw_side_wanted = e ? (atoi(e) != 0) : 1; }
@@ -161,10 +155,12 @@ static bool dw_side_wanted() {
 static int dw_side_wg_cap() { static const int n = [] { const char* e = getenv("STLT_TRAIN_DW_WG"); return e ? atoi(e) : 0; }(); return n; }
 static int dx_chain_wg_cap() { static const int n = [] { const char* e = getenv("STLT_TRAIN_DX_WG"); return e ? atoi(e) : 0; }(); return n; }
 
-static DwSide dw_side_open(const Scratch& sc) {
+// The side stream and its events belong to the call's context (ctx.h: one set per context and device, created at the first sweep that wants it,
+// destroyed with the context); a call that names no context keeps every launch on the caller's stream.
+static DwSide dw_side_open(const Scratch& sc, stlt_ctx* ctx) {
   DwSide sd;
-  if (!dw_side_wanted() || !sc.sk2) return sd;
-  DwSideDevice& dv = g_dw_side[stlt_current_device() & (STLT_MAX_DEVICES - 1)];
+  if (!ctx || !dw_side_wanted() || !sc.sk2) return sd;
+  StltSideDevice& dv = ctx->side[stlt_current_device() & (STLT_MAX_DEVICES - 1)];
   dv.busy.lock();  // also serialises the one creation per device, whichever thread's sweep comes first
   sd.dev = &dv;
   if (!dv.tried) {
@@ -631,12 +627,14 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
 
 int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_inputs* in, const void* tape_mem,
                         size_t tape_bytes, void* scratch_mem, size_t scratch_bytes, const float* dlogits,
-                        float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream) {
+                        float dropout_p, uint64_t dropout_seed, int flags, stlt_ctx* ctx, stlt_stream_t stream) {
   const bool backbone_only = (flags & STLT_FLAG_TRAIN_BACKBONE) != 0;  // `dlogits` is then the gradient of the (B*T, d) backbone output
   TRY(check_train(p, in, !backbone_only));
   if (backbone_only && (flags & STLT_FLAG_SKIP_PADDING)) return stlt_set_error(STLT_EINVAL, "STLT_FLAG_TRAIN_BACKBONE excludes STLT_FLAG_SKIP_PADDING");
   if (!g || !dlogits || !tape_mem || !scratch_mem) return stlt_set_error(STLT_EINVAL, "stlt_train_backward: null argument");
   hipStream_t s = (hipStream_t)stream;
+  StltCtxScope ctx_scope(ctx, s);  // the sweep's input-gradient products may read the context's transposed weight copies
+  if (ctx_scope.error()) return ctx_scope.error();
   const int64_t B = in->B, T = in->T, N = in->N, d = p->d, H = p->H, K = p->n_classes;
   const Tape t = tape_layout((char*)const_cast<void*>(tape_mem), B, T, N, d, p->n_spatial, p->n_temporal);
   if (tape_bytes < t.bytes) return stlt_set_error(STLT_EWORKSPACE, "tape %zu B < required %zu B", tape_bytes, t.bytes);
@@ -683,7 +681,7 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   // cleared every step: at most 31 rows per buffer.
   // (the fusion models' layout branch — STLT_FLAG_TRAIN_BACKBONE — keeps one stream: measured 43.75 against 44.1 ms per CACNF step at 64
   // clips; the block-level calls around the sweep are single-stream and the side launches only delay their small kernels)
-  DwSide side = backbone_only ? DwSide{} : dw_side_open(sc);
+  DwSide side = backbone_only ? DwSide{} : dw_side_open(sc, ctx);
   DwSideHold side_hold(&side, s);
   // weight-gradient queues: the spatial tower flushes per layer over two sets; the temporal tower, when it has few rows, collects up to
   // eight layers (32 products) per grouped launch over eight sets (STLT_TRAIN_DW_GROUP_LAYERS=1: per layer, A/B runs)

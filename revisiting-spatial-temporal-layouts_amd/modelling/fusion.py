@@ -159,8 +159,10 @@ class CrossAttentionFusionBackbone(nn.Module):
         Ah = self._appearance_train(feats)
         B, d = Lh.shape[0], Lh.shape[2]
         # row lengths - 1 of every clip (models.py:455-459) as a gather: its backward is one scatter-add, where advanced indexing
-        # (Lh[arange(B), last]) sorts the indices and runs six launches; the remainder keeps indexing's wrap-around of a negative row
-        last = torch.remainder(batch["lengths"].to(Lh.device) - 1, Lh.shape[1]).view(B, 1, 1).expand(B, 1, d)
+        # (Lh[arange(B), last]) sorts the indices and runs six launches.  Only a NEGATIVE row wraps around, as indexing wraps it; a row beyond
+        # the last frame stays out of range and the gather's bounds check fails loudly, as the reference's indexing raises IndexError
+        last = batch["lengths"].to(Lh.device) - 1
+        last = torch.where(last < 0, last + Lh.shape[1], last).view(B, 1, 1).expand(B, 1, d)
         lay_state, app_state = Lh.gather(1, last).squeeze(1), Ah[:, 0]
         kpm = batch["src_key_padding_mask_frames"]
         p = self.config.hidden_dropout_prob

@@ -361,6 +361,14 @@ class Stlt(nn.Module):
         self.prediction_head = ClassificationHead(config)
         self.logit_names = ("stlt",)
 
+    def _own_context(self):
+        """The module's own training context (include/stlt_hip.h: stlt_ctx), made at the first autograd backward that runs outside a
+        Trainer step: it owns the side stream of that sweep's weight-gradient products.  Not a parameter, not in the state dict."""
+        c = self.__dict__.get("_ctx_own")
+        if c is None or c.handle is None:
+            c = self.__dict__["_ctx_own"] = ops.TrainContext()
+        return c
+
     def train(self, mode: bool = True):
         super().train(mode)
         if self.config.load_backbone_path and self.config.freeze_backbone:
@@ -471,10 +479,14 @@ class _StltTrainFn(torch.autograd.Function):
         model._last_flat_grad = flat
         model._flat_layout = layout
 
+        # the training context the sweep names: the trainer's while its step runs this backward (its transposed weight copies, its side
+        # stream), else one the module owns for the side stream of plain autograd backwards
+        tctx = getattr(model, "_train_context", None) or model._own_context()
+
         def run(extra_flags):
             L.check(lib.stlt_train_backward(C.byref(p), C.byref(g), C.byref(inp), tape.data_ptr(), tape.numel(),
                                             scratch.data_ptr(), scratch.numel(), dl.data_ptr(), ctx.drop[0], ctx.drop[1],
-                                            ctx.drop[2] | extra_flags, torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
+                                            ctx.drop[2] | extra_flags, tctx.handle, torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
 
         sync = getattr(model, "_grad_sync", None)  # data-parallel hook: sync(flat, lo, hi) may start reducing flat[lo:hi]
         with torch.cuda.device(device):
@@ -573,8 +585,8 @@ class _BackboneTrainFn(torch.autograd.Function):
         dl = dout.contiguous().float()
         with torch.cuda.device(device):
             L.check(lib.stlt_train_backward(C.byref(p), C.byref(g), C.byref(inp), tape.data_ptr(), tape.numel(), scratch.data_ptr(), scratch.numel(),
-                                            dl.data_ptr(), ctx.drop[0], ctx.drop[1], L.FLAG_TRAIN_BACKBONE, torch.cuda.current_stream().cuda_stream),
-                    "stlt_train_backward")
+                                            dl.data_ptr(), ctx.drop[0], ctx.drop[1], L.FLAG_TRAIN_BACKBONE, ops._ctx_handle(ops.context_of(ctx.params)),
+                                            torch.cuda.current_stream().cuda_stream), "stlt_train_backward")
         return (None, None) + tuple(views.get(id(prm)) for prm in ctx.params)
 
 

@@ -104,15 +104,18 @@ def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
-def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual: Optional[torch.Tensor] = None, tile_rows: int = 128):
-    """dx (M, k_in) = dy (M, n_out) · w (n_out, k_in) (+ residual) on the small-tile kernel, the weight read as it lies
-    (include/stlt_hip.h: stlt_input_grad_small)."""
+def input_grad_small(dy: torch.Tensor, w: torch.Tensor, tile_cols: int, residual: Optional[torch.Tensor] = None, tile_rows: int = 128,
+                     context: Optional["TrainContext"] = None):
+    """dx (M, k_in) = dy (M, n_out) · w (n_out, k_in) (+ residual) on the small-tile kernel (include/stlt_hip.h: stlt_input_grad_small):
+    on the tile given, the weight read as it lies; tile_cols = 0 routes by the launch-time estimate and reads `context`'s transposed copy
+    of w when it holds a current one."""
     lib = L.load()
     _chk(dy, torch.float32, "dy"); _chk(w, torch.float32, "w")
     n_out, k_in = w.shape
     M = dy.numel() // n_out
     dx = torch.empty(*dy.shape[:-1], k_in, device=dy.device, dtype=torch.float32)
-    L.check(lib.stlt_input_grad_small(_p(dy), n_out, _p(w), n_out, k_in, _p(residual), k_in, _p(dx), k_in, M, small_tile(tile_cols, tile_rows), _stream()),
+    tile = 0 if tile_cols == 0 else small_tile(tile_cols, tile_rows)
+    L.check(lib.stlt_input_grad_small(_p(dy), n_out, _p(w), n_out, k_in, _p(residual), k_in, _p(dx), k_in, M, tile, _ctx_handle(context), _stream()),
             "stlt_input_grad_small")
     return dx
 
@@ -352,10 +355,13 @@ def prof_take_gemm_flops() -> float:
 _SCRATCH = {}
 
 
-def _scratch(nbytes: int, device) -> torch.Tensor:
-    buf = _SCRATCH.get(device)
+def _scratch(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    """Grow-only scratch lent to a backward call: one buffer per (device, current stream, slot) — kernels of one stream run in order, so
+    consecutive calls may share it; two streams of one device (two training loops on two host threads) must not."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, slot)
+    buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
-        _SCRATCH[device] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return buf
 
 
@@ -391,8 +397,8 @@ class LinearFn(torch.autograd.Function):
         (dw, db), grads = grad_targets((w, ctx.bias), (ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]))
         nbytes = int(lib.stlt_linear_bwd_scratch_bytes(N))
         sc = _scratch(nbytes, x.device)
-        L.check(lib.stlt_linear_bwd(_p(x), _p(w), _p(dy), M, N, K, _p(dx), _p(dw), _p(db), sc.data_ptr(), sc.numel(), _stream()),
-                "stlt_linear_bwd")
+        L.check(lib.stlt_linear_bwd(_p(x), _p(w), _p(dy), M, N, K, _p(dx), _p(dw), _p(db), _ctx_handle(context_of((w,))), sc.data_ptr(), sc.numel(),
+                                    _stream()), "stlt_linear_bwd")
         return dx, grads[0], grads[1], None
 
 
@@ -542,50 +548,110 @@ def _sk_scratch(device) -> torch.Tensor:
 
 
 
-_DW_DEFER = {"on": False, "keep": []}
+class TrainContext:
+    """A training loop's handle into the library (include/stlt_hip.h: stlt_ctx): what the loop leaves inside it between calls — the
+    transposed weight copies of the step in progress, the queue of deferred block weight gradients, the side stream + events of its
+    reverse sweeps — belongs to this object and to nothing else in the process.  train.Trainer owns one and the backward Functions of the
+    models it trains pass it along (context_of); a backward outside a trainer step passes none and gets none of the three."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        L.check(L.load().stlt_ctx_create(C.byref(h)), "stlt_ctx_create")
+        self.handle = h.value
+        self.defer_on = False  # inside deferred_block_weight_grads(self)
+        self.keep = []         # what the queued products read: the blocks' keep buffers and forward activations, until the flush
+
+    def close(self):
+        if getattr(self, "handle", None):
+            try:
+                L.load().stlt_ctx_destroy(self.handle)
+            finally:
+                self.handle = None
+                self.keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo):  # a copied module gets a context of its own, never a second owner of this handle
+        return TrainContext()
+
+    def __reduce__(self):
+        return (TrainContext, ())
+
+    def wt_hits(self) -> int:
+        return int(L.load().stlt_ctx_wt_hits(self.handle))
+
+    def dw_pending(self) -> int:
+        return int(L.load().stlt_ctx_dw_pending(self.handle))
+
+
+def _ctx_handle(context: Optional[TrainContext]):
+    return None if context is None else context.handle
+
+
+def context_of(ws) -> Optional[TrainContext]:
+    """The training context a backward call should name: that of the trainer whose step is running its backward over these parameters right
+    now (BoundFlatGrads.accumulating), else None — a plain autograd backward never reads a trainer's weight copies or queues into its flush."""
+    for w in ws:
+        bound = getattr(w, "_stlt_bound", None)
+        if bound is not None and bound.accumulating and bound.context is not None:
+            return bound.context
+    return None
 
 
 class deferred_block_weight_grads:
     """Context manager around ONE backward pass of a model built from the block Functions (AttnBlockFn / FfnBlockFn), on the current
-    stream: the blocks queue their weight-gradient products instead of launching 2 - 4 of them per block, and the exit runs the queue as
-    grouped launches of up to 32 products (include/stlt_hip.h: stlt_block_dw_defer / _flush).  Only blocks whose parameter gradients are
-    accumulated in place (train.Trainer's bound flat buffer: grad_targets) take part; their scratch buffers and forward activations are
-    kept alive until the flush.  The gradients are complete when the `with` block is left."""
+    stream: the blocks that name `context` queue their weight-gradient products in it instead of launching 2 - 4 of them per block, and the
+    exit runs the queue as grouped launches of up to 32 products (include/stlt_hip.h: stlt_ctx_dw_defer / _flush).  Only blocks whose
+    parameter gradients are accumulated in place (train.Trainer's bound flat buffer: grad_targets) take part; their keep buffers (the
+    gradients the queued products read: 5 - 7 rows x d floats per block, 34 blocks x ~45 MB at 64 clips of CACNF) and forward activations
+    stay alive until the flush.  The gradients are complete when the `with` block is left."""
+
+    def __init__(self, context: TrainContext):
+        self.context = context
 
     def __enter__(self):
         lib = L.load()
-        L.check(lib.stlt_block_dw_defer(-1), "stlt_block_dw_defer")
-        L.check(lib.stlt_block_dw_defer(1), "stlt_block_dw_defer")
-        _DW_DEFER["on"] = True
-        _DW_DEFER["keep"] = []
+        L.check(lib.stlt_ctx_dw_defer(self.context.handle, -1), "stlt_ctx_dw_defer")
+        L.check(lib.stlt_ctx_dw_defer(self.context.handle, 1), "stlt_ctx_dw_defer")
+        self.context.defer_on = True
+        self.context.keep = []
         return self
 
     def __exit__(self, exc_type, exc, tb):
         lib = L.load()
-        _DW_DEFER["on"] = False
+        c = self.context
+        c.defer_on = False
         try:
-            if exc_type is None and lib.stlt_block_dw_pending() > 0:
+            if exc_type is None and lib.stlt_ctx_dw_pending(c.handle) > 0:
                 dev = torch.device("cuda", torch.cuda.current_device())
                 sk = _sk_scratch(dev)
-                L.check(lib.stlt_block_dw_flush(sk.data_ptr(), sk.numel(), _stream()), "stlt_block_dw_flush")
+                L.check(lib.stlt_ctx_dw_flush(c.handle, sk.data_ptr(), sk.numel(), _stream()), "stlt_ctx_dw_flush")
         finally:
-            lib.stlt_block_dw_defer(-1)
-            _DW_DEFER["keep"] = []  # torch's allocator recycles by the current stream: the flush's launches are enqueued on it
+            lib.stlt_ctx_dw_defer(c.handle, -1)
+            c.keep = []  # torch's allocator recycles by the current stream: the flush's launches are enqueued on it
         return False
 
 
-def _block_scratch(nbytes: int, device, in_place: bool, keep) -> torch.Tensor:
-    """Scratch of a block backward: the shared per-device buffer, or — while weight gradients are deferred and this block's go in place —
-    a buffer of its own that lives (with the activations in `keep`) until the flush."""
+def _block_buffers(kind: int, rows: int, d: int, device, context: Optional[TrainContext], in_place: bool, keep):
+    """(keep, work) buffers of a block backward (include/stlt_hip.h: stlt_block_keep_bytes / _work_bytes).  `work` is the shared per-stream
+    buffer.  `keep` holds the gradients the block's weight-gradient products read: the shared per-stream buffer too, unless the call's
+    context is deferring them and this block's go in place — then a buffer of its own that lives (with the activations in `keep`) until
+    the flush."""
     lib = L.load()
-    if _DW_DEFER["on"] and in_place:
-        L.check(lib.stlt_block_dw_defer(1), "stlt_block_dw_defer")
-        sc = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _DW_DEFER["keep"].append((sc,) + tuple(keep))
-        return sc
-    if _DW_DEFER["on"]:
-        L.check(lib.stlt_block_dw_defer(0), "stlt_block_dw_defer")  # this block launches its own products (temporaries handed back to autograd)
-    return _scratch(nbytes, device)
+    work = _scratch(int(lib.stlt_block_work_bytes(rows, d)), device, 1)
+    nkeep = int(lib.stlt_block_keep_bytes(rows, d, kind))
+    if context is not None and context.defer_on:
+        if in_place:
+            L.check(lib.stlt_ctx_dw_defer(context.handle, 1), "stlt_ctx_dw_defer")
+            kb = torch.empty(nkeep, dtype=torch.uint8, device=device)
+            context.keep.append((kb,) + tuple(keep))
+            return kb, work
+        L.check(lib.stlt_ctx_dw_defer(context.handle, 0), "stlt_ctx_dw_defer")  # this block launches its own products (temporaries handed back to autograd)
+    return _scratch(nkeep, device, 2), work
 
 
 def _block_dropout(p: float):
@@ -675,10 +741,11 @@ class AttnBlockFn(torch.autograd.Function):
         params = L.AttnBlockParams(*[_p(t) for t in ws])
         gstruct = L.AttnBlockParams(*[_p(t) for t in targets])
         in_place = all(r is None for r, need in zip(grads, ctx.needs_input_grad[7:13]) if need)
-        sc = _block_scratch(int(lib.stlt_block_scratch_bytes(S * max(Lq, Lk), d)), x.device, in_place, (x, c, att, a, q, kv))
+        tctx = context_of(ws)
+        kb, wb = _block_buffers(0, S * max(Lq, Lk), d, x.device, tctx, in_place, (x, c, att, a, q, kv))
         L.check(lib.stlt_attn_block_bwd_train(C.byref(params), C.byref(gstruct), d, heads, eps, _p(x), Lq, _p(c), Lk, _p(kpm8), int(causal), S, p, seed,
-                                              site, _p(q), _p(kv), _p(att), _p(a), _p(dy), _p(dx), _p(dc), sc.data_ptr(), sc.numel(), _stream()),
-                "stlt_attn_block_bwd_train")
+                                              site, _p(q), _p(kv), _p(att), _p(a), _p(dy), _p(dx), _p(dc), _ctx_handle(tctx), kb.data_ptr(), kb.numel(),
+                                              wb.data_ptr(), wb.numel(), _stream()), "stlt_attn_block_bwd_train")
         return (dx, dc, None, None, None, None, None, *grads)
 
 
@@ -720,9 +787,11 @@ class FfnBlockFn(torch.autograd.Function):
         params = L.FfnBlockParams(*[_p(t) for t in ws])
         gstruct = L.FfnBlockParams(*[_p(t) for t in targets])
         in_place = all(r is None for r, need in zip(grads, ctx.needs_input_grad[5:11]) if need)
-        sc = _block_scratch(int(lib.stlt_block_scratch_bytes(M, d)), x.device, in_place, (x, u, h, f))
+        tctx = context_of(ws)
+        kb, wb = _block_buffers(1, M, d, x.device, tctx, in_place, (x, u, h, f))
         L.check(lib.stlt_ffn_block_bwd_train(C.byref(params), C.byref(gstruct), d, eps, act, int(inner), _p(x), M, p, seed, site, _p(u), _p(h), _p(f),
-                                             _p(dy), _p(dx), sc.data_ptr(), sc.numel(), _stream()), "stlt_ffn_block_bwd_train")
+                                             _p(dy), _p(dx), _ctx_handle(tctx), kb.data_ptr(), kb.numel(), wb.data_ptr(), wb.numel(), _stream()),
+                "stlt_ffn_block_bwd_train")
         return (dx, None, None, None, None, *grads)
 
 

@@ -208,7 +208,8 @@ class BoundFlatGrads:
     Parameters that received no gradient in a step are left out of that step's layout — torch.optim.AdamW skips
     `p.grad is None` the same way (the dead `encoder_layer` copy, unused `score_embeddings`, frozen weights)."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, context=None):
+        self.context = context  # the trainer's ops.TrainContext: what the native backwards of these parameters name while `accumulating`
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.layout_all, off = [], 0
         for p in self.params:
@@ -257,26 +258,30 @@ class BoundFlatGrads:
 
 class TransposedWeights:
     """Transposed copies of the model's Linear weights for the input-gradient products of a training step (include/stlt_hip.h:
-    stlt_wt_refresh; csrc/wt_cache.hip): dX = dY·W reads W as it lies 13 - 17 % slower than a forward product reads Wt.  One flat buffer
-    holds every copy; `refresh()` rewrites them from the weights as they are NOW and makes them current, `clear()` withdraws them.  The
-    Trainer refreshes at the start of every step (after whatever changed the weights: its own optimiser, a checkpoint load, an EMA swap)
+    stlt_ctx_wt_refresh; csrc/wt_cache.hip): dX = dY·W reads W as it lies 13 - 17 % slower than a forward product reads Wt.  One flat buffer
+    holds every copy; `refresh()` rewrites them from the weights as they are NOW and makes them current IN THE TRAINER'S CONTEXT, `clear()`
+    withdraws them.  Only backward calls that name that context can read a copy, and the library orders each such call's stream behind the
+    transposes (an event recorded at the end of the refresh), so the copies are written on a stream of their own beside the step's forward.
+    The Trainer refreshes at the start of every step (after whatever changed the weights: its own optimiser, a checkpoint load, an EMA swap)
     and clears at the end, so nothing outside a step can read a stale copy.  STLT_TRAIN_WT=0 switches it off."""
 
     MIN_ELEMENTS = 65536  # the 768 x 768 projections and up; embedding tables and the 174-class heads stay as they are
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, context):
+        self.context = context
+        first = next((p for p in model.parameters() if p.is_cuda), None)
+        dev = first.device if first is not None else None
         self.params = [p for p in model.parameters()
-                       if p.requires_grad and p.is_cuda and p.dim() == 2 and p.dtype == torch.float32 and p.numel() >= self.MIN_ELEMENTS
-                       and p.shape[0] % 32 == 0 and p.shape[1] % 4 == 0 and p.is_contiguous()]
+                       if p.requires_grad and p.is_cuda and p.device == dev and p.dim() == 2 and p.dtype == torch.float32
+                       and p.numel() >= self.MIN_ELEMENTS and p.shape[0] % 32 == 0 and p.shape[1] % 4 == 0 and p.is_contiguous()]
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
             off += p.numel()
-        self.flat = torch.empty(off, device=self.params[0].device, dtype=torch.float32) if self.params else None
+        self.flat = torch.empty(off, device=dev, dtype=torch.float32) if self.params else None
         self.entries = (L.WtEntry * max(1, len(self.params)))()
         self._sentinel = None
         self._side = None       # the copies are written beside the step's forward (only its backward reads them): a stream of their own
-        self._pending = False
 
     def refresh(self) -> None:
         if not self.params:
@@ -291,22 +296,17 @@ class TransposedWeights:
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
         # behind everything the caller's stream holds (the update that produced these weights, the last step's products that read the old
-        # copies); the step's backward joins before its first input-gradient product
+        # copies); the consumers wait for the refresh's event inside the library
         self._side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.device(dev):
-            L.check(L.load().stlt_wt_refresh(self.entries, len(self.params), self._side.cuda_stream), "stlt_wt_refresh")
-        self._pending = True
-
-    def join(self) -> None:
-        """The caller's stream waits for the copies (call before the step's backward)."""
-        if self._pending:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
-            self._pending = False
+            L.check(L.load().stlt_ctx_wt_refresh(self.context.handle, self.entries, len(self.params), self._side.cuda_stream), "stlt_ctx_wt_refresh")
 
     def clear(self) -> None:
         if self.params:
-            self.join()
-            L.load().stlt_wt_clear()
+            # the caller's stream joins the copy stream: the flat buffer may be rewritten by the next refresh only after this step's readers,
+            # and torch's allocator sees both streams ordered
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+            L.load().stlt_ctx_wt_clear(self.context.handle)
 
 
 def _train_wt_on() -> bool:
@@ -326,12 +326,15 @@ class Trainer:
         self.fused = fused_optimizer
         # Stlt fills its own flat buffer in the native reverse sweep; any other model (the fusion models) gets its .grad
         # tensors bound to one
-        self.bound = BoundFlatGrads(model) if (fused_optimizer and not hasattr(model, "_grad_params")) else None
+        # what this loop leaves inside the library between calls (transposed weight copies, deferred block weight gradients, the side stream
+        # of its reverse sweeps) hangs off its own handle: two trainers in one process never see each other's
+        self.context = ops.TrainContext() if on_gpu else None
+        self.bound = BoundFlatGrads(model, self.context) if (fused_optimizer and not hasattr(model, "_grad_params")) else None
         opt = FusedAdamW if fused_optimizer else torch.optim.AdamW  # same defaults (betas 0.9/0.999, eps 1e-8)
         self.optimizer = opt(add_weight_decay(model, weight_decay), lr=learning_rate)
         self.scheduler = linear_schedule_with_warmup(self.optimizer, warmup_steps, total_steps)
         self._comm_stream = None
-        self.transposed = TransposedWeights(model) if (fused_optimizer and on_gpu and _train_wt_on()) else None
+        self.transposed = TransposedWeights(model, self.context) if (fused_optimizer and on_gpu and _train_wt_on()) else None
 
     def _sync_slice(self, flat: torch.Tensor, lo: int, hi: int) -> None:
         """Called by the native backward when flat[lo:hi] is final: average it over the ranks on a side stream, so the
@@ -356,10 +359,6 @@ class Trainer:
         finally:
             self.transposed.clear()
 
-    def _join_transposed(self) -> None:
-        if self.transposed is not None:
-            self.transposed.join()
-
     def _step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
         self.model.train(True)
         if self.bound is not None:
@@ -367,6 +366,7 @@ class Trainer:
         self.optimizer.zero_grad()
         self.model._flat_grads_only = self.fused
         self.model._grad_sync = self._sync_slice if (self.fused and self.world > 1) else None
+        self.model._train_context = self.context  # the reverse sweep names this trainer's context (weight copies, side stream)
         logits = self.model(batch)
         if self.fused:  # loss + dlogits in one pass per head, then straight into the native reverse sweep
             loss, heads = 0.0, list(logits.values())
@@ -375,11 +375,9 @@ class Trainer:
                 l, g = fused_criterion(v, batch["labels"], self.dataset_name, 1.0 / len(heads))
                 loss = loss + l
                 grads.append(g)
-            self._join_transposed()
             torch.autograd.backward(heads, grads)
         else:
             loss = criterion(logits, batch["labels"], self.dataset_name)
-            self._join_transposed()
             loss.backward()
         if self.fused:
             # the reverse sweep left every gradient in one flat buffer: all-reduce it in place, then norm + clip +
@@ -397,6 +395,7 @@ class Trainer:
         # ordinary per-parameter .grad tensors again
         self.model._flat_grads_only = False
         self.model._grad_sync = None
+        self.model._train_context = None
         return {"loss": loss.detach(), "grad_norm": grad_norm.detach()}
 
     def _step_bound(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
@@ -410,13 +409,12 @@ class Trainer:
             l, g = fused_criterion(v, batch["labels"], self.dataset_name, 1.0 / len(heads))
             loss = loss + l
             grads.append(g)
-        self._join_transposed()
         self.bound.accumulating = True
         try:
             # the blocks' weight-gradient products (2 - 4 per block, 34 blocks in CACNF) are queued and run as a few grouped launches when
             # the backward pass is through (ops.deferred_block_weight_grads; STLT_BLOCK_DW_DEFER=0: per block, as before)
             if _BLOCK_DW_DEFER:
-                with ops.deferred_block_weight_grads():
+                with ops.deferred_block_weight_grads(self.context):
                     torch.autograd.backward(heads, grads)
             else:
                 torch.autograd.backward(heads, grads)

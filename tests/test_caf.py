@@ -286,7 +286,7 @@ def test_trainer_on_a_fusion_model_matches_the_stock_loop(pkg):
 @pytest.mark.gpu
 def test_deferred_block_weight_gradients_match_the_per_block_launches(pkg):
     """Round 5: inside a Trainer step the fusion models' blocks queue their weight-gradient products and the end of the backward pass runs
-    them as grouped launches of up to 32 products (ops.deferred_block_weight_grads; stlt_block_dw_defer / _flush).  Same gradients as the
+    them as grouped launches of up to 32 products (ops.deferred_block_weight_grads; stlt_ctx_dw_defer / _flush on the trainer's context).  Same gradients as the
     per-block launches to rounding (the grouping changes the stream-K split, i.e. the summation order), products are really queued, a
     weight shared by two blocks (the fusion models' cross-attention, models.py:411-419) accumulates both contributions, and the queue is
     empty afterwards."""
@@ -312,21 +312,21 @@ def test_deferred_block_weight_gradients_match_the_per_block_launches(pkg):
         tr.bound.accumulating = True
         try:
             if defer:
-                with pkg.ops.deferred_block_weight_grads():
+                with pkg.ops.deferred_block_weight_grads(tr.context):
                     if defer == "here":
                         torch.autograd.backward(heads, grads)
                     else:
-                        # torch's autograd engine runs the backward nodes on a thread of its own choosing; the queue is one per process
-                        # (a thread-local one was never flushed when the nodes ran elsewhere: round-5 regression)
+                        # torch's autograd engine runs the backward nodes on a thread of its own choosing; the queue follows the context
+                        # handle every block call names (a thread-local one was never flushed when the nodes ran elsewhere: round-5 regression)
                         th = threading.Thread(target=lambda: torch.autograd.backward(heads, grads))
                         th.start()
                         th.join()
-                    queued.append(lib.stlt_block_dw_pending())
+                    queued.append(tr.context.dw_pending())
             else:
                 torch.autograd.backward(heads, grads)
         finally:
             tr.bound.accumulating = False
-        assert lib.stlt_block_dw_pending() == 0
+        assert tr.context.dw_pending() == 0
         torch.cuda.synchronize()
         flats.append(tr.bound.flat.clone())
     assert queued[0] >= 8 and queued[1] == queued[0], queued
@@ -334,4 +334,5 @@ def test_deferred_block_weight_gradients_match_the_per_block_launches(pkg):
     assert torch.isfinite(a).all() and a.abs().max().item() > 0
     assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
     assert (a2 - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
-    assert lib.stlt_block_dw_defer(7) != 0 and lib.stlt_block_dw_defer(-1) == 0
+    assert lib.stlt_ctx_dw_defer(tr.context.handle, 7) != 0 and lib.stlt_ctx_dw_defer(tr.context.handle, -1) == 0
+    assert lib.stlt_ctx_dw_defer(None, 1) != 0 and lib.stlt_ctx_dw_pending(None) == -1

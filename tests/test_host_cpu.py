@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
     nm = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
     assert exported == declared, f"exported but not declared: {sorted(exported - declared)}; declared but not exported: {sorted(declared - exported)}"
-    assert lib.stlt_version() == 100
+    assert lib.stlt_version() == 110
     # workspace sizing is pure host arithmetic: callable without a GPU
     a = pkg.ops.workspace_bytes(8, 32, 7, 768, 174)
     b = pkg.ops.workspace_bytes(16, 32, 7, 768, 174)
@@ -190,7 +190,7 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
     ver, ws, sk, rc = out[0].split()
     pkg = importlib.import_module(PKG_NAME)
-    assert int(ver) == 100 and int(ws) == pkg.ops.workspace_bytes(8, 32, 7, 768, 174) and int(sk) == 64 * 1024 * 1024
+    assert int(ver) == 110 and int(ws) == pkg.ops.workspace_bytes(8, 32, 7, 768, 174) and int(sk) == 64 * 1024 * 1024
     assert int(rc) == -1 and "null" in out[1]  # argument error reported through the C-ABI, message available
 
 

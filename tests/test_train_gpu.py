@@ -545,11 +545,11 @@ def test_fused_criterion_ignores_label_minus_100_like_torch(pkg):
 
 
 def test_transposed_weight_copies_serve_the_input_gradient_products(pkg):
-    """csrc/wt_cache.hip: stlt_wt_refresh writes wt[k][n] = w[n][k] for every registered weight (ragged 64 x 64 tiles included) and, until
-    stlt_wt_clear, the input-gradient products that route to the small tiles read the copy — a row range of a packed weight included
-    (the cross-attention blocks' k | v rows of in_proj_weight).  Same dx as with the weight read as it lies (summation order aside),
-    and as torch in fp64."""
-    import ctypes as C
+    """csrc/wt_cache.hip: stlt_ctx_wt_refresh writes wt[k][n] = w[n][k] for every registered weight (ragged 64 x 64 tiles included) and,
+    until stlt_ctx_wt_clear, the input-gradient products of calls that NAME THAT CONTEXT and route to the small tiles read the copy — a row
+    range of a packed weight included (the cross-attention blocks' k | v rows of in_proj_weight).  Same dx as with the weight read as it
+    lies (summation order aside), and as torch in fp64.  A call naming another context, or none, never reads a copy; a row range that
+    starts off a multiple of four rows is not served (its copy would not be 16-byte aligned); hits count launched products."""
     lib = pkg._lib.load()
     g = torch.Generator().manual_seed(3)
     shapes = [(768, 768), (2304, 768), (96, 100), (3072, 768), (160, 36)]
@@ -558,37 +558,51 @@ def test_transposed_weight_copies_serve_the_input_gradient_products(pkg):
     ent = (pkg._lib.WtEntry * len(ws))()
     for e, w, t in zip(ent, ws, wts):
         e.w, e.wt, e.n_out, e.k_in = w.data_ptr(), t.data_ptr(), w.shape[0], w.shape[1]
-    stream = torch.cuda.current_stream().cuda_stream
+    tctx, other = pkg.ops.TrainContext(), pkg.ops.TrainContext()
+    side = torch.cuda.Stream()
     try:
-        pkg._lib.check(lib.stlt_wt_refresh(ent, len(ws), stream), "stlt_wt_refresh")
-        for w, t in zip(ws, wts):
-            assert torch.equal(t, w.t().contiguous())
+        # the refresh runs on a stream of its own; the consumers below run on the current stream WITHOUT joining it: the library orders
+        # every call that names the context behind the refresh's event
+        side.wait_stream(torch.cuda.current_stream())
+        pkg._lib.check(lib.stlt_ctx_wt_refresh(tctx.handle, ent, len(ws), side.cuda_stream), "stlt_ctx_wt_refresh")
         M = 2048
         x = torch.randn(M, 768, generator=g).to(DEV)
         cases = [(ws[0], 768), (ws[1][768:], 1536), (ws[3], 3072)]  # whole weights and the k | v rows of the packed in-projection
-        hits0 = lib.stlt_wt_hits()
         with_copy = []
         for w, n_out in cases:
-            xr = x.clone().requires_grad_(True)
             dy = torch.randn(M, n_out, generator=torch.Generator().manual_seed(n_out)).to(DEV)
-            pkg.ops.LinearFn.apply(xr, w, None).backward(dy)
-            with_copy.append((xr.grad.clone(), dy))
-        assert lib.stlt_wt_hits() - hits0 >= len(cases)
-        lib.stlt_wt_clear()
-        hits1 = lib.stlt_wt_hits()
+            with_copy.append((pkg.ops.input_grad_small(dy, w, 0, context=tctx), dy))
+        assert tctx.wt_hits() == len(cases)
+        torch.cuda.current_stream().wait_stream(side)
+        for w, t in zip(ws, wts):
+            assert torch.equal(t, w.t().contiguous())
+        # another context, no context, a plain autograd backward, and a row range starting at row 770 (770 % 4 != 0): nothing reads a copy
+        dy = with_copy[0][1]
+        d_other = pkg.ops.input_grad_small(dy, ws[0], 0, context=other)
+        d_none = pkg.ops.input_grad_small(dy, ws[0], 0)
+        xr = x.clone().requires_grad_(True)
+        pkg.ops.LinearFn.apply(xr, ws[0], None).backward(dy)
+        dy_odd = torch.randn(M, 1504, generator=torch.Generator().manual_seed(9)).to(DEV)
+        d_odd = pkg.ops.input_grad_small(dy_odd, ws[1][770:770 + 1504], 0, context=tctx)
+        assert tctx.wt_hits() == len(cases) and other.wt_hits() == 0
+        assert torch.equal(d_other, d_none) and torch.equal(xr.grad, d_none)
+        assert (d_odd.double() - dy_odd.double() @ ws[1][770:770 + 1504].double()).abs().max().item() <= 1e-4
+        pkg._lib.check(lib.stlt_ctx_wt_clear(tctx.handle), "stlt_ctx_wt_clear")
         for (dx_copy, dy), (w, n_out) in zip(with_copy, cases):
-            xr = x.clone().requires_grad_(True)
-            pkg.ops.LinearFn.apply(xr, w, None).backward(dy)
+            dx_plain = pkg.ops.input_grad_small(dy, w, 0, context=tctx)  # withdrawn: the weights are read as they lie
             ref = dy.double() @ w.double()
             scale = ref.abs().max().item()
-            assert (xr.grad.double() - ref).abs().max().item() / scale <= 1e-5  # fp32 accumulation over up to 3072 terms
+            assert (dx_plain.double() - ref).abs().max().item() / scale <= 1e-5  # fp32 accumulation over up to 3072 terms
             assert (dx_copy.double() - ref).abs().max().item() / scale <= 1e-5
-        assert lib.stlt_wt_hits() == hits1  # withdrawn: the weights are read as they lie
+        assert tctx.wt_hits() == len(cases)
         bad = (pkg._lib.WtEntry * 1)()
         bad[0].w, bad[0].wt, bad[0].n_out, bad[0].k_in = ws[0].data_ptr(), wts[0].data_ptr(), 767, 768
-        assert lib.stlt_wt_refresh(bad, 1, stream) != 0
+        assert lib.stlt_ctx_wt_refresh(tctx.handle, bad, 1, torch.cuda.current_stream().cuda_stream) != 0
+        assert lib.stlt_ctx_wt_refresh(None, ent, len(ws), torch.cuda.current_stream().cuda_stream) != 0  # no context, no registry
     finally:
-        lib.stlt_wt_clear()
+        torch.cuda.synchronize()
+        tctx.close(); other.close()
+    assert lib.stlt_ctx_wt_hits(None) == -1 and lib.stlt_ctx_destroy(None) == 0
 
 
 def test_trainer_steps_agree_with_and_without_transposed_weight_copies(pkg, monkeypatch):
@@ -607,19 +621,21 @@ def test_trainer_steps_agree_with_and_without_transposed_weight_copies(pkg, monk
         m.to(DEV)
         tr = pkg.train.Trainer(m, "something", learning_rate=1e-3, weight_decay=1e-3, clip_val=5.0, warmup_steps=0, total_steps=100)
         assert (tr.transposed is not None) == (on == "1")
-        hits0 = lib.stlt_wt_hits()
+        hits0 = tr.context.wt_hits()
         log = []
         for s in range(3):
             batch = pkg.synth.make_batch(48, c["T"], c["N"], seed=700 + s)
             batch["labels"] = torch.randint(0, c["num_classes"], (48,), generator=torch.Generator().manual_seed(800 + s))
             out = tr.step({k: v.to(DEV) for k, v in batch.items()})
             log.append((float(out["loss"]), float(out["grad_norm"])))
-        used = lib.stlt_wt_hits() - hits0
+        used = tr.context.wt_hits() - hits0
         assert (used > 0) == (on == "1"), used
-        probe = torch.zeros(8, 256, device=DEV, requires_grad=True)  # after the step: nothing is current
-        h = lib.stlt_wt_hits()
-        pkg.ops.LinearFn.apply(probe, m.backbone.transformer.layers[0].linear1.weight, None).sum().backward()
-        assert lib.stlt_wt_hits() == h
+        # after the step: nothing is current, even for a call that names the trainer's context
+        w2 = m.backbone.transformer.layers[0].linear2.weight
+        rows = next(M for M in (2048, 1024, 512, 256, 128, 64) if lib.stlt_input_grad_small_choice(M, w2.shape[0], w2.shape[1]) != 0)
+        h = tr.context.wt_hits()
+        pkg.ops.input_grad_small(torch.randn(rows, w2.shape[0], device=DEV), w2, 0, context=tr.context)
+        assert tr.context.wt_hits() == h
         runs.append((log, [p.detach().clone() for p in m.parameters()]))
     (log_a, pa), (log_b, pb) = runs
     for (la, ga), (lb, gb) in zip(log_a, log_b):
