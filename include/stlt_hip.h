@@ -546,6 +546,13 @@ int stlt_prof_collect(double* ms_out, int64_t* launches_out);  /* sync events, a
 /* FLOPs (2*M*N*K summed over the launches) of the matrix-core products enqueued on the current device while timing was on,
  * since the last call: what the roofline of a step is priced with, whatever the schedule (forward, elided layers, backward). */
 double stlt_prof_take_gemm_flops(void);
+/* The same records launch by launch, in launch order (alternative to stlt_prof_collect: either call drains them): duration from the
+ * launch's two events, the FLOPs / algorithmic bytes the launcher declared, and the launcher's note — shape, tile, workgroups, rounds,
+ * k-steps — for tools/launch_bound.py, which prices every launch of a step against its own bound.  *n_out = records drained (may exceed
+ * cap: the first cap are written). */
+#define STLT_PROF_NOTE 160
+typedef struct { int kid; int kernels; float us; float reserved; double flops, bytes; char note[STLT_PROF_NOTE]; } stlt_prof_launch;  /* kernels: kernel launches inside the record (a stream-K product = 2) */
+int stlt_prof_launches(stlt_prof_launch* out, int64_t cap, int64_t* n_out);
 
 /* Diagnostics only (tools/attn_stamps.py, tools/gemm_block_times.py): when non-NULL, stlt_attn_core_fwd runs its
  * s_memtime-stamped build (8 uint64 phase stamps per item) and stlt_linear_fwd records per-workgroup data into dev_buf:

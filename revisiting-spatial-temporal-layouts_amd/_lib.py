@@ -32,6 +32,11 @@ class WtEntry(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("n_out", C.c_int64), ("k_in", C.c_int64)]
 
 
+class ProfLaunch(C.Structure):
+    _fields_ = [("kid", C.c_int), ("kernels", C.c_int), ("us", C.c_float), ("reserved", C.c_float), ("flops", C.c_double), ("bytes", C.c_double),
+                ("note", C.c_char * 160)]
+
+
 class WgradItem(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("n_out", C.c_int64), ("x", C.c_void_p), ("k_in", C.c_int64), ("rows", C.c_int64), ("g_w", C.c_void_p)]
 
@@ -181,6 +186,7 @@ SIGNATURES = {
     "stlt_adamw_step": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, _vp]),
     "stlt_prof_enable": (C.c_int, [C.c_int]),
     "stlt_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "stlt_prof_launches": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64)]),
     "stlt_debug_set_buffer": (C.c_int, [_vp]),
 }
 

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -14,7 +15,10 @@ thread_local char g_err[512] = "";
 
 // Per-kernel timing: the switch is process-wide, the records and the event pool are per device (an event belongs to the
 // device it was created on), and a launch's two events are recorded on the launch's own stream.
-struct ProfRec { int kid; hipEvent_t a, b; };
+struct ProfRec { int kid; hipEvent_t a, b; double flops, bytes; int kernels; char note[STLT_PROF_NOTE]; };
+thread_local char t_note[STLT_PROF_NOTE] = "";
+thread_local double t_flops = 0.0, t_bytes = 0.0;
+thread_local int t_kernels = 0;  // kernel launches checked (stlt_check_launch) inside the open scope
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs[STLT_MAX_DEVICES];
@@ -58,6 +62,13 @@ int stlt_set_error(int code, const char* fmt, ...) {
 }
 
 int stlt_check_launch(const char* what) {
+  if (g_scope_depth > 0) ++t_kernels;
+  else if (g_prof_on) {  // a kernel outside every scope still gets a record (no events: 0 us), so that the records cover every kernel the library starts
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec rec{STLT_K_MISC, nullptr, nullptr, 0.0, 0.0, 1, {0}};
+    snprintf(rec.note, sizeof(rec.note), "%s (outside the recorder's scopes)", what);
+    g_prof_recs[stlt_current_device() & (STLT_MAX_DEVICES - 1)].push_back(rec);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return stlt_set_error((int)e, "%s: %s", what, hipGetErrorString(e));
   return 0;
@@ -68,6 +79,9 @@ void stlt_prof_begin(int kid, hipStream_t s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_open_start = get_event(stlt_current_device() & (STLT_MAX_DEVICES - 1));
+  t_note[0] = 0;
+  t_flops = t_bytes = 0.0;
+  t_kernels = 0;
   (void)hipEventRecord(g_open_start, s);
 }
 
@@ -75,6 +89,23 @@ void stlt_prof_add_flops(double flops) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_gemm_flops[stlt_current_device() & (STLT_MAX_DEVICES - 1)] += flops;
+  t_flops += flops;
+}
+
+// What the open (outermost) scope's launch is: shape, tile, workgroups, rounds, k-steps — appended to the launch's record for
+// stlt_prof_launches (tools/launch_bound.py prices every launch of a step against its own bound).  Free when the recorder is off.
+void stlt_prof_note(const char* fmt, ...) {
+  if (!g_prof_on || g_scope_depth == 0 || !g_open_start) return;
+  const size_t used = strlen(t_note);
+  if (used + 2 >= sizeof(t_note)) return;
+  if (used) { t_note[used] = ' '; t_note[used + 1] = 0; }
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(t_note + strlen(t_note), sizeof(t_note) - strlen(t_note), fmt, ap);
+  va_end(ap);
+}
+void stlt_prof_add_bytes(double bytes) {
+  if (g_prof_on && g_scope_depth > 0) t_bytes += bytes;
 }
 
 void stlt_prof_end(int kid, hipStream_t s) {
@@ -84,7 +115,9 @@ void stlt_prof_end(int kid, hipStream_t s) {
   const int dev = stlt_current_device() & (STLT_MAX_DEVICES - 1);
   hipEvent_t b = get_event(dev);
   (void)hipEventRecord(b, s);
-  g_prof_recs[dev].push_back({kid, g_open_start, b});
+  ProfRec rec{kid, g_open_start, b, t_flops, t_bytes, t_kernels, {0}};
+  memcpy(rec.note, t_note, sizeof(rec.note));
+  g_prof_recs[dev].push_back(rec);
   g_open_start = nullptr;
 }
 
@@ -127,6 +160,7 @@ int stlt_prof_collect(double* ms_out, int64_t* launches_out) {
   for (int k = 0; k < STLT_K_COUNT; ++k) { if (ms_out) ms_out[k] = 0.0; if (launches_out) launches_out[k] = 0; }
   const int dev = stlt_current_device() & (STLT_MAX_DEVICES - 1);  // the records of the device that is current
   for (auto& r : g_prof_recs[dev]) {
+    if (!r.a) continue;  // a kernel outside the scopes: counted by stlt_prof_launches only
     hipError_t e = hipEventSynchronize(r.b);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
@@ -136,6 +170,32 @@ int stlt_prof_collect(double* ms_out, int64_t* launches_out) {
     g_event_pool[dev].push_back(r.b);
   }
   g_prof_recs[dev].clear();
+  return 0;
+}
+
+int stlt_prof_launches(stlt_prof_launch* out, int64_t cap, int64_t* n_out) {
+  if (!n_out || (cap > 0 && !out)) return stlt_set_error(STLT_EINVAL, "stlt_prof_launches: null argument");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  const int dev = stlt_current_device() & (STLT_MAX_DEVICES - 1);
+  int64_t n = 0;
+  for (auto& r : g_prof_recs[dev]) {
+    hipError_t e = hipSuccess;
+    float ms = 0.f;
+    if (r.a) {
+      e = hipEventSynchronize(r.b);
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+    }
+    if (e != hipSuccess) return stlt_set_error((int)e, "stlt_prof_launches: %s", hipGetErrorString(e));
+    if (n < cap) {
+      out[n].kid = r.kid; out[n].kernels = r.kernels; out[n].us = ms * 1e3f; out[n].flops = r.flops; out[n].bytes = r.bytes;
+      memcpy(out[n].note, r.note, sizeof(out[n].note));
+      out[n].note[sizeof(out[n].note) - 1] = 0;
+    }
+    ++n;
+    if (r.a) { g_event_pool[dev].push_back(r.a); g_event_pool[dev].push_back(r.b); }
+  }
+  g_prof_recs[dev].clear();
+  *n_out = n;
   return 0;
 }
 

@@ -735,6 +735,8 @@ int launch_ln_bwd(const float* dy, int64_t lddy, const float* a, int64_t lda, co
   int64_t blocks = (M + rpw * RW_WAVES - 1) / (rpw * RW_WAVES);
   if (blocks > 512) blocks = 512;  // one partial row set per block (scratch is sized for that)
   StltProfScope ps(STLT_K_LN_BWD, s);
+  stlt_prof_note("ln_bwd rows=%lld d=%lld blocks=%lld", (long long)M, (long long)d, (long long)blocks);
+  stlt_prof_add_bytes((double)M * 4.0 * d * 4.0);  // dy, the two summands (or the sum), ds
   if (nv_for(d) > 4) {  // d > 1024: accumulators in LDS (no shape of the path has such rows; kept working without scratch memory)
     const size_t lds = (size_t)RW_WAVES * 3 * d * sizeof(float);  // <= 96 KB
     static StltPerDeviceOnce lds_once;
@@ -773,6 +775,8 @@ int launch_colsum_acc(const float* x, int64_t ld, int64_t M, int64_t N, float* g
 
 int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows, int64_t ncols) {
   StltProfScope ps(STLT_K_GELU, s);
+  stlt_prof_note("gelu_fwd n=%lld", (long long)n);
+  stlt_prof_add_bytes(8.0 * (double)n);
   if (n % 4) return stlt_set_error(STLT_EINVAL, "gelu: element count must be a multiple of 4");
   if (n == 0) return 0;
   int64_t blocks = (n / 4 + 255) / 256;
@@ -785,6 +789,8 @@ int launch_gelu_fwd(const float* u, float* h, int64_t n, hipStream_t s, StltDrop
 int launch_gelu_bwd_colsum(const float* dh, const float* u, float* du, int64_t M, int64_t N, float* g_colsum, float* scratch,
                            hipStream_t s, StltDrop dr, uint32_t site, const int* drop_rows) {
   StltProfScope ps(STLT_K_GELU, s);
+  stlt_prof_note("gelu_bwd+colsum rows=%lld cols=%lld", (long long)M, (long long)N);
+  stlt_prof_add_bytes(12.0 * (double)M * (double)N);
   if (!dh || !u || !du || !g_colsum || !scratch) return stlt_set_error(STLT_EINVAL, "gelu_bwd: null pointer");
   if (N % 4 || N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "gelu: column count must be a multiple of 4");
   if (M == 0 || N == 0) return 0;
@@ -813,6 +819,9 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
                     int64_t dh, float* dqkv, hipStream_t s, StltDrop dr, uint32_t site, float* g_colsum, float* scratch,
                     const AttnBwdRagged* rg) {
   StltProfScope ps(STLT_K_ATTN_BWD, s);
+  stlt_prof_note("attn_bwd S=%lld L=%lld H=%lld causal=%d%s", (long long)S, (long long)L, (long long)H, causal, rg ? " ragged" : "");
+  stlt_prof_add_bytes(4.0 * (double)(S * L) * (double)(H * dh) * 7.0 + (double)(S * L));  // read qkv + dctx, write dqkv
+  stlt_prof_add_flops(10.0 * (double)S * (double)H * (double)L * (double)L * (double)dh);   // S, dP, dV, dQ, dK
   if (!qkv || !dctx || (!kpm && !rg) || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
   if (L <= 0 || L > AB_LONG_MAXL)
     return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld)", AB_LONG_MAXL, (long long)L);

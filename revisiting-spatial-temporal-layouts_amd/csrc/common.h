@@ -36,6 +36,8 @@ extern unsigned long long* g_stlt_debug_buf;
 void stlt_prof_begin(int kid, hipStream_t s);
 void stlt_prof_end(int kid, hipStream_t s);
 void stlt_prof_add_flops(double flops);
+void stlt_prof_note(const char* fmt, ...) __attribute__((format(printf, 1, 2)));  // the open scope's launch in words (shape, tile, workgroups, rounds, k-steps)
+void stlt_prof_add_bytes(double bytes);                                          // ... and its algorithmic bytes (HBM-bound kernels)
 struct StltProfScope {  // scopes nest: only the outermost one of a thread records (a launcher that calls another launcher is one entry)
   int kid; hipStream_t s;
   StltProfScope(int k, hipStream_t st) : kid(k), s(st) { stlt_prof_begin(kid, s); }

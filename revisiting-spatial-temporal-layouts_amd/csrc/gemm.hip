@@ -1114,14 +1114,38 @@ static bool make_sk_plan(int64_t n_tiles, int64_t nk, int64_t G, const double* w
   return true;
 }
 
+static int launch_gemm_impl(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                            const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
+                            int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi_in, bool on_copy);
+
 // C (M,N) = opA(A)·opB(B) [+ bias | + R], contraction length K (multiple of 32).  n_split > 1: C is a slab buffer.
 int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
                 const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
                 int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi_in) {
+  // An input gradient dX (M, N = k_in) = dY (M, K = n_out) · W (n_out, k_in) whose weight has a current transposed copy in the call's
+  // training context (wt_cache.hip: the trainer refreshed it at the start of its step): the same product is the FORWARD layout on the
+  // copy, dX = dY·(Wt)ᵀ — operand fragments by 16-byte LDS reads instead of the NN layout's four-byte gather of W (0.84 - 0.89 of the
+  // peak against the forward's 0.888 on the 14 336-row spatial products), add-source and fused GELU backward included.
+  static const bool copy_on = [] { const char* e = getenv("STLT_GEMM_DX_WT"); return !(e && e[0] == '0'); }();  // A/B knob
+  if (copy_on && !transA && transB && n_split == 1 && b && ldb == N && M > 0) {
+    const float* wt = nullptr;
+    int64_t ldwt = 0;
+    if (stlt_wt_lookup(b, K, N, &wt, &ldwt)) {
+      const int rc = launch_gemm_impl(0, 0, a, lda, wt, ldwt, bias, r, ldr, c, ldc, slab_stride, M, N, K, n_split, act, s, epi_in, true);
+      if (rc == 0) stlt_wt_count_hit();
+      return rc;
+    }
+  }
+  return launch_gemm_impl(transA, transB, a, lda, b, ldb, bias, r, ldr, c, ldc, slab_stride, M, N, K, n_split, act, s, epi_in, false);
+}
+
+static int launch_gemm_impl(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias,
+                            const float* r, int64_t ldr, float* c, int64_t ldc, int64_t slab_stride, int64_t M, int64_t N,
+                            int64_t K, int n_split, int act, hipStream_t s, const StltGemmEpi* epi_in, bool on_copy) {
   if (!a || !b || !c) return stlt_set_error(STLT_EINVAL, "gemm: null pointer");
   const StltGemmEpi epi = epi_in ? *epi_in : StltGemmEpi{StltDrop{0u, 1.0f, 0ull}, 0u, nullptr, nullptr};
   if (act == STLT_ACT_GELU_BWD) {
-    if (!epi_in || !epi.cs_part || !r || transA || !transB || n_split != 1 || bias)
+    if (!epi_in || !epi.cs_part || !r || transA || (!transB && !on_copy) || n_split != 1 || bias)
       return stlt_set_error(STLT_EINVAL, "gemm: the fused GELU backward is the dX layout with u as the add-source and a column-sum buffer");
   }
   if (M < 0 || N <= 0 || K <= 0) return stlt_set_error(STLT_EINVAL, "gemm: bad shape (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
@@ -1150,6 +1174,8 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   if (n_wg > n_cu()) n_wg = n_cu();
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(2.0 * (double)M * (double)N * (double)K);
+  stlt_prof_note("gemm%s M=%lld N=%lld K=%lld act=%d%s tile=256x128 tiles=%lld", transA ? "(dW)" : (transB ? "(dX)" : (on_copy ? "(dX on the Wt copy)" : "")), (long long)M, (long long)N, (long long)K, act,
+                 r ? "+R" : "", (long long)(tiles_m * tiles_n));
   dim3 block(GEMM_THREADS);
   // Stream-K when whole tiles would leave CUs idle (fewer tiles than CUs, or a ragged last round) and the caller
   // lent scratch for the partial tiles (StltGemmScratch / stlt_gemm_set_scratch).
@@ -1171,6 +1197,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
       const int S = (int)((n_tiles * nk + G - 1) / G);
       dim3 grid((unsigned)G);
       float* P = t_gemm_scratch;
+      stlt_prof_note("stream-K wg=%lld ksteps/wg=%d (+fix-up)", (long long)G, S);
       static const bool ws_sk = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
       // hybrid: whole-tile rounds in the grouped order + a stream-K tail (loader-wave build, full grid of 8 x Gx workgroups,
       // the tail at least 4 k-steps per workgroup: the last whole round joins it otherwise).  STLT_GEMM_HYBRID=0: plain stream-K.
@@ -1187,6 +1214,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
       if (transA) { if (r) LAUNCH_SK(STLT_ACT_NONE, true, true, true); else LAUNCH_SK(STLT_ACT_NONE, true, true, false); }
       else if (transB && act == STLT_ACT_GELU_BWD) LAUNCH_SK(STLT_ACT_GELU_BWD, false, true, true);
       else if (transB) { if (r) LAUNCH_SK(STLT_ACT_NONE, false, true, true); else LAUNCH_SK(STLT_ACT_NONE, false, true, false); }
+      else if (act == STLT_ACT_GELU_BWD) LAUNCH_SK(STLT_ACT_GELU_BWD, false, false, true);  // the FFN hidden gradient on the transposed copy of W2
       else if (r) LAUNCH_SK(STLT_ACT_NONE, false, false, true);  // y = x·Wᵀ + b + r (the residual of a post-norm layer)
       else if (act == STLT_ACT_GELU) LAUNCH_SK(STLT_ACT_GELU, false, false, false);
       else if (act == STLT_ACT_RELU) LAUNCH_SK(STLT_ACT_RELU, false, false, false);
@@ -1205,6 +1233,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
     }
   }
   dim3 grid((unsigned)n_wg);
+  stlt_prof_note("wg=%lld rounds=%lld ksteps=%lld split=%d", (long long)n_wg, (long long)((tiles_m * tiles_n * n_split + n_wg - 1) / n_wg), (long long)(nk / n_split), n_split);
   // wave-specialised build (4 DMA-only waves beside the 8 MFMA waves) unless STLT_GEMM_WS=0 (A/B measurements)
   static const bool ws = [] { const char* e = getenv("STLT_GEMM_WS"); return e ? atoi(e) != 0 : (STLT_GEMM_WS_DEFAULT != 0); }();
   const dim3 block_ws(GEMM_THREADS_WS);
@@ -1213,6 +1242,7 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   if (transA) { if (r) LAUNCH(STLT_ACT_NONE, false, true, true, true); else LAUNCH(STLT_ACT_NONE, false, true, true, false); }
   else if (transB && act == STLT_ACT_GELU_BWD) LAUNCH(STLT_ACT_GELU_BWD, false, false, true, true);
   else if (transB) { if (r) LAUNCH(STLT_ACT_NONE, false, false, true, true); else LAUNCH(STLT_ACT_NONE, false, false, true, false); }
+  else if (act == STLT_ACT_GELU_BWD) LAUNCH(STLT_ACT_GELU_BWD, false, false, false, true);  // the FFN hidden gradient on the transposed copy of W2
   else if (r && g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true, false, false, true);  // diagnostic build path only (residual-add epilogue)
   else if (r) LAUNCH(STLT_ACT_NONE, false, false, false, true);  // y = x·Wᵀ + b + r
   else if (g_stlt_debug_buf && getenv("STLT_GEMM_STAMP")) LAUNCH(STLT_ACT_NONE, true, false, false, false);  // diagnostic build path only
@@ -1266,6 +1296,7 @@ int launch_weight_grad_group(const StltWeightGradItem* items, int n_items, hipSt
   const int S = (int)((steps + G - 1) / G);
   StltProfScope ps(STLT_K_GEMM, s);
   stlt_prof_add_flops(flops);
+  stlt_prof_note("gemm(dW group) products=%d tiles=%lld ksteps=%lld tile=256x128 stream-K wg=%lld ksteps/wg=%d (+fix-up)", n, (long long)tiles, (long long)steps, (long long)G, S);
   float* P = t_gemm_scratch;
   hipLaunchKernelGGL((gemm_nt_kernel<STLT_ACT_NONE, false, true, true, true, true, true, true>), dim3((unsigned)G), dim3(GEMM_THREADS_WS), 0, s,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, (int64_t)0,

@@ -51,6 +51,11 @@ bool tile_ok(int rb, int nt) {
 }
 
 int launch16_any(int code, const Gemm16Args& a, int act, bool add, bool wkn, hipStream_t s) {
+  {
+    const long long tiles = (long long)a.tiles_m * a.tiles_n, cus = stlt_device_cus();
+    stlt_prof_note("gemm16%s M=%d N=%d K=%d act=%d%s tile=%dx%d tiles=%lld wg=%lld rounds=%lld ksteps=%d", wkn ? "(dX,W as it lies)" : "", a.M, a.N, a.K, act, add ? "+R" : "",
+                   16 * tile_rb(code), 16 * tile_nt(code), tiles, tiles < cus ? tiles : cus, (tiles + cus - 1) / cus, a.K / 32);
+  }
   switch (tile_rb(code)) {
     case 8: return launch16_rb8(tile_nt(code), a, act, add, wkn, s);
     case 4: return launch16_rb4(tile_nt(code), a, act, add, wkn, s);

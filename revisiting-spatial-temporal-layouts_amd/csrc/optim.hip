@@ -95,6 +95,8 @@ int stlt_grad_norm(const float* flat_grad, int64_t n, float max_norm, float* scr
   if (n < 0 || ((uintptr_t)flat_grad & 15)) return stlt_set_error(STLT_EINVAL, "stlt_grad_norm: buffer must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   StltProfScope ps(STLT_K_OPTIM, s);
+  stlt_prof_note("grad_norm n=%lld", (long long)n);
+  stlt_prof_add_bytes(4.0 * (double)n);
   int64_t blocks = (n / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat_grad, n / 4, n, scratch);
@@ -108,6 +110,8 @@ int stlt_adamw_step(const stlt_opt_chunk* chunks_dev, int64_t n_chunks, const fl
   if (!chunks_dev || !flat_grad || !exp_avg || !exp_avg_sq) return stlt_set_error(STLT_EINVAL, "stlt_adamw_step: null pointer");
   if (step < 1 || n_chunks < 0 || n_chunks > 0x7fffffffLL) return stlt_set_error(STLT_EINVAL, "stlt_adamw_step: bad step / chunk count");
   StltProfScope ps(STLT_K_OPTIM, (hipStream_t)stream);
+  stlt_prof_note("adamw chunks=%lld (of up to 16384 elements: gradient, parameter and both moments read, parameter and moments written)", (long long)n_chunks);
+  stlt_prof_add_bytes(28.0 * 16384.0 * (double)n_chunks);  // upper bound: the last chunk of a parameter is partly filled
   if (n_chunks == 0) return 0;
   // scalars as torch computes them: python floats (double), rounded to fp32 where they meet the tensors
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);

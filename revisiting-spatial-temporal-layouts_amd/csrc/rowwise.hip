@@ -197,6 +197,8 @@ int launch_embed(const int64_t* categories, const float* boxes, const float* sco
   if (scores && (!score_w || !score_b)) return stlt_set_error(STLT_EINVAL, "stlt_embed_fwd: scores given without score_w/score_b");
   if (n_tokens == 0) return 0;
   StltProfScope ps(STLT_K_EMBED, s);
+  stlt_prof_note("embed rows=%lld d=%lld", (long long)n_tokens, (long long)d);
+  stlt_prof_add_bytes((double)n_tokens * (4.0 * d * (pre_out ? 2 : 1) + 29.0));
   dim3 grid((unsigned)((n_tokens + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((embed_kernel<NV>), grid, dim3(256), 0, s, categories, boxes, scores,
                                             cat_table, (int)n_categories, box_w, box_b, score_w, score_b, ln_w, ln_b,
@@ -212,6 +214,8 @@ int launch_add_layernorm(const float* x, int64_t ldx, const float* res, int64_t 
   if (ldx % 4 || ldout % 4 || (res && ldres % 4)) return stlt_set_error(STLT_EINVAL, "stlt_add_layernorm_fwd: leading dims must be multiples of 4");
   if (M == 0) return 0;
   StltProfScope ps(STLT_K_ADDLN, s);
+  stlt_prof_note("add_ln rows=%lld d=%lld%s", (long long)M, (long long)d, res ? " +res" : "");
+  stlt_prof_add_bytes((double)M * 4.0 * d * (res ? 3 : 2));
   dim3 grid((unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((add_ln_kernel<NV>), grid, dim3(256), 0, s, x, ldx, res, ldres, w, b, eps,
                                             M, (int)d, out, ldout, dr, site, drop_rows));
@@ -228,6 +232,8 @@ int launch_frames_embed(const float* spatial, int64_t row_stride, const int64_t*
   const int64_t rows = src_index ? n_rows : B * T;  // ragged mode: n_rows compacted frames
   if (rows == 0) return 0;
   StltProfScope ps(STLT_K_FRAMES, s);
+  stlt_prof_note("frames_embed rows=%lld d=%lld", (long long)rows, (long long)d);
+  stlt_prof_add_bytes((double)rows * (4.0 * d * (pre_out ? 3 : 2) + 9.0));
   dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   DISPATCH_NV(nv_for(d), hipLaunchKernelGGL((frames_embed_kernel<NV>), grid, dim3(256), 0, s, spatial, row_stride,
                                             frame_types, pos_table, type_table, ln_w, ln_b, eps, rows, (int)T, (int)d,
@@ -241,6 +247,8 @@ int launch_gather_last(const float* x, const int64_t* lengths, int64_t B, int64_
   if (!x || !lengths || !out) return stlt_set_error(STLT_EINVAL, "stlt_gather_last_fwd: null pointer");
   if (B == 0) return 0;
   StltProfScope ps(STLT_K_GATHER, s);
+  stlt_prof_note("gather_last rows=%lld d=%lld", (long long)B, (long long)d);
+  stlt_prof_add_bytes((double)B * 8.0 * d);
   hipLaunchKernelGGL(gather_last_kernel, dim3((unsigned)B), dim3(256), 0, s, x, lengths, B, (int)T, (int)d, out);
   return stlt_check_launch("gather_last_kernel");
 }

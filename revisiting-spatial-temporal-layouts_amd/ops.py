@@ -343,6 +343,19 @@ def prof_collect():
     return {L.K_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}
 
 
+def prof_launches(cap: int = 65536):
+    """-> [{"kernel", "us", "flops", "bytes", "note"}, ...] launch by launch, in launch order, since the last collect (drains the records)."""
+    buf = (L.ProfLaunch * cap)()
+    n = C.c_int64(0)
+    L.check(L.load().stlt_prof_launches(buf, cap, C.byref(n)), "stlt_prof_launches")
+    out = []
+    for i in range(min(cap, n.value)):
+        r = buf[i]
+        out.append({"kernel": L.K_NAMES[r.kid] if 0 <= r.kid < len(L.K_NAMES) else str(r.kid), "kernels": int(r.kernels), "us": float(r.us), "flops": float(r.flops),
+                    "bytes": float(r.bytes), "note": r.note.decode("utf-8", "replace")})
+    return out
+
+
 def prof_take_gemm_flops() -> float:
     """2*M*N*K summed over the matrix-core launches enqueued while timing was on, since the last call."""
     return float(L.load().stlt_prof_take_gemm_flops())
@@ -890,7 +903,7 @@ def _install_device_guards():
     import types
     g = globals()
     for name, obj in list(g.items()):
-        if name.startswith("_") or name in ("prof_enable", "prof_collect", "prof_take_gemm_flops", "workspace_bytes", "dropout"):
+        if name.startswith("_") or name in ("prof_enable", "prof_collect", "prof_launches", "prof_take_gemm_flops", "workspace_bytes", "dropout"):
             continue
         if isinstance(obj, types.FunctionType) and obj.__module__ == __name__:
             g[name] = _guarded(obj)

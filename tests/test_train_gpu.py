@@ -605,6 +605,49 @@ def test_transposed_weight_copies_serve_the_input_gradient_products(pkg):
     assert lib.stlt_ctx_wt_hits(None) == -1 and lib.stlt_ctx_destroy(None) == 0
 
 
+def test_large_tile_input_gradients_run_as_forward_products_on_the_copies(pkg):
+    """Round 6: an input-gradient product that stays on the large-tile kernel (the 14 336-row spatial products of a 64-clip step) is served
+    from the context's transposed copy as well — the forward (NT) layout on Wt, add-source included — and gives the NN layout's result to
+    the rounding of a different summation order; without a context the weight is read as it lies."""
+    lib = pkg._lib.load()
+    g = torch.Generator().manual_seed(11)
+    M = 14336
+    tctx = pkg.ops.TrainContext()
+    try:
+        for n_out, k_in in ((768, 3072), (3072, 768), (2304, 768)):
+            assert lib.stlt_input_grad_small_choice(M, n_out, k_in) == 0  # the routing keeps these on the large tiles
+            w = (torch.randn(n_out, k_in, generator=g) / math.sqrt(k_in)).to(DEV)
+            wt = torch.empty(k_in, n_out, device=DEV)
+            dy = torch.randn(M, n_out, generator=g).to(DEV)
+            x = torch.zeros(M, k_in, device=DEV)
+            ent = (pkg._lib.WtEntry * 1)()
+            ent[0].w, ent[0].wt, ent[0].n_out, ent[0].k_in = w.data_ptr(), wt.data_ptr(), n_out, k_in
+            stream = torch.cuda.current_stream().cuda_stream
+            sc = torch.empty(int(lib.stlt_linear_bwd_scratch_bytes(n_out)), dtype=torch.uint8, device=DEV)
+
+            def dx_of(handle):
+                dx = torch.empty(M, k_in, device=DEV)
+                pkg._lib.check(lib.stlt_linear_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), M, n_out, k_in, dx.data_ptr(), None, None, handle, sc.data_ptr(), sc.numel(),
+                                                   stream), "stlt_linear_bwd")
+                return dx
+
+            plain = dx_of(None)
+            pkg._lib.check(lib.stlt_ctx_wt_refresh(tctx.handle, ent, 1, stream), "stlt_ctx_wt_refresh")
+            h0 = tctx.wt_hits()
+            on_copy = dx_of(tctx.handle)
+            assert tctx.wt_hits() == h0 + 1
+            assert torch.equal(dx_of(None), plain)  # no context: never the copy
+            pkg._lib.check(lib.stlt_ctx_wt_clear(tctx.handle), "stlt_ctx_wt_clear")
+            ref = dy[:512].double() @ w.double()
+            scale = ref.abs().max().item()
+            assert (plain[:512].double() - ref).abs().max().item() / scale <= 1e-5
+            assert (on_copy[:512].double() - ref).abs().max().item() / scale <= 1e-5
+            assert (on_copy - plain).abs().max().item() / scale <= 1e-5
+    finally:
+        torch.cuda.synchronize()
+        tctx.close()
+
+
 def test_trainer_steps_agree_with_and_without_transposed_weight_copies(pkg, monkeypatch):
     """train.Trainer refreshes the copies at the start of every step and withdraws them at its end: three steps with dropout off give the
     same losses, gradient norms and parameters as with STLT_TRAIN_WT=0 (to the rounding of a different summation order in dX), the copies
