@@ -107,6 +107,10 @@ void stlt_prof_note(const char* fmt, ...) {
 void stlt_prof_add_bytes(double bytes) {
   if (g_prof_on && g_scope_depth > 0) t_bytes += bytes;
 }
+// FLOPs of a launch that is not a matrix-core product of the GEMM roofline (fused MHSA, attention cores): on the launch's record only
+void stlt_prof_note_flops(double flops) {
+  if (g_prof_on && g_scope_depth > 0) t_flops += flops;
+}
 
 void stlt_prof_end(int kid, hipStream_t s) {
   if (--g_scope_depth > 0) return;

@@ -369,7 +369,7 @@ int launch_attn_general(const float* q, int64_t ldq, const float* k, const float
   StltProfScope ps(kid, s);
   stlt_prof_note("attn S=%lld Lq=%lld Lk=%lld H=%lld causal=%d", (long long)S, (long long)Lq, (long long)Lk, (long long)H, causal);
   stlt_prof_add_bytes(4.0 * (double)H * DH * (2.0 * (double)(S * Lq) + 2.0 * (double)(S * Lk)) + (double)(S * Lk));  // read q, k, v; write ctx; one mask byte per key
-  stlt_prof_add_flops(4.0 * (double)S * (double)H * (double)Lq * (double)Lk * DH);
+  stlt_prof_note_flops(4.0 * (double)S * (double)H * (double)Lq * (double)Lk * DH);
   // short self-attention on a packed buffer (with or without the dropout of the probabilities): the 16-row-tile kernel (attn16.hip)
   if (Lq == Lk && Lq <= 64 && k == q + H * dh && v == q + 2 * H * dh && ldq == 3 * H * dh && ldkv == ldq && !g_stlt_debug_buf) {
     bool taken = false;

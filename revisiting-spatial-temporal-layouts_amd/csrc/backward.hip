@@ -821,7 +821,7 @@ int launch_attn_bwd(const float* qkv, const float* dctx, const uint8_t* kpm, int
   StltProfScope ps(STLT_K_ATTN_BWD, s);
   stlt_prof_note("attn_bwd S=%lld L=%lld H=%lld causal=%d%s", (long long)S, (long long)L, (long long)H, causal, rg ? " ragged" : "");
   stlt_prof_add_bytes(4.0 * (double)(S * L) * (double)(H * dh) * 7.0 + (double)(S * L));  // read qkv + dctx, write dqkv
-  stlt_prof_add_flops(10.0 * (double)S * (double)H * (double)L * (double)L * (double)dh);   // S, dP, dV, dQ, dK
+  stlt_prof_note_flops(10.0 * (double)S * (double)H * (double)L * (double)L * (double)dh);   // S, dP, dV, dQ, dK
   if (!qkv || !dctx || (!kpm && !rg) || !dqkv) return stlt_set_error(STLT_EINVAL, "attn_bwd: null pointer");
   if (L <= 0 || L > AB_LONG_MAXL)
     return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens (got L=%lld)", AB_LONG_MAXL, (long long)L);

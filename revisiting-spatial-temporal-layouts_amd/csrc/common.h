@@ -37,7 +37,8 @@ void stlt_prof_begin(int kid, hipStream_t s);
 void stlt_prof_end(int kid, hipStream_t s);
 void stlt_prof_add_flops(double flops);
 void stlt_prof_note(const char* fmt, ...) __attribute__((format(printf, 1, 2)));  // the open scope's launch in words (shape, tile, workgroups, rounds, k-steps)
-void stlt_prof_add_bytes(double bytes);                                          // ... and its algorithmic bytes (HBM-bound kernels)
+void stlt_prof_add_bytes(double bytes);
+void stlt_prof_note_flops(double flops);                                         // ... and FLOPs that do not belong to the GEMM roofline's sum (stlt_prof_take_gemm_flops)                                          // ... and its algorithmic bytes (HBM-bound kernels)
 struct StltProfScope {  // scopes nest: only the outermost one of a thread records (a launcher that calls another launcher is one entry)
   int kid; hipStream_t s;
   StltProfScope(int k, hipStream_t st) : kid(k), s(st) { stlt_prof_begin(kid, s); }
@@ -202,6 +203,9 @@ __device__ __forceinline__ f32x4 gelu_bwd4(f32x4 g, f32x4 u, const StltGemmEpi& 
 // gemm_any.hip: launch_gemm's fallback for contraction lengths that are not multiples of 32 (tiles staged by ordinary loads, same layouts and epilogues)
 int launch_gemm_any(int transA, int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, const float* r,
                     int64_t ldr, float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t s);
+// gemm_any.hip: products of at most 128 rows as split-k partial tiles + a finishing launch (needs lent stream-K scratch); *taken = launched
+int launch_gemm_skinny(int transB, const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, const float* r, int64_t ldr, float* c,
+                       int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t s, bool* taken);
 // gemm_bf16x3.hip: the forward product on the BF16 matrix cores with three-piece operands (opt-in); *taken = launched
 float* stlt_gemm_scratch_ptr(size_t* bytes);  // gemm.hip: the calling thread's lent stream-K scratch (nullptr: none)
 bool stlt_split_bf16_takes(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw);  // would it (switched on, shape fits)?

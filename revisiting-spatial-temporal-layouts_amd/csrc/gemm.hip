@@ -1126,6 +1126,17 @@ int launch_gemm(int transA, int transB, const float* a, int64_t lda, const float
   // training context (wt_cache.hip: the trainer refreshed it at the start of its step): the same product is the FORWARD layout on the
   // copy, dX = dY·(Wt)ᵀ — operand fragments by 16-byte LDS reads instead of the NN layout's four-byte gather of W (0.84 - 0.89 of the
   // peak against the forward's 0.888 on the 14 336-row spatial products), add-source and fused GELU backward included.
+  if (!transA && n_split == 1 && M > 0 && M <= 128 && a && b && c && !(epi_in && act == STLT_ACT_GELU_BWD)) {  // a few rows: split-k partial tiles (gemm_any.hip)
+    bool taken = false;
+    if (int e = launch_gemm_skinny(transB, a, lda, b, ldb, bias, r, ldr, c, ldc, M, N, K, act, s, &taken)) return e;
+    if (taken) return 0;
+  }
+  // A weight gradient over a few rows (dW (n_out, k_in) += dYᵀ·X with at most 128 rows to contract: the heads and the one-row-per-clip tail of a
+  // 64-clip step): 2 - 4 k-slabs per 256 x 128 tile leave the large kernel a launch of partial tiles + a fix-up (43 us for 768 x 768 x 64);
+  // 64 x 64 whole tiles on the compatibility kernel fill the chip with one launch
+  static const bool skinny_dw = [] { const char* e = getenv("STLT_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
+  if (skinny_dw && transA && transB && n_split == 1 && K > 0 && K <= 128 && !bias && act == STLT_ACT_NONE && a && b && c && M > 0 && (!r || ldr >= N))
+    return launch_gemm_any(1, 1, a, lda, b, ldb, nullptr, r, ldr, c, ldc, M, N, K, STLT_ACT_NONE, s);
   static const bool copy_on = [] { const char* e = getenv("STLT_GEMM_DX_WT"); return !(e && e[0] == '0'); }();  // A/B knob
   if (copy_on && !transA && transB && n_split == 1 && b && ldb == N && M > 0) {
     const float* wt = nullptr;
@@ -1356,6 +1367,8 @@ int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias
   bool taken = false;  // opt-in split-bf16 build of the same product (gemm_bf16x3.hip); off unless STLT_GEMM_SPLIT_BF16=6
   if (int e = launch_linear_bf16x3(x, ldx, w, K, bias, nullptr, 0, y, ldy, M, N, K, act, s, &taken)) return e;
   if (taken) return 0;
+  if (int e = launch_gemm_skinny(0, x, ldx, w, K, bias, nullptr, 0, y, ldy, M, N, K, act, s, &taken)) return e;  // a few rows (one per clip of a small batch): split-k partial tiles
+  if (taken) return 0;
   if (int e = launch_linear_gemm16(x, ldx, w, K, bias, nullptr, 0, y, ldy, M, N, K, act, s, &taken)) return e;  // under-filled launches: whole small tiles
   if (taken) return 0;
   return launch_gemm(0, 0, x, ldx, w, K, bias, nullptr, 0, y, ldy, 0, M, N, K, 1, act, s);
@@ -1367,6 +1380,8 @@ int launch_linear_add(const float* x, int64_t ldx, const float* w, const float* 
                       int64_t ldy, int64_t M, int64_t N, int64_t K, hipStream_t s) {
   bool taken = false;
   if (int e = launch_linear_bf16x3(x, ldx, w, K, bias, r, ldr, y, ldy, M, N, K, STLT_ACT_NONE, s, &taken)) return e;
+  if (taken) return 0;
+  if (int e = launch_gemm_skinny(0, x, ldx, w, K, bias, r, ldr, y, ldy, M, N, K, STLT_ACT_NONE, s, &taken)) return e;
   if (taken) return 0;
   if (int e = launch_linear_gemm16(x, ldx, w, K, bias, r, ldr, y, ldy, M, N, K, STLT_ACT_NONE, s, &taken)) return e;
   if (taken) return 0;

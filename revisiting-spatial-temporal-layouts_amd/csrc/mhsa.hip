@@ -531,7 +531,7 @@ int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, cons
     const long long items = (long long)a.n_groups * H, cus = stlt_device_cus();
     stlt_prof_note("mhsa16 S=%lld L=%lld H=%lld d=%lld causal=%d train=%d item=%dx192 items=%lld wg=%lld rounds=%lld ksteps=%lld keyblocks=%d", (long long)S, (long long)L,
                    (long long)H, (long long)d, causal, (int)train, a.rows_per_item, items, items < cus ? items : cus, (items + cus - 1) / cus, (long long)(d / 32), nkb);
-    stlt_prof_add_flops(6.0 * (double)(S * L) * (double)d * (double)d + 4.0 * (double)S * (double)H * (double)(L * L) * 64.0);
+    stlt_prof_note_flops(6.0 * (double)(S * L) * (double)d * (double)d + 4.0 * (double)S * (double)H * (double)(L * L) * 64.0);
     stlt_prof_add_bytes(8.0 * (double)(S * L) * (double)d + 4.0 * (3.0 * d * d + 3.0 * d) + (double)(S * L));
   }
   if (train && !qkv_out) return stlt_set_error(STLT_EINVAL, "mhsa_fused: dropout needs the qkv output (training forward)");

@@ -7,6 +7,7 @@ device pointers.  There is no CPU path: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -58,6 +59,10 @@ def embed(categories, boxes, scores, cat_table, box_w, box_b, score_w, score_b, 
     return out
 
 
+_TLS = threading.local()
+_SKINNY_ROWS = 128  # STLT_GEMM_SKINNY_ROWS' default: products of at most this many rows can run as split-k partial tiles when scratch is lent
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = L.ACT_NONE,
            out: Optional[torch.Tensor] = None, rows: Optional[int] = None, ldx: Optional[int] = None):
     """nn.Linear forward y = act(x wᵀ + b) on the f32 matrix cores.  x (..., K) contiguous; with rows/ldx a strided row view."""
@@ -75,7 +80,17 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: 
         out_shape = (rows, N)
     if out is None:
         out = torch.empty(out_shape, device=x.device, dtype=torch.float32)
-    L.check(lib.stlt_linear_fwd(_p(x), ldx_, _p(w), _p(bias), _p(out), N, M, N, K, act, _stream()), "stlt_linear_fwd")
+    lend = 0 < M <= _SKINNY_ROWS and x.is_cuda and not getattr(_TLS, "user_scratch", False)
+    if lend:
+        # a few rows (the heads of a 64-clip step): with scratch lent the library runs them as split-k partial tiles over the whole chip
+        # instead of 2 - 12 workgroups of serial k-steps (include/stlt_hip.h: stlt_gemm_set_scratch; csrc/gemm_any.hip: launch_gemm_skinny)
+        sk = _sk_scratch(x.device)
+        L.check(lib.stlt_gemm_set_scratch(sk.data_ptr(), sk.numel()), "stlt_gemm_set_scratch")
+    try:
+        L.check(lib.stlt_linear_fwd(_p(x), ldx_, _p(w), _p(bias), _p(out), N, M, N, K, act, _stream()), "stlt_linear_fwd")
+    finally:
+        if lend:
+            lib.stlt_gemm_set_scratch(None, 0)
     return out
 
 
@@ -157,9 +172,11 @@ class gemm_scratch:
         n = lib.stlt_gemm_scratch_bytes()
         self.buf = torch.empty(n, dtype=torch.uint8, device=self.device)
         L.check(lib.stlt_gemm_set_scratch(self.buf.data_ptr(), n), "stlt_gemm_set_scratch")
+        _TLS.user_scratch = True  # `linear` leaves the calling thread's lent scratch alone
         return self
 
     def __exit__(self, *exc):
+        _TLS.user_scratch = False
         L.check(L.load().stlt_gemm_set_scratch(None, 0), "stlt_gemm_set_scratch")
         torch.cuda.synchronize()  # the buffer may still be read by enqueued fix-up kernels
         self.buf = None

@@ -853,3 +853,39 @@ def _drop_mask(O, p, seed, site, S, H, L):
     idx = ((((s_ * np.uint64(L) + i_) * np.uint64(H)) + h_) << np.uint64(8)) | j_
     keep = O.dropout_keep(p, seed, site, idx)
     return torch.from_numpy(keep).double() * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+
+@pytest.mark.parametrize("M", [1, 17, 64, 65, 128])
+@pytest.mark.parametrize("N,K", [(768, 768), (3072, 768), (768, 3072), (174, 768), (100, 200)])
+def test_skinny_products_split_k_partial_tiles_match_fp64(pkg, M, N, K):
+    """Round 6 (csrc/gemm_any.hip: launch_gemm_skinny): products of at most 128 rows — the one-row-per-clip tail of a tower at a 64-clip batch,
+    the prediction head's 174 columns — run as split-k partial tiles + a finishing launch when stream-K scratch is lent: forward with bias /
+    GELU / ReLU / add-source, and the input-gradient layout.  Bitwise reproducible."""
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    lib = pkg._lib.load()
+    pkg.ops.prof_enable(True)
+    try:
+        with pkg.ops.gemm_scratch():
+            pkg.ops.prof_launches()
+            y0 = pkg.ops.linear(x, w, b)
+            y0_again = pkg.ops.linear(x, w, b)
+            yg = pkg.ops.linear(x, w, b, act=pkg._lib.ACT_GELU)
+            yr = pkg.ops.linear(x, w, None, act=pkg._lib.ACT_RELU)
+            dy = torch.randn(M, N, generator=g).to(DEV)
+            dx = pkg.ops.gemm(dy, w, trans_b=True)  # (M, K) = dy (M, N) · w (N, K): the input-gradient layout
+            torch.cuda.synchronize()
+            notes = [r["note"] for r in pkg.ops.prof_launches()]
+    finally:
+        pkg.ops.prof_enable(False)
+    assert all("skinny" in n for n in notes) and len(notes) == 5, notes  # every one of them took the split-k path
+    plain = pkg.ops.linear(x, w, b)  # outside the context manager `linear` lends the per-stream scratch itself for so few rows: the same path
+    ref = x.double() @ w.double().t() + b.double()
+    tol = 2e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item())
+    assert torch.equal(y0, y0_again) and torch.equal(plain, y0)
+    assert (y0.double() - ref).abs().max().item() <= tol and (plain.double() - ref).abs().max().item() <= tol
+    assert (yg.double() - torch.nn.functional.gelu(ref)).abs().max().item() <= tol
+    assert (yr.double() - torch.relu(x.double() @ w.double().t())).abs().max().item() <= tol
+    assert (dx.double() - dy.double() @ w.double()).abs().max().item() <= 2e-6 * math.sqrt(N) * max(1.0, (dy.double() @ w.double()).abs().max().item())

@@ -23,7 +23,10 @@ SWITCH_SETS = {
 SUBSET = ["tests/test_model_gpu.py", "tests/test_fit_epochs.py", "tests/test_ckpt_roundtrip.py", "tests/test_caf.py",
           "tests/test_train_gpu.py::test_gradients_match_oracle_autograd", "tests/test_train_gpu.py::test_three_training_steps_match_reference_golden",
           "tests/test_train_gpu.py::test_dropout_forward_and_gradients_match_masked_oracle", "tests/test_train_gpu.py::test_trainer_fused_and_stock_optimizer_agree"]
-DESELECT = ["tests/test_model_gpu.py::test_bench_sized_launches_reproduce_the_golden_rows"]  # spawns its own children; minutes, not seconds
+DESELECT = ["tests/test_model_gpu.py::test_bench_sized_launches_reproduce_the_golden_rows",  # spawns its own children; minutes, not seconds
+            "tests/test_train_gpu.py::test_gradients_match_oracle_autograd[cfg4-2-True-True]",  # 10 s each: the fp64 oracle's autograd at cfg4
+            "tests/test_train_gpu.py::test_gradients_match_oracle_autograd[cfg4-2-True-False]",
+            "tests/test_model_gpu.py::test_matches_oracle_on_fresh_seed_with_scores_absent_and_present"]
 
 
 @pytest.mark.parametrize("name", sorted(SWITCH_SETS))
