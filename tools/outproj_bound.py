@@ -9,7 +9,7 @@ would not be a launch of its own.  Measured here, per layer, at the temporal tow
       one that 512 MB of other traffic has pushed out                         -> the cost of the ctx read;
   (c) back-to-back fused kernel + out-projection vs the sum of the two alone  -> the launch boundary.
 Everything else of the out-projection (its 2 S L d^2 FLOPs) would still have to be computed inside the fused kernel, on 64-row items
-(12 heads of a row group per workgroup: LABNOTES.md)."""
+(12 heads of a row group per workgroup: docs/LABNOTES_rounds1-5.md)."""
 import ctypes as C
 import json
 import os
