@@ -181,7 +181,10 @@ def side_forward_leg(pkg, torch, dev, config, B, steps, warmup, shape=None, spli
     model, _ = _build_model(pkg, torch, dev, config)
     model.backbone.skip_padding = bool(skip_padding)  # opt-in: the real tokens / frames only (same logits to ~3e-6)
     T, N, d, H = c["T"], c["N"], c["hidden_size"], c["num_attention_heads"]
-    batch = {k: v.to(dev) for k, v in pkg.synth.make_batch(B, T, N, dataset=c["dataset"], seed=2000).items()}
+    cpu_batch = pkg.synth.make_batch(B, T, N, dataset=c["dataset"], seed=2000)
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+    if skip_padding:  # the batch carries its two real-row counts, as a collater would provide them: the forward reads nothing back
+        batch.update(pkg.collate.real_counts(cpu_batch))
 
     def step():
         with torch.no_grad():
@@ -723,10 +726,17 @@ def leg_skip_padding(ctx):
     pkg, torch, dev, args, B, T, N = ctx.pkg, ctx.torch, ctx.dev, ctx.args, ctx.B, ctx.T, ctx.N
     cb = ctx.cpu_batch
     real_tok = int(((~cb["src_key_padding_mask_boxes"]) & (~cb["src_key_padding_mask_frames"])[:, :, None]).sum())
+    counted = dict(ctx.batch, **pkg.collate.real_counts(cb))  # the batch with its two real-row counts (a collater's by-product): no read-back
+
+    def step_counted():
+        with torch.no_grad():
+            return ctx.model(counted)["stlt"]
+
     try:
         ctx.model.backbone.skip_padding = True
         n_sk = min(args.steps, 20)
         sk_s, sk_logits = _timed(torch, dev, ctx.step, min(args.warmup, 5), n_sk)
+        skc_s, skc_logits = _timed(torch, dev, step_counted, min(args.warmup, 5), n_sk)
         sk_x3 = None
         if not args.no_split_bf16 and not args.split_bf16_main:
             try:  # both opt-in switches together: real tokens only, products on the split-bf16 kernel
@@ -740,6 +750,8 @@ def leg_skip_padding(ctx):
         ctx.model.backbone.skip_padding = False
         pkg.ops.set_gemm_split_bf16(0)
     return {"value": round(B / sk_s, 2), "unit": "clips/s", "ms_per_step": round(sk_s * 1e3, 4), "split_bf16": sk_x3,
+            "with_row_counts": {"value": round(B / skc_s, 2), "ms_per_step": round(skc_s * 1e3, 4), "bit_identical": bool(torch.equal(skc_logits, sk_logits)),
+                                "note": "the batch carries num_real_tokens / num_real_frames (collate.real_counts): no read-back, no stream synchronisation"},
             "real_token_frac": round(real_tok / (B * T * N), 4), "real_frame_frac": round(float((~cb["src_key_padding_mask_frames"]).float().mean()), 4),
             "logit_max_abs_diff_vs_padded": float((sk_logits - ctx.logits).abs().max())}
 

@@ -14,8 +14,9 @@
  *     (stlt_ctx, below), which the caller creates, names in the calls that may use it, and destroys.  fp32, row-major,
  *     contiguous unless a leading dimension (ld*) is given in ELEMENTS.  ids/lengths int64, masks uint8 (1 = padded / masked).
  *   - asynchronous on `stream` (a hipStream_t passed as void*); no implicit synchronisation — the one exception
- *     is STLT_FLAG_SKIP_PADDING, which reads two row counts back (one stream synchronisation per call); everything
- *     else is a fixed launch sequence that can be captured in a hipGraph.
+ *     is STLT_FLAG_SKIP_PADDING without the caller's row counts (stlt_inputs.n_real_tokens / n_real_frames), which reads
+ *     two row counts back (one stream synchronisation per call); everything else is a fixed launch sequence that can be
+ *     captured in a hipGraph.
  *   - per-thread state: the error string and the scratch lent with stlt_gemm_set_scratch (both thread-local).
  *     Process-wide: write-once caches of device properties and the routing switches (stlt_set_gemm_small_tiles,
  *     stlt_set_gemm_split_bf16, stlt_set_train_side_stream: plain integers, set them before the calls they steer, not
@@ -249,6 +250,11 @@ typedef struct {
   const int64_t* frame_types;  /* (B,T) */
   const uint8_t* kpm_frames;   /* (B,T)    src_key_padding_mask_frames */
   const int64_t* lengths;      /* (B) */
+  /* STLT_FLAG_SKIP_PADDING only, optional (0 = unknown): the batch's real rows as the collater can count them on the host —
+   * n_real_frames = number of zeros in kpm_frames, n_real_tokens = number of zeros in kpm_boxes inside those frames.  With both given the
+   * call reads nothing back: no stream synchronisation, capturable in a hipGraph (for batches with these counts).  They are verified on the
+   * device: counts that are not the masks', or masks that break the collater contract, give NaN results instead of an error return. */
+  int64_t n_real_tokens, n_real_frames;
 } stlt_inputs;
 
 #define STLT_FLAG_CLS_ONLY_LAST_SPATIAL 1 /* last spatial layer: Q/out-proj/FFN on the CLS rows only (the only rows read, models.py:79) */

@@ -84,7 +84,8 @@ class CafParams(C.Structure):
 
 class Inputs(C.Structure):
     _fields_ = [("B", C.c_int64), ("T", C.c_int64), ("N", C.c_int64)] + [
-        (n, _vp) for n in ("categories", "boxes", "scores", "kpm_boxes", "frame_types", "kpm_frames", "lengths")]
+        (n, _vp) for n in ("categories", "boxes", "scores", "kpm_boxes", "frame_types", "kpm_frames", "lengths")] + [
+        ("n_real_tokens", C.c_int64), ("n_real_frames", C.c_int64)]
 
 
 # symbol -> (restype, argtypes); the not-gpu tests check that every one of these is exported

@@ -58,3 +58,13 @@ class DeviceCollater:
         out["labels"] = torch.stack([torch.as_tensor(s["labels"]) for s in samples]).to(dev)
         out["video_id"] = [s.get("video_id") for s in samples]
         return out
+
+
+def real_counts(batch) -> dict:
+    """{"num_real_tokens", "num_real_frames"} of a collated batch, counted from its masks (on whatever device they live: call it on the host
+    side of the loader, where the masks are made — reference datasets.py:274-286): frames = zeros of src_key_padding_mask_frames, tokens =
+    zeros of src_key_padding_mask_boxes inside those frames.  Added to the batch as host integers they let a skip-padding forward / training
+    step run without reading its row counts back (include/stlt_hip.h: stlt_inputs.n_real_tokens / n_real_frames)."""
+    real = ~batch["src_key_padding_mask_frames"].bool()
+    tokens = ((~batch["src_key_padding_mask_boxes"].bool()) & real[:, :, None]).sum()
+    return {"num_real_tokens": int(tokens), "num_real_frames": int(real.sum())}

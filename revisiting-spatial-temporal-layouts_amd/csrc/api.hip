@@ -547,14 +547,21 @@ static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* wor
   float* hh = (float*)(base + w.hh);
   const RaggedIndex ix = ragged_index_carve(base + w.ridx, B, T, N);
   TRY(launch_ragged_index(in->kpm_boxes, in->kpm_frames, in->lengths, B, T, N, ix, s));
-  int counts[4] = {0, 0, 0, 0};
-  if (hipError_t e = hipMemcpyAsync(counts, ix.counts, sizeof(counts), hipMemcpyDeviceToHost, s); e != hipSuccess)
-    return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
-  if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess)
-    return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
-  if (counts[2] != 0)
-    return stlt_set_error(STLT_EINVAL, "skip-padding needs collater-shaped masks: slot 0 of every real frame unmasked and frame lengths-1 real (datasets.py:247-288)");
-  const int64_t Ms = counts[0], Mf = counts[1];
+  int64_t Ms = 0, Mf = 0;
+  const bool host_counts = in->n_real_tokens > 0 || in->n_real_frames > 0;  // the caller knows the two row counts: no read-back, no synchronisation
+  if (host_counts) {
+    Ms = in->n_real_tokens; Mf = in->n_real_frames;
+    TRY(launch_ragged_host_counts(ix, Ms, Mf, B * T * N, B * T, s));
+  } else {
+    int counts[4] = {0, 0, 0, 0};
+    if (hipError_t e = hipMemcpyAsync(counts, ix.counts, sizeof(counts), hipMemcpyDeviceToHost, s); e != hipSuccess)
+      return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
+    if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess)
+      return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
+    if (counts[2] != 0)
+      return stlt_set_error(STLT_EINVAL, "skip-padding needs collater-shaped masks: slot 0 of every real frame unmasked and frame lengths-1 real (datasets.py:247-288)");
+    Ms = counts[0]; Mf = counts[1];
+  }
   TRY(launch_embed(in->categories, in->boxes, in->scores, p->cat_emb, p->n_categories, p->box_w, p->box_b, p->score_w,
                    p->score_b, p->emb_ln_w, p->emb_ln_b, p->ln_eps, Ms, d, x, s, nullptr, StltDrop{0u, 1.0f, 0ull}, ix.t_orig));
   // spatial transformer: segments = frames; after it only each frame's CLS row is read (models.py:79)
@@ -580,7 +587,10 @@ static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* wor
   const int64_t tp_full = out_btd ? p->n_temporal : p->n_temporal - 1;
   for (int64_t l = 0; l < tp_full; ++l)
     TRY(encoder_layer_ragged(p->temporal[l], d, H, tbuf, Mf, ix.f_seg_start, ix.f_seg_end, 1, STLT_K_ATTN_TEMPORAL, qkv, ctx, tmp, x, hh, tbuf, s));
-  if (out_btd) return launch_scatter_rows(tbuf, ix.f_orig, Mf, d, out_btd, B * T, s);
+  if (out_btd) {
+    TRY(launch_scatter_rows(tbuf, ix.f_orig, Mf, d, out_btd, B * T, s));
+    return host_counts ? launch_ragged_poison(ix, Ms, Mf, out_btd, B * T * d, s) : 0;
+  }
   if (p->n_temporal > 0) {
     const stlt_layer_params& lp = p->temporal[p->n_temporal - 1];
     TRY(launch_linear(tbuf, d, lp.in_proj_w, lp.in_proj_b, qkv, 3 * d, Mf, 3 * d, d, STLT_ACT_NONE, s));
@@ -589,7 +599,7 @@ static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* wor
   } else {
     TRY(launch_gather_rows(tbuf, d, ix.last_row, B, d, h0, s));
   }
-  return 0;
+  return host_counts ? launch_ragged_poison(ix, Ms, Mf, h0, B * d, s) : 0;  // counts that are not the index's: NaN rows for the head, NaN logits
 }
 
 // exported to caf.hip (same library, C++ linkage)

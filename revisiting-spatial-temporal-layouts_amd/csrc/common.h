@@ -358,6 +358,9 @@ RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N);
 int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, const int64_t* lengths, int64_t B, int64_t T,
                         int64_t N, const RaggedIndex& idx, hipStream_t s);
 int launch_gather_rows(const float* src, int64_t ld, const int* rows, int64_t n, int64_t d, float* out, hipStream_t s);
+// the caller's row counts instead of a read-back: index entries up to the caller's counts made safe, and the result poisoned (NaN) when they are not the index's
+int launch_ragged_host_counts(const RaggedIndex& idx, int64_t n_tok, int64_t n_frm, int64_t max_tok, int64_t max_frm, hipStream_t s);
+int launch_ragged_poison(const RaggedIndex& idx, int64_t n_tok, int64_t n_frm, float* out, int64_t n, hipStream_t s);
 // hidden size / head count a model or block may have: any head dim up to 256 (64: the MFMA kernels; others: attn_any.hip); rows are
 // moved 16 bytes at a time (hidden sizes that are not multiples of 32 run their products on gemm_any.hip)
 inline bool stlt_heads_ok(int64_t d, int64_t H) { return d > 0 && H > 0 && d % H == 0 && d / H <= 256 && d % 4 == 0; }

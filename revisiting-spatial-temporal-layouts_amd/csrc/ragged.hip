@@ -16,10 +16,14 @@ namespace {
 // real tokens / frames of each clip.  One block per clip, thread t = frame t (T <= 256).
 __global__ __launch_bounds__(256) void ragged_count_kernel(const uint8_t* __restrict__ kpm_boxes,
                                                            const uint8_t* __restrict__ kpm_frames, int T, int N,
-                                                           int* __restrict__ clip_tok, int* __restrict__ clip_frm) {
+                                                           int* __restrict__ clip_tok, int* __restrict__ clip_frm, int* __restrict__ counts) {
   __shared__ int s_tok[256], s_frm[256];
   const int64_t b = blockIdx.x;
   const int t = threadIdx.x;
+  // the contract flag starts from zero for this index (the fill kernel, two launches later, only ever raises it).  Cleared here and not by
+  // a memset: a memset node of a captured graph was seen to run out of order with the kernels around it on replay (round 6: the second
+  // replay of a skip-padding forward found the freshly written counts zeroed)
+  if (b == 0 && t == 0) { counts[2] = 0; counts[3] = 0; }
   int cnt = 0, real = 0;
   if (t < T && kpm_frames[b * T + t] == 0) {
     real = 1;
@@ -158,7 +162,44 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
+// Row counts given by the caller (stlt_inputs.n_real_tokens / n_real_frames: a collater knows them on the host) instead of read back.  Rows
+// between the index's own counts and the caller's get a self-contained entry (token 0 / frame 0, a one-row segment), so that a count that is
+// too LARGE stays inside every buffer; stlt_ragged_poison then turns the call's result into NaN when the caller's counts are not the index's
+// (or the masks break the collater contract) — the check the read-back made on the host, moved behind the launches it used to precede.
+__global__ __launch_bounds__(256) void ragged_host_counts_kernel(RaggedIndex ix, int n_tok, int n_frm) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int have_tok = ix.counts[0], have_frm = ix.counts[1];
+  if (i >= have_tok && i < n_tok) { ix.t_orig[i] = 0; ix.t_seg_start[i] = i; ix.t_seg_end[i] = i + 1; }
+  if (i >= have_frm && i < n_frm) { ix.f_orig[i] = 0; ix.f_cls_row[i] = 0; ix.f_seg_start[i] = i; ix.f_seg_end[i] = i + 1; }
+}
+// dst = 0 as a kernel (not hipMemsetAsync: see ragged_count_kernel — a captured graph must replay this before the scatter that follows)
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) reinterpret_cast<f32x4*>(dst)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(256) void ragged_poison_kernel(const int* __restrict__ counts, int n_tok, int n_frm, float* __restrict__ out, int64_t n) {
+  if (counts[0] == n_tok && counts[1] == n_frm && counts[2] == 0) return;
+  const float nan = __int_as_float(0x7fc00000);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = nan;
+}
+
 }  // namespace
+
+int launch_ragged_host_counts(const RaggedIndex& ix, int64_t n_tok, int64_t n_frm, int64_t max_tok, int64_t max_frm, hipStream_t s) {
+  if (n_tok <= 0 || n_frm <= 0 || n_tok > max_tok || n_frm > max_frm || n_frm > n_tok)
+    return stlt_set_error(STLT_EINVAL, "skip-padding: n_real_tokens = %lld / n_real_frames = %lld do not fit the batch (%lld tokens, %lld frames)", (long long)n_tok,
+                          (long long)n_frm, (long long)max_tok, (long long)max_frm);
+  StltProfScope ps(STLT_K_MISC, s);
+  hipLaunchKernelGGL(ragged_host_counts_kernel, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, s, ix, (int)n_tok, (int)n_frm);
+  return stlt_check_launch("ragged_host_counts_kernel");
+}
+int launch_ragged_poison(const RaggedIndex& ix, int64_t n_tok, int64_t n_frm, float* out, int64_t n, hipStream_t s) {
+  if (!out || n <= 0) return 0;
+  StltProfScope ps(STLT_K_MISC, s);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(ragged_poison_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ix.counts, (int)n_tok, (int)n_frm, out, n);
+  return stlt_check_launch("ragged_poison_kernel");
+}
 
 size_t ragged_index_bytes(int64_t B, int64_t T, int64_t N) {
   const size_t tok = (size_t)B * T * N, bt = (size_t)B * T;
@@ -184,9 +225,7 @@ int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, con
   if (!kpm_boxes || !kpm_frames) return stlt_set_error(STLT_EINVAL, "ragged_index: null mask");
   if (T > 256) return stlt_set_error(STLT_EINVAL, "ragged_index: T=%lld > 256", (long long)T);
   if (B * T * N > 0x7fffff00LL) return stlt_set_error(STLT_EINVAL, "ragged_index: batch too large for 32-bit row indices");
-  if (hipError_t e = hipMemsetAsync(ix.counts, 0, 4 * sizeof(int), s); e != hipSuccess)
-    return stlt_set_error((int)e, "ragged_index: memset: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(ragged_count_kernel, dim3((unsigned)B), dim3(256), 0, s, kpm_boxes, kpm_frames, (int)T, (int)N, ix.clip_tok, ix.clip_frm);
+  hipLaunchKernelGGL(ragged_count_kernel, dim3((unsigned)B), dim3(256), 0, s, kpm_boxes, kpm_frames, (int)T, (int)N, ix.clip_tok, ix.clip_frm, ix.counts);
   if (int e = stlt_check_launch("ragged_count_kernel")) return e;
   hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, s, ix.clip_tok, ix.clip_frm, B, ix.clip_tok_off, ix.clip_frm_off, ix.counts);
   if (int e = stlt_check_launch("ragged_scan_kernel")) return e;
@@ -216,8 +255,14 @@ int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d,
   StltProfScope ps(STLT_K_MISC, s);
   if (!src || !rows || !dst) return stlt_set_error(STLT_EINVAL, "scatter_rows: null pointer");
   if (d % 4) return stlt_set_error(STLT_EINVAL, "scatter_rows: d must be a multiple of 4");
-  if (hipError_t e = hipMemsetAsync(dst, 0, (size_t)dst_rows * d * sizeof(float), s); e != hipSuccess)
-    return stlt_set_error((int)e, "scatter_rows: memset: %s", hipGetErrorString(e));
+  if (dst_rows > 0) {
+    if (((uintptr_t)dst & 15) != 0) return stlt_set_error(STLT_EINVAL, "scatter_rows: dst must be 16-byte aligned");
+    const int64_t n4 = dst_rows * d / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, n4);
+    if (int e = stlt_check_launch("zero_rows_kernel")) return e;
+  }
   if (n == 0) return 0;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, src, rows, n, (int)d, dst);
   return stlt_check_launch("scatter_rows_kernel");

@@ -535,8 +535,17 @@ size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int6
   return scratch_layout(nullptr, B, T, N, d, n_categories).bytes;
 }
 
-// Row counts of the ragged index: one device->host copy + stream synchronisation.
-static int read_ragged_counts(const RaggedIndex& ix, int64_t& Ms, int64_t& Mf, hipStream_t s) {
+// Row counts of the ragged index: the caller's (stlt_inputs.n_real_tokens / n_real_frames, no synchronisation; `pad`: the forward makes the
+// index safe for them, the backward finds it so), else one device->host copy + stream synchronisation.
+static int read_ragged_counts(const RaggedIndex& ix, const stlt_inputs* in, bool pad, int64_t& Ms, int64_t& Mf, bool* from_host, hipStream_t s) {
+  *from_host = in->n_real_tokens > 0 || in->n_real_frames > 0;
+  if (*from_host) {
+    Ms = in->n_real_tokens;
+    Mf = in->n_real_frames;
+    if (pad) return launch_ragged_host_counts(ix, Ms, Mf, in->B * in->T * in->N, in->B * in->T, s);
+    if (Ms <= 0 || Mf <= 0 || Ms > in->B * in->T * in->N || Mf > in->B * in->T || Mf > Ms) return stlt_set_error(STLT_EINVAL, "skip-padding: n_real_tokens / n_real_frames do not fit the batch");
+    return 0;
+  }
   int counts[4] = {0, 0, 0, 0};
   if (hipError_t e = hipMemcpyAsync(counts, ix.counts, sizeof(counts), hipMemcpyDeviceToHost, s); e != hipSuccess)
     return stlt_set_error((int)e, "skip-padding: count read-back: %s", hipGetErrorString(e));
@@ -566,12 +575,13 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
   // launches over the real rows only (ragged.hip); dropout masks are then drawn per compacted row.
   const bool ragged = (flags & STLT_FLAG_SKIP_PADDING) != 0;
   int64_t tok = B * T * N, BT = B * T;
+  bool host_counts = false;
   const RaggedIndex ix = ragged_index_carve(t.ridx, B, T, N);
   if (ragged) {
     if (N > AB_MAX_ROWS || T > AB_MAX_ROWS)  // the reverse sweep would refuse the tape anyway; head dims other than 64 hold a segment's keys in LDS
       return stlt_set_error(STLT_EINVAL, "skip-padding training supports sequences of at most %d tokens (N=%lld, T=%lld)", AB_MAX_ROWS, (long long)N, (long long)T);
     TRY(launch_ragged_index(in->kpm_boxes, in->kpm_frames, in->lengths, B, T, N, ix, s));
-    TRY(read_ragged_counts(ix, tok, BT, s));
+    TRY(read_ragged_counts(ix, in, true, tok, BT, &host_counts, s));
   } else {
     TRY(launch_padded_rows(in->lengths, B, T, N, ix, s));  // rows the tail layers pick: f*N and b*T + lengths-1
   }
@@ -622,7 +632,8 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
   TRY(launch_gelu_fwd(t.u0, t.z1, B * d, s));
   TRY(launch_add_layernorm(t.z1, d, nullptr, 0, p->head_ln_w, p->head_ln_b, p->ln_eps, B, d, t.z2, d, s));
   TRY(launch_linear(t.z2, d, p->fc2_w, p->fc2_b, logits, p->n_classes, B, p->n_classes, d, STLT_ACT_NONE, s));
-  return 0;
+  // the caller's row counts were taken on trust: NaN logits (hence a NaN loss) when they are not the index's or the masks break the contract
+  return host_counts ? launch_ragged_poison(ix, tok, BT, logits, B * p->n_classes, s) : 0;
 }
 
 int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_inputs* in, const void* tape_mem,
@@ -667,7 +678,8 @@ int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_i
   const RaggedIndex ix = ragged_index_carve(t.ridx, B, T, N);  // filled by the forward (ragged index, or the padded layout's picked rows)
   AttnBwdRagged rg_sp{}, rg_tp{};
   if (ragged) {
-    TRY(read_ragged_counts(ix, tok, BT, s));
+    bool host_counts = false;
+    TRY(read_ragged_counts(ix, in, false, tok, BT, &host_counts, s));
     tokp = up32(tok);
     btp = up32(BT);
     if (N > AB_MAX_ROWS || T > AB_MAX_ROWS) return stlt_set_error(STLT_EINVAL, "attention backward supports sequences of at most %d tokens", AB_MAX_ROWS);

@@ -40,6 +40,8 @@ def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[s
     lo, hi = shard_bounds(n, rank, world)
     out = {}
     for k, v in batch.items():
+        if world > 1 and k in ("num_real_tokens", "num_real_frames"):
+            continue  # row counts of the GLOBAL batch (collate.real_counts): a shard reads its own back instead
         if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n:
             out[k] = v[lo:hi]
         elif isinstance(v, (list, tuple)) and len(v) == n:

@@ -167,6 +167,20 @@ def _prep_inputs(batch: Dict[str, torch.Tensor], need_lengths: bool):
     inp.frame_types = take(batch["frame_types"], torch.int64, "frame_types", (B, T))
     inp.kpm_frames = take(batch["src_key_padding_mask_frames"], torch.uint8, "src_key_padding_mask_frames", (B, T))
     inp.lengths = take(batch["lengths"], torch.int64, "lengths", (B,)) if need_lengths else None
+    # optional: the batch's real rows, counted where the masks were made (collate.real_counts on the host).  With them a skip-padding
+    # forward / training step reads nothing back from the device (include/stlt_hip.h: stlt_inputs.n_real_tokens)
+    if "num_real_tokens" in batch or "num_real_frames" in batch:
+        counts = []
+        for key in ("num_real_tokens", "num_real_frames"):
+            v = batch.get(key)
+            if isinstance(v, torch.Tensor):
+                if v.is_cuda:
+                    raise L.StltHipError(f"{key} must be a host integer (a device tensor would have to be read back, which is what it is there to avoid)")
+                v = int(v)
+            if not isinstance(v, int) or v <= 0:
+                raise L.StltHipError("num_real_tokens and num_real_frames come together, as positive host integers")
+            counts.append(v)
+        inp.n_real_tokens, inp.n_real_frames = counts
     return inp, keep, (B, T, N)
 
 

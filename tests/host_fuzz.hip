@@ -202,6 +202,7 @@ void make_model(Model& m, bool with_head) {
   m.in.T = dim(64, 300);
   m.in.N = dim(36, 128);
   m.in.categories = F<int64_t>(110); m.in.boxes = F<float>(111); m.in.scores = coin(2) ? nullptr : FA<float>(112);
+  if (coin(3)) { m.in.n_real_tokens = dim(1 << 16, 1ll << 33); m.in.n_real_frames = dim(1 << 12, 1ll << 31); }  // the caller's row counts for skip-padding
   m.in.kpm_boxes = F<uint8_t>(113); m.in.frame_types = F<int64_t>(114); m.in.kpm_frames = F<uint8_t>(115); m.in.lengths = F<int64_t>(116);
 }
 

@@ -404,3 +404,52 @@ def test_forward_replays_from_a_hip_graph(pkg, name):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(captured, eager_b) and not torch.equal(eager_a, eager_b)
+
+
+def test_skip_padding_with_the_batchs_row_counts_reads_nothing_back_and_replays_from_a_graph(pkg):
+    """Round 6: a batch that carries its two real-row counts (collate.real_counts: what a collater can count where it makes the masks) runs the
+    skip-padding forward without the read-back of those counts — same logits bit for bit, no stream synchronisation inside the call (it
+    captures into a hipGraph and replays on new inputs with the same counts), and counts that are not the masks' give NaN logits instead of
+    touching memory they should not."""
+    name = "cfg1"
+    sd, batch, z, meta = golden_case(name)
+    m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
+    m.load_state_dict(sd, strict=True)
+    m = m.train(False).to(DEV)
+    m.backbone.skip_padding = True
+    counts = pkg.collate.real_counts(batch)
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        plain = m(dev)["stlt"]
+        with_counts = m(dict(dev, **counts))["stlt"]
+        assert torch.equal(plain, with_counts)
+        assert (with_counts.cpu() - torch.from_numpy(z["logits"])).abs().max().item() <= TOL
+        # wrong counts, either way: NaN, not a crash (the index entries up to the caller's counts are made safe, the result is poisoned)
+        for dt, df in ((-3, 0), (5, 0), (0, -1), (7, 2)):
+            bad = dict(dev, num_real_tokens=counts["num_real_tokens"] + dt, num_real_frames=counts["num_real_frames"] + df)
+            assert torch.isnan(m(bad)["stlt"]).all(), (dt, df)
+        again = m(dict(dev, **counts))["stlt"]
+        assert torch.equal(again, plain)
+        with pytest.raises(pkg.StltHipError):
+            m(dict(dev, num_real_tokens=torch.tensor(counts["num_real_tokens"], device=DEV), num_real_frames=counts["num_real_frames"]))
+        # graph capture: only possible because nothing is read back
+        static = {k: v.clone() for k, v in dev.items()}
+        static.update(counts)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(static)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(static)["stlt"]
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain)
+        # new inputs with the same counts: the boxes change, the masks (hence the counts) do not
+        static["boxes"].copy_((dev["boxes"] * 0.5).contiguous())
+        g.replay()
+        torch.cuda.synchronize()
+        ref = m(dict({k: v for k, v in static.items() if k not in counts}))["stlt"]  # eager, with the read-back
+        assert not torch.equal(ref, plain)
+        assert torch.equal(out, ref), float((out - ref).abs().max())
