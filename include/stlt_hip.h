@@ -252,8 +252,12 @@ typedef struct {
   const int64_t* lengths;      /* (B) */
   /* STLT_FLAG_SKIP_PADDING only, optional (0 = unknown): the batch's real rows as the collater can count them on the host —
    * n_real_frames = number of zeros in kpm_frames, n_real_tokens = number of zeros in kpm_boxes inside those frames.  With both given the
-   * call reads nothing back: no stream synchronisation, capturable in a hipGraph (for batches with these counts).  They are verified on the
-   * device: counts that are not the masks', or masks that break the collater contract, give NaN results instead of an error return. */
+   * call reads nothing back: no stream synchronisation, capturable in a hipGraph.  In the inference calls (stlt_forward, stlt_backbone_forward,
+   * stlt_caf_forward_flags) the two numbers may be UPPER BOUNDS: the rows between the real counts and the bounds are computed as
+   * self-contained dummy rows nobody reads, so one captured graph serves every batch whose counts stay below the bounds it was captured
+   * with (a bucket, a percentile of the dataset).  The training calls need the exact counts (a dummy row would leave a gradient).  Either way
+   * they are verified on the device: real counts above the bounds (training: different from them), or masks that break the collater contract,
+   * give NaN results instead of an error return. */
   int64_t n_real_tokens, n_real_frames;
 } stlt_inputs;
 

@@ -60,11 +60,17 @@ class DeviceCollater:
         return out
 
 
-def real_counts(batch) -> dict:
+def real_counts(batch, round_up_to: int = 1) -> dict:
     """{"num_real_tokens", "num_real_frames"} of a collated batch, counted from its masks (on whatever device they live: call it on the host
     side of the loader, where the masks are made — reference datasets.py:274-286): frames = zeros of src_key_padding_mask_frames, tokens =
     zeros of src_key_padding_mask_boxes inside those frames.  Added to the batch as host integers they let a skip-padding forward / training
-    step run without reading its row counts back (include/stlt_hip.h: stlt_inputs.n_real_tokens / n_real_frames)."""
+    step run without reading its row counts back (include/stlt_hip.h: stlt_inputs.n_real_tokens / n_real_frames).  round_up_to > 1 rounds both
+    up to a multiple (capped at the padded sizes): upper bounds, which the inference calls accept."""
     real = ~batch["src_key_padding_mask_frames"].bool()
-    tokens = ((~batch["src_key_padding_mask_boxes"].bool()) & real[:, :, None]).sum()
-    return {"num_real_tokens": int(tokens), "num_real_frames": int(real.sum())}
+    tokens = int(((~batch["src_key_padding_mask_boxes"].bool()) & real[:, :, None]).sum())
+    frames = int(real.sum())
+    if round_up_to > 1:  # inference only: upper bounds are enough, so one captured hipGraph (or one launch plan) serves a bucket of batches
+        B, T, N = batch["src_key_padding_mask_boxes"].shape
+        up = lambda v, cap: min(cap, (v + round_up_to - 1) // round_up_to * round_up_to)  # noqa: E731
+        tokens, frames = up(tokens, B * T * N), up(frames, B * T)
+    return {"num_real_tokens": tokens, "num_real_frames": frames}

@@ -588,8 +588,8 @@ static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* wor
   for (int64_t l = 0; l < tp_full; ++l)
     TRY(encoder_layer_ragged(p->temporal[l], d, H, tbuf, Mf, ix.f_seg_start, ix.f_seg_end, 1, STLT_K_ATTN_TEMPORAL, qkv, ctx, tmp, x, hh, tbuf, s));
   if (out_btd) {
-    TRY(launch_scatter_rows(tbuf, ix.f_orig, Mf, d, out_btd, B * T, s));
-    return host_counts ? launch_ragged_poison(ix, Ms, Mf, out_btd, B * T * d, s) : 0;
+    TRY(launch_scatter_rows(tbuf, ix.f_orig, Mf, d, out_btd, B * T, s, host_counts ? ix.counts + 1 : nullptr));
+    return host_counts ? launch_ragged_poison(ix, Ms, Mf, true, out_btd, B * T * d, s) : 0;
   }
   if (p->n_temporal > 0) {
     const stlt_layer_params& lp = p->temporal[p->n_temporal - 1];
@@ -599,7 +599,9 @@ static int forward_ragged(const stlt_params* p, const stlt_inputs* in, void* wor
   } else {
     TRY(launch_gather_rows(tbuf, d, ix.last_row, B, d, h0, s));
   }
-  return host_counts ? launch_ragged_poison(ix, Ms, Mf, h0, B * d, s) : 0;  // counts that are not the index's: NaN rows for the head, NaN logits
+  // the caller's counts were taken on trust; in inference they may be upper bounds (the rows in between are dummies nobody reads).  Real counts
+  // above them, or masks that break the contract: NaN rows for the head, NaN logits
+  return host_counts ? launch_ragged_poison(ix, Ms, Mf, true, h0, B * d, s) : 0;
 }
 
 // exported to caf.hip (same library, C++ linkage)

@@ -352,7 +352,7 @@ struct RaggedIndex {
 // padded layout: ix.f_cls_row[f] = f*N, ix.last_row[b] = b*T + lengths[b]-1
 int launch_padded_rows(const int64_t* lengths, int64_t B, int64_t T, int64_t N, const RaggedIndex& idx, hipStream_t s);
 int launch_ragged_groups(const RaggedIndex& idx, int64_t n_tokens, int64_t n_frames, int frames_per_group, hipStream_t s);
-int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s);  // dst = 0; dst[rows[i]] = src[i]
+int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s, const int* n_dev = nullptr);  // dst = 0; dst[rows[i]] = src[i] (i < *n_dev when given)
 size_t ragged_index_bytes(int64_t B, int64_t T, int64_t N);
 RaggedIndex ragged_index_carve(void* base, int64_t B, int64_t T, int64_t N);
 int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, const int64_t* lengths, int64_t B, int64_t T,
@@ -360,7 +360,7 @@ int launch_ragged_index(const uint8_t* kpm_boxes, const uint8_t* kpm_frames, con
 int launch_gather_rows(const float* src, int64_t ld, const int* rows, int64_t n, int64_t d, float* out, hipStream_t s);
 // the caller's row counts instead of a read-back: index entries up to the caller's counts made safe, and the result poisoned (NaN) when they are not the index's
 int launch_ragged_host_counts(const RaggedIndex& idx, int64_t n_tok, int64_t n_frm, int64_t max_tok, int64_t max_frm, hipStream_t s);
-int launch_ragged_poison(const RaggedIndex& idx, int64_t n_tok, int64_t n_frm, float* out, int64_t n, hipStream_t s);
+int launch_ragged_poison(const RaggedIndex& idx, int64_t n_tok, int64_t n_frm, bool allow_more, float* out, int64_t n, hipStream_t s);
 // hidden size / head count a model or block may have: any head dim up to 256 (64: the MFMA kernels; others: attn_any.hip); rows are
 // moved 16 bytes at a time (hidden sizes that are not multiples of 32 run their products on gemm_any.hip)
 inline bool stlt_heads_ok(int64_t d, int64_t H) { return d > 0 && H > 0 && d % H == 0 && d / H <= 256 && d % 4 == 0; }

@@ -143,10 +143,10 @@ __global__ __launch_bounds__(256) void ragged_groups_kernel(const int* __restric
 }
 
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, int64_t n, int d,
-                                                           float* __restrict__ dst) {
+                                                           float* __restrict__ dst, const int* __restrict__ n_dev) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
+  if (i >= n || (n_dev && i >= *n_dev)) return;  // n_dev: the real row count on the device, when n is only an upper bound (rows beyond it are dummies)
   float* o = dst + (int64_t)rows[i] * d;
   for (int e = lane * 4; e < d; e += 256) *reinterpret_cast<f32x4*>(o + e) = *reinterpret_cast<const f32x4*>(src + i * d + e);
 }
@@ -176,8 +176,11 @@ __global__ __launch_bounds__(256) void ragged_host_counts_kernel(RaggedIndex ix,
 __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ dst, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) reinterpret_cast<f32x4*>(dst)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-__global__ __launch_bounds__(256) void ragged_poison_kernel(const int* __restrict__ counts, int n_tok, int n_frm, float* __restrict__ out, int64_t n) {
-  if (counts[0] == n_tok && counts[1] == n_frm && counts[2] == 0) return;
+// allow_more: the caller's counts are upper bounds (inference: the rows between the real counts and the bounds are self-contained dummy rows
+// nobody reads); else they must be the index's own (training: a dummy row would leave a gradient)
+__global__ __launch_bounds__(256) void ragged_poison_kernel(const int* __restrict__ counts, int n_tok, int n_frm, int allow_more, float* __restrict__ out, int64_t n) {
+  const bool ok = allow_more ? (counts[0] <= n_tok && counts[1] <= n_frm) : (counts[0] == n_tok && counts[1] == n_frm);
+  if (ok && counts[2] == 0) return;
   const float nan = __int_as_float(0x7fc00000);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = nan;
 }
@@ -192,12 +195,12 @@ int launch_ragged_host_counts(const RaggedIndex& ix, int64_t n_tok, int64_t n_fr
   hipLaunchKernelGGL(ragged_host_counts_kernel, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, s, ix, (int)n_tok, (int)n_frm);
   return stlt_check_launch("ragged_host_counts_kernel");
 }
-int launch_ragged_poison(const RaggedIndex& ix, int64_t n_tok, int64_t n_frm, float* out, int64_t n, hipStream_t s) {
+int launch_ragged_poison(const RaggedIndex& ix, int64_t n_tok, int64_t n_frm, bool allow_more, float* out, int64_t n, hipStream_t s) {
   if (!out || n <= 0) return 0;
   StltProfScope ps(STLT_K_MISC, s);
   int64_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(ragged_poison_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ix.counts, (int)n_tok, (int)n_frm, out, n);
+  hipLaunchKernelGGL(ragged_poison_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ix.counts, (int)n_tok, (int)n_frm, allow_more ? 1 : 0, out, n);
   return stlt_check_launch("ragged_poison_kernel");
 }
 
@@ -251,7 +254,7 @@ int launch_ragged_groups(const RaggedIndex& ix, int64_t n_tokens, int64_t n_fram
   return stlt_check_launch("ragged_groups_kernel");
 }
 
-int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s) {
+int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d, float* dst, int64_t dst_rows, hipStream_t s, const int* n_dev) {
   StltProfScope ps(STLT_K_MISC, s);
   if (!src || !rows || !dst) return stlt_set_error(STLT_EINVAL, "scatter_rows: null pointer");
   if (d % 4) return stlt_set_error(STLT_EINVAL, "scatter_rows: d must be a multiple of 4");
@@ -264,7 +267,7 @@ int launch_scatter_rows(const float* src, const int* rows, int64_t n, int64_t d,
     if (int e = stlt_check_launch("zero_rows_kernel")) return e;
   }
   if (n == 0) return 0;
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, src, rows, n, (int)d, dst);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, src, rows, n, (int)d, dst, n_dev);
   return stlt_check_launch("scatter_rows_kernel");
 }
 

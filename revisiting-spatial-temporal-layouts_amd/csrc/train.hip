@@ -633,7 +633,7 @@ int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape_m
   TRY(launch_add_layernorm(t.z1, d, nullptr, 0, p->head_ln_w, p->head_ln_b, p->ln_eps, B, d, t.z2, d, s));
   TRY(launch_linear(t.z2, d, p->fc2_w, p->fc2_b, logits, p->n_classes, B, p->n_classes, d, STLT_ACT_NONE, s));
   // the caller's row counts were taken on trust: NaN logits (hence a NaN loss) when they are not the index's or the masks break the contract
-  return host_counts ? launch_ragged_poison(ix, tok, BT, logits, B * p->n_classes, s) : 0;
+  return host_counts ? launch_ragged_poison(ix, tok, BT, false, logits, B * p->n_classes, s) : 0;
 }
 
 int stlt_train_backward(const stlt_params* p, const stlt_params* g, const stlt_inputs* in, const void* tape_mem,

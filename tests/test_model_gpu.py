@@ -408,10 +408,11 @@ def test_forward_replays_from_a_hip_graph(pkg, name):
 
 def test_skip_padding_with_the_batchs_row_counts_reads_nothing_back_and_replays_from_a_graph(pkg):
     """Round 6: a batch that carries its two real-row counts (collate.real_counts: what a collater can count where it makes the masks) runs the
-    skip-padding forward without the read-back of those counts — same logits bit for bit, no stream synchronisation inside the call (it
-    captures into a hipGraph and replays on new inputs with the same counts), and counts that are not the masks' give NaN logits instead of
-    touching memory they should not."""
+    skip-padding forward without the read-back of those counts — same logits bit for bit, no stream synchronisation inside the call.  In
+    inference the counts may be UPPER BOUNDS (the rows in between are dummy rows nobody reads): one captured hipGraph then replays over
+    batches of different raggedness.  Real counts above the caller's give NaN logits instead of touching memory they should not."""
     name = "cfg1"
+    c = pkg.synth.CONFIGS[name]
     sd, batch, z, meta = golden_case(name)
     m = pkg.Stlt(pkg.StltModelConfig(**pkg.synth.model_kwargs(name)))
     m.load_state_dict(sd, strict=True)
@@ -424,17 +425,27 @@ def test_skip_padding_with_the_batchs_row_counts_reads_nothing_back_and_replays_
         with_counts = m(dict(dev, **counts))["stlt"]
         assert torch.equal(plain, with_counts)
         assert (with_counts.cpu() - torch.from_numpy(z["logits"])).abs().max().item() <= TOL
-        # wrong counts, either way: NaN, not a crash (the index entries up to the caller's counts are made safe, the result is poisoned)
-        for dt, df in ((-3, 0), (5, 0), (0, -1), (7, 2)):
+        # upper bounds: dummy rows are computed and never read (other launch shapes: rounding may differ, nothing else)
+        for dt, df in ((5, 0), (7, 2), (64, 16)):
+            more = dict(dev, num_real_tokens=counts["num_real_tokens"] + dt, num_real_frames=counts["num_real_frames"] + df)
+            got = m(more)["stlt"]
+            assert torch.isfinite(got).all() and (got - plain).abs().max().item() <= 2e-5, (dt, df)
+        # real counts ABOVE the caller's: NaN, not a crash
+        for dt, df in ((-3, 0), (0, -1), (-40, -5)):
             bad = dict(dev, num_real_tokens=counts["num_real_tokens"] + dt, num_real_frames=counts["num_real_frames"] + df)
             assert torch.isnan(m(bad)["stlt"]).all(), (dt, df)
-        again = m(dict(dev, **counts))["stlt"]
-        assert torch.equal(again, plain)
+        assert torch.equal(m(dict(dev, **counts))["stlt"], plain)
         with pytest.raises(pkg.StltHipError):
             m(dict(dev, num_real_tokens=torch.tensor(counts["num_real_tokens"], device=DEV), num_real_frames=counts["num_real_frames"]))
-        # graph capture: only possible because nothing is read back
+        # one captured graph for a BUCKET of batches: bounds = the counts rounded up to a multiple of 64
+        B = batch["categories"].shape[0]
+        other = pkg.synth.make_batch(B, c["T"], c["N"], dataset=c["dataset"], seed=4242)  # same shape, other lengths / object counts
+        ca, cb = pkg.collate.real_counts(batch, round_up_to=64), pkg.collate.real_counts(other, round_up_to=64)
+        bound = {k: max(ca[k], cb[k]) for k in ca}
+        assert pkg.collate.real_counts(other) != counts
         static = {k: v.clone() for k, v in dev.items()}
-        static.update(counts)
+        static.update(bound)
+        eager_a = m(static)["stlt"].clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -443,13 +454,15 @@ def test_skip_padding_with_the_batchs_row_counts_reads_nothing_back_and_replays_
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = m(static)["stlt"]
+        for _ in range(3):  # (the second replay is the one a misordered memset node broke)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager_a)
+        assert (out - plain).abs().max().item() <= 2e-5
+        for k, v in other.items():
+            static[k].copy_(v.to(DEV))
         g.replay()
         torch.cuda.synchronize()
-        assert torch.equal(out, plain)
-        # new inputs with the same counts: the boxes change, the masks (hence the counts) do not
-        static["boxes"].copy_((dev["boxes"] * 0.5).contiguous())
-        g.replay()
-        torch.cuda.synchronize()
-        ref = m(dict({k: v for k, v in static.items() if k not in counts}))["stlt"]  # eager, with the read-back
-        assert not torch.equal(ref, plain)
-        assert torch.equal(out, ref), float((out - ref).abs().max())
+        eager_b = m(dict({k: v.to(DEV) for k, v in other.items()}, **bound))["stlt"]
+        ref_b = m({k: v.to(DEV) for k, v in other.items()})["stlt"]  # with the read-back
+        assert torch.equal(out, eager_b) and (out - ref_b).abs().max().item() <= 2e-5 and not torch.equal(eager_a, eager_b)
