@@ -131,3 +131,20 @@ def test_train_mode_two_rank_launch_line():
     assert "all-reduce" in j["config"]["parallelism"] and "cpu_baseline" not in j
     assert j["ranks"]["world_size"] == 2 and len(j["ranks"]["ms_per_step_by_rank"]) == 2
     assert j["allreduce"]["ms_per_step_without_allreduce"] > 0  # the same steps without the gradient exchange, for the exposed time
+
+
+@pytest.mark.parametrize("mode", ["forward", "train"])
+def test_launch_bound_tool_prices_every_launch(mode):
+    """tools/launch_bound.py (event-timed form; the rocprofv3 form is tools/collect_launch_bound.sh): one row per launch with the launcher's note,
+    a bound and a ratio, and the step's sums."""
+    r = subprocess.run([sys.executable, "tools/launch_bound.py", "--config", "cfg2", "--batch", "8", "--steps", "2", "--warmup", "3", "--mode", mode], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.splitlines() if l.strip() and l.strip()[0].isdigit()]
+    assert len(rows) >= (80 if mode == "forward" else 150), len(rows)
+    assert all(float(x[3]) > 0 for x in rows) and sum(x[2] != "-" for x in rows) >= len(rows) - 4
+    notes = r.stdout
+    assert "gemm16" in notes and "add_ln rows=" in notes and "M=" in notes and "ksteps=" in notes
+    assert "(skinny)" in notes  # 8 clips: the one-row-per-clip tail runs as split-k partial tiles
+    step = [l for l in r.stdout.splitlines() if l.startswith("# step:")][0]
+    assert "achieved / bound" in step
