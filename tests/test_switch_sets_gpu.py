@@ -21,11 +21,12 @@ SWITCH_SETS = {
 # logits vs the reference goldens (every config, both schedules, skip-padding), gradients vs the fp64 oracle, the reference-captured
 # optimisation steps, the epoch shell, the fusion models' goldens and gradients
 SUBSET = ["tests/test_model_gpu.py", "tests/test_fit_epochs.py", "tests/test_ckpt_roundtrip.py", "tests/test_caf.py",
-          "tests/test_train_gpu.py::test_gradients_match_oracle_autograd", "tests/test_train_gpu.py::test_three_training_steps_match_reference_golden",
-          "tests/test_train_gpu.py::test_dropout_forward_and_gradients_match_masked_oracle", "tests/test_train_gpu.py::test_trainer_fused_and_stock_optimizer_agree"]
+          "tests/test_train_gpu.py::test_gradients_match_oracle_autograd", "tests/test_train_gpu.py::test_three_training_steps_match_reference_golden"]
 DESELECT = ["tests/test_model_gpu.py::test_bench_sized_launches_reproduce_the_golden_rows",  # spawns its own children; minutes, not seconds
-            "tests/test_train_gpu.py::test_gradients_match_oracle_autograd[cfg4-2-True-True]",  # 10 s each: the fp64 oracle's autograd at cfg4
+            "tests/test_train_gpu.py::test_gradients_match_oracle_autograd[cfg4-2-True-True]",  # 10 s each: the fp64 oracle's autograd at cfg4 ...
             "tests/test_train_gpu.py::test_gradients_match_oracle_autograd[cfg4-2-True-False]",
+            "tests/test_train_gpu.py::test_gradients_match_oracle_autograd[cfg2-2-False-True]",  # ... 3 s each at cfg2 (cfg1's four cases stay)
+            "tests/test_train_gpu.py::test_gradients_match_oracle_autograd[cfg2-2-False-False]",
             "tests/test_model_gpu.py::test_matches_oracle_on_fresh_seed_with_scores_absent_and_present"]
 
 
@@ -39,5 +40,5 @@ def test_parity_subset_under_a_non_default_switch_set(name):
     tail = r.stdout[-3000:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
     last = [l for l in r.stdout.splitlines() if " passed" in l][-1]
-    assert " failed" not in last and int(last.split(" passed")[0].split()[-1]) >= 40, last
+    assert " failed" not in last and int(last.split(" passed")[0].split()[-1]) >= 35, last
     print(f"[{name}] {last}")
