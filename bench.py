@@ -33,6 +33,7 @@ PKG = "revisiting-spatial-temporal-layouts_amd"
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X f32-input MFMA dense peak (MI355X_MICROARCH.md, Chip-level parameters)
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak
+CPU_BASELINE_BUDGET_S = float(os.environ.get("STLT_BENCH_CPU_BUDGET_S", "10"))  # seconds of CPU work of the cpu_baseline leg (the test suite shortens it)
 
 
 def gemm_flops_per_step(B, T, N, d, n_sp, n_tp, classes, cls_only, fused_tp_layers=0, fused_sp_layers=0):
@@ -553,7 +554,7 @@ def bench_train(args, pkg, torch, dist, rank, world, dev, one_gpu, pin=None):
             cands = sorted({t for t in (8, 16, 32, default_threads) if 0 < t <= cores})
             probe = {t: cpu_rate(t, 0.0, 1)[0] for t in cands}
             best = max(probe, key=probe.get)
-            rate, n_it = cpu_rate(best, 10.0, 2)
+            rate, n_it = cpu_rate(best, CPU_BASELINE_BUDGET_S, 2)
             torch.set_num_threads(default_threads)
             out["cpu_baseline"] = {"value": round(rate, 2), "unit": "clips/s", "cores": best, "kind": "port",
                                    "sample": f"oracle/stlt_oracle.py under torch autograd + clip_grad_norm_ + torch.optim.AdamW (torch {torch.__version__} "
@@ -835,7 +836,7 @@ def leg_cpu_baseline(ctx, x3):
         cands = sorted({t for t in (8, 16, 32, 64, default_threads) if 0 < t <= cores})
         probe = {t: cpu_rate(t, 0.0, 1)[0] for t in cands}
         best = max(probe, key=probe.get)
-        rate, n_it = cpu_rate(best, 10.0, 2)
+        rate, n_it = cpu_rate(best, CPU_BASELINE_BUDGET_S, 2)
         with torch.no_grad():
             ref = O.stlt_forward(ctx.sd, sample, c["num_attention_heads"])["stlt"]  # parity sample
         torch.set_num_threads(default_threads)

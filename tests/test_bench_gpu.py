@@ -37,7 +37,7 @@ def _last_json(stdout: str, with_legs=False):
 
 def test_single_process_line():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "64"], cwd=ROOT, capture_output=True, text=True,
-                       timeout=600)
+                       timeout=600, env=dict(os.environ, STLT_BENCH_CPU_BUDGET_S="2"))
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "clips/s" and j["scaling"] == "weak"
@@ -108,7 +108,7 @@ def test_two_rank_launch_line():
 
 def test_train_mode_single_process_line():
     r = subprocess.run([sys.executable, "bench.py", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "8"], cwd=ROOT,
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, STLT_BENCH_CPU_BUDGET_S="2"))
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     assert REQUIRED <= set(j) and j["n_gpus"] == 1 and j["value"] > 0 and "train step" in j["metric"]
