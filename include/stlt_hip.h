@@ -264,7 +264,8 @@ typedef struct {
 #define STLT_FLAG_CLS_ONLY_LAST_SPATIAL 1 /* last spatial layer: Q/out-proj/FFN on the CLS rows only (the only rows read, models.py:79) */
 #define STLT_FLAG_SKIP_PADDING 4 /* stlt_forward with out_btd == NULL: compute the real (unmasked) tokens and frames only.  Same logits: a padded row is
                                    masked as a key everywhere and never read as a query result.  Implies both flags above.  Needs collater-shaped
-                                   masks (slot 0 of a real frame unmasked, frame lengths-1 real); synchronises the stream once per call. */
+                                   masks (slot 0 of a real frame unmasked, frame lengths-1 real); synchronises the stream once per call unless stlt_inputs carries
+                                   the batch's two row counts (n_real_tokens / n_real_frames). */
 #define STLT_FLAG_TRAIN_UPPER_ONLY 8   /* stlt_train_backward: stop after the prediction head and the temporal tower (their gradients are final) */
 #define STLT_FLAG_TRAIN_LOWER_ONLY 16  /* stlt_train_backward: resume from there (frames embeddings, spatial tower, token embeddings); the scratch must be
                                           untouched in between.  Lets a data-parallel caller all-reduce the upper gradients while the lower half runs. */
@@ -325,7 +326,7 @@ int stlt_caf_forward(const stlt_caf_params* p, const stlt_inputs* in, const floa
 /* The same with STLT_FLAG_SKIP_PADDING accepted in `flags`: the layout branch runs on the real tokens / frames only (the
  * collater's masks, as for stlt_forward); padded frames' rows of the (B,T,d) layout state are zero — downstream they are
  * only masked keys (models.py:403-431) — so the logits are those of the padded schedule to rounding.  Like stlt_forward
- * with that flag it synchronises the stream once (two row counts are read back to size the launches). */
+ * with that flag it synchronises the stream once (two row counts are read back to size the launches) unless stlt_inputs carries them. */
 int stlt_caf_forward_flags(const stlt_caf_params* p, const stlt_inputs* in, const float* appearance_features, void* workspace,
                            size_t workspace_bytes, int flags, float* logits_caf, float* logits_stlt, float* logits_resnet3d,
                            float* logits_ensemble, stlt_stream_t stream);
@@ -360,7 +361,7 @@ size_t stlt_train_scratch_bytes(int64_t B, int64_t T, int64_t N, int64_t d, int6
 /* flags: 0, or STLT_FLAG_SKIP_PADDING (the same value in both calls of a step): forward and reverse sweep run over the
  * real tokens / frames only — same loss and gradients when dropout is off; with dropout the masks are drawn per
  * compacted row, i.e. a different (equally valid) random stream than the padded schedule's.  Each call then
- * synchronises the stream once. */
+ * synchronises the stream once, unless stlt_inputs carries the batch's exact row counts (n_real_tokens / n_real_frames). */
 int stlt_train_forward(const stlt_params* p, const stlt_inputs* in, void* tape, size_t tape_bytes, float* logits,
                        float dropout_p, uint64_t dropout_seed, int flags, stlt_stream_t stream);
 int stlt_train_backward(const stlt_params* p, const stlt_params* grads, const stlt_inputs* in, const void* tape,
