@@ -18,3 +18,4 @@ one cfg2p_b64 "--config cfg2p --batch 64"
 one cfg2_b64 "--config cfg2 --batch 64"
 one train_b64 "--config cfg2 --batch 64 --mode train"
 one cacnf_train_b64 "--config cfg2 --batch 64 --mode cacnf_train --steps 10"
+one cfg2_b1024 "--config cfg2 --batch 1024 --steps 10 --warmup 3"   # the headline forward, for reference
