@@ -71,6 +71,56 @@ def test_embed(pkg, d, C, with_scores):
     assert (got.double() - ref).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("d,with_scores", [(64, True), (512, False), (768, True), (1024, True)])
+def test_embed_of_many_tokens_is_bit_identical_to_the_per_token_kernel(pkg, d, with_scores):
+    """Round 6: from STLT_EMBED_ROWS tokens (32 768) a wave embeds 8 consecutive tokens with the parameters in registers
+    (rowwise.hip embed_rows_kernel); below it one token per wave.  Same rows from either, and the oracle's on a sample.
+    The token count is not a multiple of the 32 tokens of a workgroup: the last wave holds 5 tokens."""
+    C, n = 9, 32768 + 8 * 3 + 5
+    g = torch.Generator().manual_seed(21)
+    cats = torch.randint(0, C, (1, n, 1), generator=g)
+    boxes = torch.rand(1, n, 1, 4, generator=g)
+    scores = torch.rand(1, n, 1, generator=g)
+    sd = {"category_embeddings.weight": _rand(C, d, seed=8), "box_embedding.weight": _rand(d, 4, seed=9, scale=0.5),
+          "box_embedding.bias": _rand(d, seed=10, scale=0.5), "score_embeddings.weight": _rand(d, 1, seed=11),
+          "score_embeddings.bias": _rand(d, seed=12, scale=0.5), "layer_norm.weight": 1 + _rand(d, seed=13, scale=0.1),
+          "layer_norm.bias": _rand(d, seed=14, scale=0.1)}
+    D = {k: v.to(DEV) for k, v in sd.items()}
+
+    def run(lo, hi):
+        return pkg.ops.embed(cats[:, lo:hi].contiguous().to(DEV), boxes[:, lo:hi].contiguous().to(DEV),
+                             scores[:, lo:hi].contiguous().to(DEV) if with_scores else None, D["category_embeddings.weight"],
+                             D["box_embedding.weight"], D["box_embedding.bias"], D["score_embeddings.weight"],
+                             D["score_embeddings.bias"], D["layer_norm.weight"], D["layer_norm.bias"], 1e-12)
+
+    whole = run(0, n)
+    assert whole.shape == (1, n, 1, d)
+    for lo, hi in ((0, 4096), (16384, 16384 + 999), (n - 2048, n)):  # per-token kernel: fewer than 32 768 tokens per call
+        assert torch.equal(whole[:, lo:hi], run(lo, hi)), (lo, hi)
+    batch = {"categories": cats[:, n - 300:], "boxes": boxes[:, n - 300:]}
+    if with_scores:
+        batch["scores"] = scores[:, n - 300:]
+    ref = O.category_box_embeddings({k: v.double() for k, v in sd.items()}, "", batch, 1e-12)
+    assert (whole[:, n - 300:].cpu().double() - ref).abs().max().item() <= 2e-5
+
+
+def test_dpp_wave_sum_is_the_butterfly_sum_bit_for_bit(tmp_path):
+    """Round 6: the LayerNorm reductions of rowwise.hip run on v_permlane32_swap / v_permlane16_swap / DPP instead of six ds_bpermute
+    steps (csrc/wave_dpp.h).  tools/wave_sum_check.hip runs both on 2^20 values of mixed magnitude: same bits in every lane."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wave_sum_check")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-I", os.path.join(root, "revisiting-spatial-temporal-layouts_amd", "csrc"),
+                    os.path.join(root, "tools", "wave_sum_check.hip"), "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert '"mismatches": 0' in r.stdout
+
+
 def _attn_ref(qkv, kpm, causal, H):
     S, L, _ = qkv.shape
     masked = kpm[:, None, :].expand(S, L, L).clone()

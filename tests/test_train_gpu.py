@@ -80,6 +80,41 @@ def _check_gradients(pkg, name, B, with_scores, skip_padding, T=None, N=None):
     assert m.backbone.frames_embeddings.layout_embedding.category_box_embeddings.category_embeddings.weight.grad[0].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("skip_padding", [False, True])
+def test_training_pass_over_more_than_32768_tokens_agrees_with_its_two_halves(pkg, skip_padding):
+    """Round 6: from 32 768 tokens the embedding runs 8 tokens per wave (rowwise.hip embed_rows_kernel), also when it writes the training
+    tape's pre-LayerNorm rows and when it reads the ragged index.  cfg2's widths with one layer per tower, 148 clips x 224 tokens: the
+    logits of the whole batch are those of its halves (each below the threshold) and the gradients are their mean."""
+    c = pkg.synth.CONFIGS["cfg2"]
+    B = 148
+    assert B * c["T"] * c["N"] >= 32768 > (B // 2) * c["T"] * c["N"]
+    m = pkg.Stlt(pkg.StltModelConfig(num_classes=c["num_classes"], unique_categories=4, hidden_size=c["hidden_size"],
+                                     num_attention_heads=c["num_attention_heads"], num_spatial_layers=1, num_temporal_layers=1,
+                                     hidden_dropout_prob=0.0))
+    m.load_state_dict(pkg.synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=31, gain=1.5))
+    m.train(True)
+    m.to(DEV)
+    m.backbone.skip_padding = skip_padding
+    batch = {k: v.to(DEV) for k, v in pkg.synth.make_batch(B, c["T"], c["N"], dataset=c["dataset"], seed=77, with_scores=True).items()}
+    labels = torch.randint(0, c["num_classes"], (B,), generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def run(lo, hi):
+        m.zero_grad(set_to_none=True)
+        out = m({k: v[lo:hi].contiguous() for k, v in batch.items()})["stlt"]
+        F.cross_entropy(out, labels[lo:hi]).backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    out, g = run(0, B)
+    out_a, g_a = run(0, B // 2)
+    out_b, g_b = run(B // 2, B)
+    assert (out - torch.cat([out_a, out_b])).abs().max().item() <= 2e-5
+    assert set(g) == set(g_a) == set(g_b)
+    for k in g:
+        mean = 0.5 * (g_a[k] + g_b[k])
+        scale = max(mean.abs().max().item(), 1e-6)
+        assert (g[k] - mean).abs().max().item() / scale <= 2e-4, k
+
+
 def test_backward_is_bitwise_reproducible_and_accumulates(pkg):
     name = "cfg1"
     c = pkg.synth.CONFIGS[name]
