@@ -60,7 +60,12 @@ struct Mhsa16Args {
   StltDrop dr; uint32_t site;
 };
 
-template <int NKB, bool CAUSAL, bool TRAIN>
+// WINDOW (round 6; non-causal launches whose sequences are not 16-row aligned, i.e. the spatial tower's frames of 5 - 8 objects): the key
+// rows of a query block are read as 16-row blocks starting AT the first row of its first query's sequence instead of at the 16-row block
+// holding that row.  The keys a block of 16 queries of 7-token frames can see span at most 28 rows: 2 blocks from the sequence's first row,
+// 3 from the aligned block (20 -> 15 key blocks per 126-row item, NKB 3 -> 2).  The LDS tiles are swizzled by (row & 15) and a block is 16
+// consecutive rows wherever it starts, so the reads stay conflict-free; rows past the 128-row tile are masked (and clamped for V).
+template <int NKB, bool CAUSAL, bool TRAIN, bool WINDOW>
 __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -310,27 +315,30 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
         for (int t = 0; t < 12; ++t) *reinterpret_cast<f32x4*>(qrow + (t >> 2) * d + (t & 3) * 16) = acc[t];
       }
     }
-    // key blocks of this query block: from the block holding the first row of its first query's sequence ...
+    // key rows of this query block: from the first row of its first query's sequence (WINDOW) or the 16-row block holding it ...
     const int blk_row0 = rb * 16;
     const bool blk_ok = blk_row0 < rows_here;  // wave-uniform
-    const int first_kb = ((blk_row0 / L) * L) >> 4;
-    int last_kb = rb;  // ... to its own block (causal), or to the block holding the last row of its last query's sequence
+    const int seq_row0 = (blk_row0 / L) * L;
+    const int k0 = WINDOW ? seq_row0 : (seq_row0 & ~15);
+    int last_row = blk_row0 + 15;  // ... to its own block (causal), or to the last row of its last query's sequence
     if (!CAUSAL) {
       const int r_last = blk_row0 + 15 < rows_here ? blk_row0 + 15 : rows_here - 1;
-      last_kb = ((r_last / L + 1) * L - 1) >> 4;
+      last_row = (r_last / L + 1) * L - 1;
     }
+    const int n_kb = ((last_row - k0) >> 4) + 1;  // key blocks i = 0 .. n_kb - 1 hold rows k0 + 16 i .. + 15
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // attention barrier 1: every wave's K / V rows and metadata are in LDS
     f32x4 st[NKB];
 #pragma unroll
     for (int i = 0; i < NKB; ++i) {
       st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int kb = first_kb + i;
-      if (blk_ok && kb <= last_kb) {
-        const float* krow = Kt + (kb * 16 + li) * 64;
+      if (blk_ok && i < n_kb) {
+        const int krow_i = k0 + 16 * i + li;  // WINDOW: may lie past the tile's 128 rows (still inside the stage): masked below
+        const float* krow = Kt + krow_i * 64;
+        const int ksw = WINDOW ? (krow_i & 15) : li;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-          const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + (((cb * 4 + lg) ^ li) * 4));
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + (((cb * 4 + lg) ^ ksw) * 4));
 #pragma unroll
           for (int r = 0; r < 4; ++r) st[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[r], acc[cb][r], st[i], 0, 0, 0);
         }
@@ -339,14 +347,20 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // attention barrier 2: the K tile is read (the loaders may refill its stage); q, k, v accumulators are dead
     if (blk_ok) {
-      // mask + softmax: st[i][r] = score of key (first_kb + i) * 16 + 4 lg + r against query li
+      // mask + softmax: st[i][r] = score of key k0 + 16 i + 4 lg + r against query li
       float m = -1e30f;
 #pragma unroll
       for (int i = 0; i < NKB; ++i) {
-        const int kb = first_kb + i;
-        if (kb <= last_kb) {
-          const int4 km = *reinterpret_cast<const int4*>(kmeta + kb * 16 + 4 * lg);
-          const int meta[4] = {km.x, km.y, km.z, km.w};
+        if (i < n_kb) {
+          const int j0 = k0 + 16 * i + 4 * lg;
+          int meta[4];
+          if (WINDOW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) meta[r] = j0 + r < FM ? kmeta[j0 + r] : -1;
+          } else {
+            const int4 km = *reinterpret_cast<const int4*>(kmeta + j0);
+            meta[0] = km.x; meta[1] = km.y; meta[2] = km.z; meta[3] = km.w;
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = (meta[r] >= 0) & ((meta[r] >> 8) == q_seq) & (!CAUSAL || (meta[r] & 0xff) <= q_pos);
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < NKB; ++i) {
-        if (first_kb + i <= last_kb) {
+        if (i < n_kb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = st[i][r] > -1e29f ? __expf(st[i][r] - m) : 0.f;
@@ -377,19 +391,19 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
       // the sequence's first row; masked keys have probability 0 either way)
       const uint64_t drop_key = TRAIN ? stlt_drop_key(a.dr, a.site) : 0ull;
       const uint64_t qidx = (((uint64_t)(row0 + my_row)) * H + head) << 8;
-      // Oᵀ[channel][query] += Vᵀ·Pᵀ: MFMA step (i, r) sums keys (first_kb + i) * 16 + 4 g + r over g
+      // Oᵀ[channel][query] += Vᵀ·Pᵀ: MFMA step (i, r) sums keys k0 + 16 i + 4 g + r over g
       f32x4 o[4];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) o[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < NKB; ++i) {
-        const int kb = first_kb + i;
-        if (kb <= last_kb) {
+        if (i < n_kb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int j = kb * 16 + 4 * lg + r;
+            const int j_key = k0 + 16 * i + 4 * lg + r;
+            const int j = (WINDOW && j_key > FM - 1) ? FM - 1 : j_key;  // a row past the tile has probability 0: read a finite V row for it
             float pr = st[i][r];
-            if (TRAIN && a.dr.thr) pr = stlt_keep_k(a.dr.thr, drop_key, qidx | (uint64_t)((j - q_seq * L) & 0xff)) ? pr * a.dr.scale : 0.f;
+            if (TRAIN && a.dr.thr) pr = stlt_keep_k(a.dr.thr, drop_key, qidx | (uint64_t)((j_key - q_seq * L) & 0xff)) ? pr * a.dr.scale : 0.f;
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
               const float vv = Vt[j * 64 + (((cb * 4 + (li >> 2)) ^ (j & 15)) * 4) + (li & 3)];
@@ -417,26 +431,43 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
   }
 }
 
-// largest number of 16-key blocks a 16-query block of an item needs (host side; the kernel's NKB)
-static int mhsa16_key_blocks(int L, int rows_per_item, bool causal) {
-  int worst = 1;
+// largest number of 16-key blocks a 16-query block of an item needs (host side; the kernel's NKB); window: blocks counted from the first
+// row of the block's first sequence instead of from the 16-row block holding it
+static int mhsa16_key_blocks_as(int L, int rows_per_item, bool causal, bool window, int* total = nullptr) {
+  int worst = 1, sum = 0;
   for (int b = 0; b * 16 < rows_per_item; ++b) {
-    const int first_kb = ((b * 16 / L) * L) >> 4;
-    int last_kb = b;
+    const int seq_row0 = (b * 16 / L) * L;
+    const int k0 = window ? seq_row0 : (seq_row0 & ~15);
+    int last_row = b * 16 + 15;
     if (!causal) {
       const int r_last = b * 16 + 15 < rows_per_item ? b * 16 + 15 : rows_per_item - 1;
-      last_kb = ((r_last / L + 1) * L - 1) >> 4;
+      last_row = (r_last / L + 1) * L - 1;
     }
-    if (last_kb - first_kb + 1 > worst) worst = last_kb - first_kb + 1;
+    const int n = ((last_row - k0) >> 4) + 1;
+    if (n > worst) worst = n;
+    sum += n;
   }
+  if (total) *total = sum;
   return worst;
 }
+// STLT_MHSA_WINDOW=0: aligned key blocks everywhere (A/B runs); default: the window form where an item needs fewer key blocks with it
+// (non-causal only; the window never needs more per query block)
+static bool mhsa16_window(int L, int rows_per_item, bool causal) {
+  static const int on = [] { const char* e = getenv("STLT_MHSA_WINDOW"); return e ? atoi(e) : 1; }();
+  if (!on || causal) return false;
+  int total_w = 0, total_a = 0;
+  const int worst_w = mhsa16_key_blocks_as(L, rows_per_item, false, true, &total_w), worst_a = mhsa16_key_blocks_as(L, rows_per_item, false, false, &total_a);
+  return worst_w <= worst_a && total_w < total_a;
+}
+static int mhsa16_key_blocks(int L, int rows_per_item, bool causal) {
+  return mhsa16_key_blocks_as(L, rows_per_item, causal, mhsa16_window(L, rows_per_item, causal));
+}
 
-template <int NKB, bool CAUSAL, bool TRAIN>
+template <int NKB, bool CAUSAL, bool TRAIN, bool WINDOW>
 static int launch_mhsa16_as(const Mhsa16Args& a, hipStream_t s) {
   static StltPerDeviceOnce attr_done;
   if (!attr_done.flag()) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)mhsa16_kernel<NKB, CAUSAL, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM * (int)sizeof(float)); e != hipSuccess)
+    if (hipError_t e = hipFuncSetAttribute((const void*)mhsa16_kernel<NKB, CAUSAL, TRAIN, WINDOW>, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM * (int)sizeof(float)); e != hipSuccess)
       return stlt_set_error((int)e, "mhsa16: %s", hipGetErrorString(e));
     attr_done.flag() = true;
   }
@@ -455,18 +486,18 @@ static int launch_mhsa16_as(const Mhsa16Args& a, hipStream_t s) {
   const int want_sets = env_sets ? env_sets : (CAUSAL ? 2 : 1);
   b.head_sets = 1;
   if ((want_sets == 2 || want_sets == 4) && (G & 7) == 0 && a.H % want_sets == 0 && n_items >= 4 * G && a.n_groups >= 8) b.head_sets = want_sets;
-  hipLaunchKernelGGL((mhsa16_kernel<NKB, CAUSAL, TRAIN>), dim3((unsigned)G), dim3(F_THREADS), G_SMEM * sizeof(float), s, b);
+  hipLaunchKernelGGL((mhsa16_kernel<NKB, CAUSAL, TRAIN, WINDOW>), dim3((unsigned)G), dim3(F_THREADS), G_SMEM * sizeof(float), s, b);
   return stlt_check_launch("mhsa16_kernel");
 }
 
-template <bool CAUSAL, bool TRAIN>
+template <bool CAUSAL, bool TRAIN, bool WINDOW>
 static int launch_mhsa16_nkb(int nkb, const Mhsa16Args& a, hipStream_t s) {
   switch (nkb) {
-    case 1: return launch_mhsa16_as<1, CAUSAL, TRAIN>(a, s);
-    case 2: return launch_mhsa16_as<2, CAUSAL, TRAIN>(a, s);
-    case 3: return launch_mhsa16_as<3, CAUSAL, TRAIN>(a, s);
-    case 4: return launch_mhsa16_as<4, CAUSAL, TRAIN>(a, s);
-    default: return launch_mhsa16_as<5, CAUSAL, TRAIN>(a, s);
+    case 1: return launch_mhsa16_as<1, CAUSAL, TRAIN, WINDOW>(a, s);
+    case 2: return launch_mhsa16_as<2, CAUSAL, TRAIN, WINDOW>(a, s);
+    case 3: return launch_mhsa16_as<3, CAUSAL, TRAIN, WINDOW>(a, s);
+    case 4: return launch_mhsa16_as<4, CAUSAL, TRAIN, WINDOW>(a, s);
+    default: return launch_mhsa16_as<5, CAUSAL, TRAIN, WINDOW>(a, s);
   }
 }
 
@@ -529,12 +560,13 @@ int launch_mhsa_fused(const float* x, const float* w_in, const float* b_in, cons
   const bool train = qkv_out != nullptr || dr.thr != 0;
   {
     const long long items = (long long)a.n_groups * H, cus = stlt_device_cus();
-    stlt_prof_note("mhsa16 S=%lld L=%lld H=%lld d=%lld causal=%d train=%d item=%dx192 items=%lld wg=%lld rounds=%lld ksteps=%lld keyblocks=%d", (long long)S, (long long)L,
-                   (long long)H, (long long)d, causal, (int)train, a.rows_per_item, items, items < cus ? items : cus, (items + cus - 1) / cus, (long long)(d / 32), nkb);
+    stlt_prof_note("mhsa16 S=%lld L=%lld H=%lld d=%lld causal=%d train=%d item=%dx192 items=%lld wg=%lld rounds=%lld ksteps=%lld keyblocks=%d%s", (long long)S, (long long)L,
+                   (long long)H, (long long)d, causal, (int)train, a.rows_per_item, items, items < cus ? items : cus, (items + cus - 1) / cus, (long long)(d / 32), nkb, mhsa16_window(a.L, a.rows_per_item, causal != 0) ? "w" : "");
     stlt_prof_note_flops(6.0 * (double)(S * L) * (double)d * (double)d + 4.0 * (double)S * (double)H * (double)(L * L) * 64.0);
     stlt_prof_add_bytes(8.0 * (double)(S * L) * (double)d + 4.0 * (3.0 * d * d + 3.0 * d) + (double)(S * L));
   }
   if (train && !qkv_out) return stlt_set_error(STLT_EINVAL, "mhsa_fused: dropout needs the qkv output (training forward)");
-  if (causal) return train ? launch_mhsa16_nkb<true, true>(nkb, a, s) : launch_mhsa16_nkb<true, false>(nkb, a, s);
-  return train ? launch_mhsa16_nkb<false, true>(nkb, a, s) : launch_mhsa16_nkb<false, false>(nkb, a, s);
+  if (causal) return train ? launch_mhsa16_nkb<true, true, false>(nkb, a, s) : launch_mhsa16_nkb<true, false, false>(nkb, a, s);
+  if (mhsa16_window(a.L, a.rows_per_item, false)) return train ? launch_mhsa16_nkb<false, true, true>(nkb, a, s) : launch_mhsa16_nkb<false, false, true>(nkb, a, s);
+  return train ? launch_mhsa16_nkb<false, true, false>(nkb, a, s) : launch_mhsa16_nkb<false, false, false>(nkb, a, s);
 }

@@ -760,11 +760,16 @@ def test_mhsa_fused_every_sequence_length(pkg, L, causal):
     x, w, b, kpm = _mhsa_case(S, L, H, 1000 + L)
     xd, wd, bd, kd = x.to(DEV), w.to(DEV), b.to(DEV), kpm.to(DEV)
     rows = 128 // L * L
-    worst = 1
-    for blk in range(0, rows, 16):
-        first = (blk // L) * L // 16
-        last = blk // 16 if causal else ((min(blk + 15, rows - 1) // L + 1) * L - 1) // 16
-        worst = max(worst, last - first + 1)
+
+    def key_blocks(window):  # mhsa.hip mhsa16_key_blocks_as: 16-row key blocks from the block holding a sequence's first row, or from that row
+        worst = 1
+        for blk in range(0, rows, 16):
+            k0 = (blk // L) * L if window else (blk // L) * L // 16 * 16
+            last_row = blk + 15 if causal else (min(blk + 15, rows - 1) // L + 1) * L - 1
+            worst = max(worst, (last_row - k0) // 16 + 1)
+        return worst
+
+    worst = key_blocks(False) if causal else min(key_blocks(False), key_blocks(True))
     if worst > 5:
         with pytest.raises(pkg._lib.StltHipError):
             pkg.ops.mhsa_fused(xd, wd, bd, kd, H, causal=causal)
