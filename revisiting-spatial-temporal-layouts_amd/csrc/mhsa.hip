@@ -13,7 +13,7 @@
 namespace {
 
 #ifndef STLT_MHSA_ABLATE
-#define STLT_MHSA_ABLATE 0  // timing-only builds (wrong results): bit 0 no ctx stores (what keeping the attention output on chip for a fused out-projection could save at most)
+#define STLT_MHSA_ABLATE 0  // timing-only builds (wrong results): bit 0 no ctx stores (what keeping the attention output on chip for a fused out-projection could save at most); bit 2 no attention phase but its two barriers (the in-projection alone, accumulators kept alive): 5 749 against 6 077 us for 32 768 frames of 7 objects, 830 against 862 us for 1 024 clips of 32 frames (profiles/round6_mhsa_window_ab.txt)
 #endif
 #ifndef STLT_MHSA_LOADER
 #define STLT_MHSA_LOADER 2
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     const int my_row = rb * 16 + li;
     const bool row_ok = my_row < rows_here;
     const int q_seq = my_row / L, q_pos = my_row - q_seq * L;
-    {  // k, v -> LDS tiles; this row's key metadata: -1 = absent / padded, else (sequence in item << 8) | position
+    if (!(STLT_MHSA_ABLATE & 4)) {  // k, v -> LDS tiles; this row's key metadata: -1 = absent / padded, else (sequence in item << 8) | position
       const int base = my_row * 64;
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
 #pragma unroll
     for (int i = 0; i < NKB; ++i) {
       st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (blk_ok && i < n_kb) {
+      if (blk_ok && i < n_kb && !(STLT_MHSA_ABLATE & 4)) {
         const int krow_i = k0 + 16 * i + li;  // WINDOW: may lie past the tile's 128 rows (still inside the stage): masked below
         const float* krow = Kt + krow_i * 64;
         const int ksw = WINDOW ? (krow_i & 15) : li;
@@ -346,7 +346,10 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // attention barrier 2: the K tile is read (the loaders may refill its stage); q, k, v accumulators are dead
-    if (blk_ok) {
+    if (STLT_MHSA_ABLATE & 4) {
+#pragma unroll
+      for (int t = 0; t < 12; ++t) asm volatile("" :: "v"(acc[t]));  // the product is kept
+    } else if (blk_ok) {
       // mask + softmax: st[i][r] = score of key k0 + 16 i + 4 lg + r against query li
       float m = -1e30f;
 #pragma unroll
