@@ -9,11 +9,15 @@
 // 85.7 / 242.2 / 896.1, profiles/round4_mhsa_fused_ab.txt) and takes every other one.
 #include <cstdlib>
 #include "common.h"
+#include "wave_dpp.h"
 
 namespace {
 
 #ifndef STLT_MHSA_ABLATE
 #define STLT_MHSA_ABLATE 0  // timing-only builds (wrong results): bit 0 no ctx stores (what keeping the attention output on chip for a fused out-projection could save at most); bit 2 no attention phase but its two barriers (the in-projection alone, accumulators kept alive): 5 749 against 6 077 us for 32 768 frames of 7 objects, 830 against 862 us for 1 024 clips of 32 frames (profiles/round6_mhsa_window_ab.txt)
+#endif
+#ifndef STLT_MHSA_SWAP_REDUCE
+#define STLT_MHSA_SWAP_REDUCE 1  // 0: the softmax's two cross-group reductions through ds_bpermute shuffles (A/B builds)
 #endif
 #ifndef STLT_MHSA_LOADER
 #define STLT_MHSA_LOADER 2
@@ -64,7 +68,8 @@ struct Mhsa16Args {
 // rows of a query block are read as 16-row blocks starting AT the first row of its first query's sequence instead of at the 16-row block
 // holding that row.  The keys a block of 16 queries of 7-token frames can see span at most 28 rows: 2 blocks from the sequence's first row,
 // 3 from the aligned block (20 -> 15 key blocks per 126-row item, NKB 3 -> 2).  The LDS tiles are swizzled by (row & 15) and a block is 16
-// consecutive rows wherever it starts, so the reads stay conflict-free; rows past the 128-row tile are masked (and clamped for V).
+// consecutive rows wherever it starts, so the reads stay conflict-free; the launcher takes this form only when every block of every window
+// lies inside the 128-row tile (mhsa16_window).
 template <int NKB, bool CAUSAL, bool TRAIN, bool WINDOW>
 __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     for (int i = 0; i < NKB; ++i) {
       st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (blk_ok && i < n_kb && !(STLT_MHSA_ABLATE & 4)) {
-        const int krow_i = k0 + 16 * i + li;  // WINDOW: may lie past the tile's 128 rows (still inside the stage): masked below
+        const int krow_i = k0 + 16 * i + li;  // WINDOW: inside the tile's 128 rows (mhsa16_window checks the shape)
         const float* krow = Kt + krow_i * 64;
         const int ksw = WINDOW ? (krow_i & 15) : li;
 #pragma unroll
@@ -357,9 +362,9 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
         if (i < n_kb) {
           const int j0 = k0 + 16 * i + 4 * lg;
           int meta[4];
-          if (WINDOW) {
+          if (WINDOW) {  // 4-byte aligned only
 #pragma unroll
-            for (int r = 0; r < 4; ++r) meta[r] = j0 + r < FM ? kmeta[j0 + r] : -1;
+            for (int r = 0; r < 4; ++r) meta[r] = kmeta[j0 + r];
           } else {
             const int4 km = *reinterpret_cast<const int4*>(kmeta + j0);
             meta[0] = km.x; meta[1] = km.y; meta[2] = km.z; meta[3] = km.w;
@@ -372,8 +377,18 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
           }
         }
       }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      {  // over the four 16-lane groups (lanes ^ 16, ^ 32) on the permlane swaps: no LDS round trips on the phase's critical path
+        float pa, pb;
+        if (STLT_MHSA_SWAP_REDUCE) {
+          wave_pair16(m, pa, pb);
+          m = fmaxf(pa, pb);
+          wave_pair32(m, pa, pb);
+          m = fmaxf(pa, pb);
+        } else {
+          m = fmaxf(m, __shfl_xor(m, 16, 64));
+          m = fmaxf(m, __shfl_xor(m, 32, 64));
+        }
+      }
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < NKB; ++i) {
@@ -386,8 +401,18 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
           }
         }
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      {
+        float pa, pb;
+        if (STLT_MHSA_SWAP_REDUCE) {
+          wave_pair16(sum, pa, pb);
+          sum = pa + pb;
+          wave_pair32(sum, pa, pb);
+          sum = pa + pb;
+        } else {
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+        }
+      }
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
       // TRAIN: dropout of the probabilities, applied where a probability is consumed (attn.hip's element index:
       // ((query token * H + head) << 8) | key position; an unmasked key is in the query's sequence, so its position is its row minus
@@ -403,10 +428,9 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
         if (i < n_kb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int j_key = k0 + 16 * i + 4 * lg + r;
-            const int j = (WINDOW && j_key > FM - 1) ? FM - 1 : j_key;  // a row past the tile has probability 0: read a finite V row for it
+            const int j = k0 + 16 * i + 4 * lg + r;
             float pr = st[i][r];
-            if (TRAIN && a.dr.thr) pr = stlt_keep_k(a.dr.thr, drop_key, qidx | (uint64_t)((j_key - q_seq * L) & 0xff)) ? pr * a.dr.scale : 0.f;
+            if (TRAIN && a.dr.thr) pr = stlt_keep_k(a.dr.thr, drop_key, qidx | (uint64_t)((j - q_seq * L) & 0xff)) ? pr * a.dr.scale : 0.f;
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
               const float vv = Vt[j * 64 + (((cb * 4 + (li >> 2)) ^ (j & 15)) * 4) + (li & 3)];
@@ -436,8 +460,9 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
 
 // largest number of 16-key blocks a 16-query block of an item needs (host side; the kernel's NKB); window: blocks counted from the first
 // row of the block's first sequence instead of from the 16-row block holding it
-static int mhsa16_key_blocks_as(int L, int rows_per_item, bool causal, bool window, int* total = nullptr) {
+static int mhsa16_key_blocks_as(int L, int rows_per_item, bool causal, bool window, int* total = nullptr, bool* all_inside = nullptr) {
   int worst = 1, sum = 0;
+  bool inside = true;  // every key block within the item's 128-row K / V tiles
   for (int b = 0; b * 16 < rows_per_item; ++b) {
     const int seq_row0 = (b * 16 / L) * L;
     const int k0 = window ? seq_row0 : (seq_row0 & ~15);
@@ -449,8 +474,10 @@ static int mhsa16_key_blocks_as(int L, int rows_per_item, bool causal, bool wind
     const int n = ((last_row - k0) >> 4) + 1;
     if (n > worst) worst = n;
     sum += n;
+    if (k0 + 16 * n > FM) inside = false;
   }
   if (total) *total = sum;
+  if (all_inside) *all_inside = inside;
   return worst;
 }
 // STLT_MHSA_WINDOW=0: aligned key blocks everywhere (A/B runs); default: the window form where an item needs fewer key blocks with it
@@ -459,8 +486,9 @@ static bool mhsa16_window(int L, int rows_per_item, bool causal) {
   static const int on = [] { const char* e = getenv("STLT_MHSA_WINDOW"); return e ? atoi(e) : 1; }();
   if (!on || causal) return false;
   int total_w = 0, total_a = 0;
-  const int worst_w = mhsa16_key_blocks_as(L, rows_per_item, false, true, &total_w), worst_a = mhsa16_key_blocks_as(L, rows_per_item, false, false, &total_a);
-  return worst_w <= worst_a && total_w < total_a;
+  bool inside = false;
+  const int worst_w = mhsa16_key_blocks_as(L, rows_per_item, false, true, &total_w, &inside), worst_a = mhsa16_key_blocks_as(L, rows_per_item, false, false, &total_a);
+  return inside && worst_w <= worst_a && total_w < total_a;
 }
 static int mhsa16_key_blocks(int L, int rows_per_item, bool causal) {
   return mhsa16_key_blocks_as(L, rows_per_item, causal, mhsa16_window(L, rows_per_item, causal));

@@ -1,4 +1,4 @@
-// Wave-wide sums on the DPP / permlane data paths of gfx950 (included by rowwise.hip and by tools/wave_sum_check.hip).
+// Wave-wide sums on the DPP / permlane data paths of gfx950 (included by rowwise.hip, mhsa.hip and by tools/wave_sum_check.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -11,6 +11,18 @@
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// own value and the value of lane ^ 16 / lane ^ 32, in some order (enough for max and for a two-term sum, which are symmetric): after the
+// swap of two copies, one register holds the own value and the other the partner's in every lane
+__device__ __forceinline__ void wave_pair16(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void wave_pair32(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 #ifndef STLT_LN_DPP
 #define STLT_LN_DPP 1  // 0: the LayerNorm reductions through common.h's wave_sum (A/B builds)

@@ -14,11 +14,24 @@ __device__ __forceinline__ float butterfly_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void both_kernel(const float* __restrict__ in, float* __restrict__ dpp, float* __restrict__ ref) {
+// mode 0: the 64-lane sum; mode 1: max over lanes ^ 16, ^ 32 (mhsa.hip's softmax reductions on wave_pair16 / wave_pair32); mode 2: that sum
+__global__ __launch_bounds__(256) void both_kernel(const float* __restrict__ in, float* __restrict__ dpp, float* __restrict__ ref, int mode) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const float v = in[i];
-  dpp[i] = wave_sum_dpp(v);
-  ref[i] = butterfly_sum(v);
+  if (mode == 0) {
+    dpp[i] = wave_sum_dpp(v);
+    ref[i] = butterfly_sum(v);
+    return;
+  }
+  float a, b, x = v, y = v;
+  wave_pair16(x, a, b);
+  x = mode == 1 ? fmaxf(a, b) : a + b;
+  wave_pair32(x, a, b);
+  x = mode == 1 ? fmaxf(a, b) : a + b;
+  dpp[i] = x;
+  y = mode == 1 ? fmaxf(y, __shfl_xor(y, 16, 64)) : y + __shfl_xor(y, 16, 64);
+  y = mode == 1 ? fmaxf(y, __shfl_xor(y, 32, 64)) : y + __shfl_xor(y, 32, 64);
+  ref[i] = y;
 }
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
@@ -35,14 +48,16 @@ int main() {
   float *d_in, *d_a, *d_b;
   CHECK(hipMalloc(&d_in, n * 4)); CHECK(hipMalloc(&d_a, n * 4)); CHECK(hipMalloc(&d_b, n * 4));
   CHECK(hipMemcpy(d_in, h.data(), n * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(both_kernel, dim3(n / 256), dim3(256), 0, 0, d_in, d_a, d_b);
-  CHECK(hipGetLastError());
-  CHECK(hipMemcpy(a.data(), d_a, n * 4, hipMemcpyDeviceToHost));
-  CHECK(hipMemcpy(b.data(), d_b, n * 4, hipMemcpyDeviceToHost));
   long bad = 0, uniform_bad = 0;
-  for (int i = 0; i < n; ++i) {
-    if (memcmp(&a[i], &b[i], 4)) { if (bad < 5) printf("lane %d: dpp %.9g butterfly %.9g\n", i, a[i], b[i]); ++bad; }
-    if (memcmp(&a[i], &a[i & ~63], 4)) ++uniform_bad;  // every lane of a wave holds the same sum
+  for (int mode = 0; mode < 3; ++mode) {
+    hipLaunchKernelGGL(both_kernel, dim3(n / 256), dim3(256), 0, 0, d_in, d_a, d_b, mode);
+    CHECK(hipGetLastError());
+    CHECK(hipMemcpy(a.data(), d_a, n * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(b.data(), d_b, n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      if (memcmp(&a[i], &b[i], 4)) { if (bad < 5) printf("mode %d lane %d: swap/dpp %.9g shuffle %.9g\n", mode, i, a[i], b[i]); ++bad; }
+      if (mode == 0 && memcmp(&a[i], &a[i & ~63], 4)) ++uniform_bad;  // every lane of a wave holds the same sum
+    }
   }
   printf("{\"values\": %d, \"mismatches\": %ld, \"lanes_disagreeing_within_a_wave\": %ld}\n", n, bad, uniform_bad);
   return (bad || uniform_bad) ? 1 : 0;
