@@ -19,6 +19,9 @@ namespace {
 #ifndef STLT_MHSA_SWAP_REDUCE
 #define STLT_MHSA_SWAP_REDUCE 1  // 0: the softmax's two cross-group reductions through ds_bpermute shuffles (A/B builds)
 #endif
+#ifndef STLT_MHSA_EARLY_RESTART
+#define STLT_MHSA_EARLY_RESTART 0  // 1 (A/B builds): the next item's bias rows and first fragments requested right behind attention barrier 2 (the q / k / v accumulators are dead there), under the softmax and PV, instead of after the phase — measured slower: 6 131 against 6 060 us (32 768 frames of 7), 866 - 877 against 860 us (1 024 clips of 32 frames), profiles/round6_mhsa_window_ab.txt
+#endif
 #ifndef STLT_MHSA_LOADER
 #define STLT_MHSA_LOADER 2
 #endif
@@ -351,6 +354,10 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // attention barrier 2: the K tile is read (the loaders may refill its stage); q, k, v accumulators are dead
+    if (STLT_MHSA_EARLY_RESTART && step + 1 < total_steps) {  // next item: accumulators from its bias strip (published by the last k-step's barrier), first fragments
+      init_acc(c_it + 1);
+      read_phase(stage, 0, F[0]);
+    }
     if (STLT_MHSA_ABLATE & 4) {
 #pragma unroll
       for (int t = 0; t < 12; ++t) asm volatile("" :: "v"(acc[t]));  // the product is kept
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
     }
     ++c_it;
     c_kt = 0;
-    if (step + 1 < total_steps) {  // next item: accumulators from its bias strip (published by the last k-step's barrier), first fragments
+    if (!STLT_MHSA_EARLY_RESTART && step + 1 < total_steps) {
       init_acc(c_it);
       read_phase(stage, 0, F[0]);
     }
