@@ -137,6 +137,8 @@ def test_train_mode_two_rank_launch_line():
 def test_launch_bound_tool_prices_every_launch(mode):
     """tools/launch_bound.py (event-timed form; the rocprofv3 form is tools/collect_launch_bound.sh): one row per launch with the launcher's note,
     a bound and a ratio, and the step's sums."""
+    if os.environ.get("STLT_GEMM16") == "0" or os.environ.get("STLT_GEMM_SPLIT_BF16", "0") != "0":
+        pytest.skip("the table's expectations (small-tile products present, a note and a bound on every product) are the default dispatch's")
     r = subprocess.run([sys.executable, "tools/launch_bound.py", "--config", "cfg2", "--batch", "8", "--steps", "2", "--warmup", "3", "--mode", mode], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

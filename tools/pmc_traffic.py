@@ -17,8 +17,8 @@ def family(name: str) -> str:
     m = re.search(r"attn16_kernel<(\d), (true|false), (true|false)", name)
     if m:  # <NB, FULL, CAUSAL, SPLIT>: 16-row tiles, the kernel of the L <= 64 passes (temporal = causal)
         return "attn16_kernel/" + ("temporal" if m.group(3) == "true" else "spatial")
-    m = re.search(r"mhsa16_kernel<(\d), (true|false), (true|false)>", name)
-    if m:  # <NKB, CAUSAL, TRAIN>: the fused in-projection + attention kernel (temporal = causal)
+    m = re.search(r"mhsa16_kernel<(\d), (true|false), (true|false)(?:, (?:true|false))?>", name)
+    if m:  # <NKB, CAUSAL, TRAIN, WINDOW>: the fused in-projection + attention kernel (temporal = causal)
         return "mhsa16_kernel/" + ("temporal" if m.group(2) == "true" else "spatial")
     m = re.search(r"(gemm_nt_kernel<\d|gemm_fixup_kernel|[a-z_0-9]+_kernel)", name)
     return m.group(1) if m else name[:40]
