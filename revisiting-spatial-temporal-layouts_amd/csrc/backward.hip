@@ -5,10 +5,14 @@
 // The large products (dX = dY·W, dW = dYᵀ·X) run on the MFMA kernel of gemm.hip.
 #include <cstdlib>
 #include "common.h"
+#include "wave_dpp.h"
 
 namespace {
 
 constexpr int RW_WAVES = 4;  // waves per 256-thread block for the row-wise kernels
+#ifndef STLT_LN_BWD_PIPE
+#define STLT_LN_BWD_PIPE 1  // 0: a row's loads issued when its turn comes (A/B builds)
+#endif
 
 // ------------------------------------------------------------------ LayerNorm backward
 // y = LN(s) * w + b with s = a (+ b2).  Given dy: ds = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*w;
@@ -37,21 +41,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     wv[i] = e < d ? *reinterpret_cast<const f32x4*>(w + e) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float inv_d = 1.0f / (float)d;
+  // The waves are persistent at 2 per SIMD (136+ registers, 512 blocks), each walking ~7 rows whose work is one dependent chain (three row
+  // loads -> four wave-wide sums -> stores): the next row's loads are issued before the current row's arithmetic (STLT_LN_BWD_PIPE), and the
+  // sums run on DPP / permlane swaps (wave_dpp.h: the shuffle butterfly's bits without its 24 LDS round trips per row).
+  f32x4 na[NV], nb[NV], ng[NV];  // the next row as loaded: a, b2, dy
+  auto load_row = [&](int64_t row) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < d) {
+        na[i] = *reinterpret_cast<const f32x4*>(a + row * lda + e);
+        if (b2) nb[i] = *reinterpret_cast<const f32x4*>(b2 + row * ldb + e);
+        ng[i] = *reinterpret_cast<const f32x4*>(dy + row * lddy + e);
+      }
+    }
+  };
+  if (STLT_LN_BWD_PIPE && gw < M) load_row(gw);
   for (int64_t row = gw; row < M; row += n_waves) {
     const uint64_t drow = (dr.thr && drop_rows) ? (uint64_t)drop_rows[row] : (uint64_t)row;  // dropout masks follow the row's original position
-    f32x4 x[NV], g[NV];
+    f32x4 x[NV], g[NV], bcur[NV];
+    if (!STLT_LN_BWD_PIPE) load_row(row);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      x[i] = na[i];
+      bcur[i] = nb[i];
+      g[i] = ng[i];
+    }
+    if (STLT_LN_BWD_PIPE && row + n_waves < M) load_row(row + n_waves);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = (i * 64 + lane) * 4;
       if (e < d) {
-        x[i] = *reinterpret_cast<const f32x4*>(a + row * lda + e);
         if (b2) {
-          f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + row * ldb + e);
+          f32x4 bv = bcur[i];
           if (dr.thr && site_b2) bv = stlt_drop4(dr, site_b2, drow * d + e, bv);  // the forward added drop(b2)
           x[i] += bv;
         }
-        g[i] = *reinterpret_cast<const f32x4*>(dy + row * lddy + e);
         if (dr.thr && site_dy) g[i] = stlt_drop4(dr, site_dy, drow * d + e, g[i]);  // dropout on the LN output
         sum += (x[i].x + x[i].y) + (x[i].z + x[i].w);
       } else {
@@ -59,7 +85,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    const float mean = wave_sum(sum) * inv_d;
+    const float mean = wave_sum_dpp(sum) * inv_d;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -69,7 +95,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         q += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
       }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * inv_d + eps);
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -83,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         sgx += (g[i].x * x[i].x + g[i].y * x[i].y) + (g[i].z * x[i].z + g[i].w * x[i].w);
       }
     }
-    const float mg = wave_sum(sg) * inv_d, mgx = wave_sum(sgx) * inv_d;
+    const float mg = wave_sum_dpp(sg) * inv_d, mgx = wave_sum_dpp(sgx) * inv_d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = (i * 64 + lane) * 4;
