@@ -29,6 +29,7 @@
 // Bit-for-bit it is a different summation order than attn.hip (16-key blocks); both are tested against the same fp64 oracle.
 #include <cstdlib>
 #include "common.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -218,8 +219,7 @@ __global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2 && !DROP) ? 3 : 1) v
           m = fmaxf(m, st[kb][r]);
         }
       }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = groups_max(m);
       if (tail_pass) m = fmaxf(m, s_tail);
       float sum = 0.f;
 #pragma unroll
@@ -232,8 +232,7 @@ __global__ __launch_bounds__(64 * WAVES16, (TAIL && NB == 2 && !DROP) ? 3 : 1) v
           sum += p;
         }
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = groups_sum(sum);
       float p_tail = 0.f;
       if (tail_pass) {
         p_tail = s_tail > -1e29f ? __expf(s_tail - m) : 0.f;

@@ -18,6 +18,7 @@
 // slab w / H of the scratch buffer, which launch_reduce_slabs adds in fixed order: bitwise reproducible.
 #include <cstdlib>
 #include "common.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -164,8 +165,7 @@ __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const Bw
           m = fmaxf(m, st[kb][r]);
         }
       }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = groups_max(m);
       float sum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
@@ -177,8 +177,7 @@ __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const Bw
           sum += p;
         }
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = groups_sum(sum);
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
       float dsum = 0.f;
 #pragma unroll
@@ -202,8 +201,7 @@ __global__ __launch_bounds__(64 * waves_for(NB)) void attn_bwd16_kernel(const Bw
           dsum += p * g;
         }
       }
-      dsum += __shfl_xor(dsum, 16, 64);
-      dsum += __shfl_xor(dsum, 32, 64);
+      dsum = groups_sum(dsum);
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
         ds[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -11,6 +11,7 @@
 // for sequences of at most 48 tokens on either side.
 #include <cstdlib>
 #include "common.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -119,8 +120,7 @@ __global__ __launch_bounds__(64 * xwaves(NBQ, NBK)) void attn_bwdx16_kernel(cons
           m = fmaxf(m, st[kb][r]);
         }
       }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = groups_max(m);
       float sum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < NBK; ++kb) {
@@ -131,8 +131,7 @@ __global__ __launch_bounds__(64 * xwaves(NBQ, NBK)) void attn_bwdx16_kernel(cons
           sum += p;
         }
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = groups_sum(sum);
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
       float dsum = 0.f;
 #pragma unroll
@@ -154,8 +153,7 @@ __global__ __launch_bounds__(64 * xwaves(NBQ, NBK)) void attn_bwdx16_kernel(cons
           dsum += p * g;
         }
       }
-      dsum += __shfl_xor(dsum, 16, 64);
-      dsum += __shfl_xor(dsum, 32, 64);
+      dsum = groups_sum(dsum);
 #pragma unroll
       for (int kb = 0; kb < NBK; ++kb)
 #pragma unroll

@@ -384,17 +384,11 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
           }
         }
       }
-      {  // over the four 16-lane groups (lanes ^ 16, ^ 32) on the permlane swaps: no LDS round trips on the phase's critical path
-        float pa, pb;
-        if (STLT_MHSA_SWAP_REDUCE) {
-          wave_pair16(m, pa, pb);
-          m = fmaxf(pa, pb);
-          wave_pair32(m, pa, pb);
-          m = fmaxf(pa, pb);
-        } else {
-          m = fmaxf(m, __shfl_xor(m, 16, 64));
-          m = fmaxf(m, __shfl_xor(m, 32, 64));
-        }
+      if (STLT_MHSA_SWAP_REDUCE) {  // over the four 16-lane groups: permlane swaps, no LDS round trips on the phase's critical path
+        m = groups_max(m);
+      } else {
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
       }
       float sum = 0.f;
 #pragma unroll
@@ -408,17 +402,11 @@ __global__ __launch_bounds__(F_THREADS, 3) void mhsa16_kernel(const Mhsa16Args a
           }
         }
       }
-      {
-        float pa, pb;
-        if (STLT_MHSA_SWAP_REDUCE) {
-          wave_pair16(sum, pa, pb);
-          sum = pa + pb;
-          wave_pair32(sum, pa, pb);
-          sum = pa + pb;
-        } else {
-          sum += __shfl_xor(sum, 16, 64);
-          sum += __shfl_xor(sum, 32, 64);
-        }
+      if (STLT_MHSA_SWAP_REDUCE) {
+        sum = groups_sum(sum);
+      } else {
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
       }
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;  // fully masked row -> zeros
       // TRAIN: dropout of the probabilities, applied where a probability is consumed (attn.hip's element index:

@@ -1,4 +1,4 @@
-// Wave-wide sums on the DPP / permlane data paths of gfx950 (included by rowwise.hip, mhsa.hip and by tools/wave_sum_check.hip).
+// Wave-wide sums on the DPP / permlane data paths of gfx950 (included by rowwise.hip, backward.hip, mhsa.hip, the attention kernels and tools/wave_sum_check.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,6 +23,33 @@ __device__ __forceinline__ void wave_pair32(float v, float& a, float& b) {
   a = v;
   b = v;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// max / sum over the four 16-lane groups of a wave (lanes ^ 16, ^ 32): what the attention kernels' softmax needs per query column; the same
+// values, added / compared in the same pairs, as `v = op(v, __shfl_xor(v, 16)); v = op(v, __shfl_xor(v, 32))`, without the two LDS round trips
+#ifndef STLT_GROUPS_SWAP
+#define STLT_GROUPS_SWAP 1  // 0: through ds_bpermute shuffles (A/B builds)
+#endif
+__device__ __forceinline__ float groups_max(float v) {
+#if !STLT_GROUPS_SWAP
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+#endif
+  float a, b;
+  wave_pair16(v, a, b);
+  v = fmaxf(a, b);
+  wave_pair32(v, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float groups_sum(float v) {
+#if !STLT_GROUPS_SWAP
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+#endif
+  float a, b;
+  wave_pair16(v, a, b);
+  v = a + b;
+  wave_pair32(v, a, b);
+  return a + b;
 }
 #ifndef STLT_LN_DPP
 #define STLT_LN_DPP 1  // 0: the LayerNorm reductions through common.h's wave_sum (A/B builds)
